@@ -1,0 +1,280 @@
+#!/usr/bin/env python3
+"""Golden-vector generator (test infrastructure; runs ONLY in the build container).
+
+Imports the reference's own Python from /root/reference (read-only) under the five
+benign shims listed in SURVEY.md section 8c, feeds it seeded inputs and stores the
+inputs + the reference's outputs as small .npz fixtures under tests/golden/.
+Nothing of the reference's source travels: fixtures are data only.
+
+    python oracle/gen_golden.py [group ...]        # default: all groups
+
+The GPU box never runs this file (no /root/reference there); tests read the .npz.
+"""
+import collections
+import collections.abc
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(REPO, "tests", "golden")
+REF = "/root/reference"
+
+
+def load_reference():
+    sys.dont_write_bytecode = True
+    sys.modules["cv2"] = types.ModuleType("cv2")                       # shim 1: drawing only
+    ti = types.ModuleType("torchinfo"); ti.summary = lambda *a, **k: None
+    sys.modules["torchinfo"] = ti                                       # shim 2
+    pl = types.ModuleType("pytorch_lightning")
+    pl.LightningModule = nn.Module; pl.LightningDataModule = object
+    sys.modules["pytorch_lightning"] = pl                               # shim 3
+    collections.Iterable = collections.abc.Iterable                     # shim 4
+    torch.Tensor.cuda = lambda self, *a, **k: self                      # shim 5: no GPU here
+    nn.Module.cuda = lambda self, *a, **k: self
+    torch.cuda.FloatTensor = torch.FloatTensor
+    sys.path.insert(0, REF)
+    os.chdir(REF)                                                       # class-level open("dataset//pallete")
+    from LightningFunc import accuracy, losses
+    return losses, accuracy
+
+
+def npy(t):
+    return t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
+
+
+def save(name, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: npy(v) for k, v in arrays.items()})
+    print(f"wrote {path}  ({os.path.getsize(path)} B, {len(arrays)} arrays)")
+
+
+V4_ANCHORS = [[12, 16], [19, 36], [40, 28], [36, 75], [76, 55], [72, 146], [142, 110], [192, 243], [459, 401]]
+V4_MASKS = [[0, 1, 2], [3, 4, 5], [6, 7, 8]]
+
+
+def make_targets(g, B, per_img, C):
+    """SURVEY 8d config-2 recipe (draw order matters)."""
+    n = B * per_img
+    b = torch.arange(B).repeat_interleave(per_img).float()
+    cls = torch.randint(0, C, (n,), generator=g).float()
+    wh = torch.rand(n, 2, generator=g) * 0.48 + 0.02
+    xy = torch.rand(n, 2, generator=g) * (1 - wh)
+    return torch.cat([b[:, None], cls[:, None], xy, wh], 1)
+
+
+def assign_cases(G, C):
+    """name -> target [nT,6]; B=2.  Anchors are v4 scale-1 anchors scaled to the grid."""
+    g = torch.Generator().manual_seed(100 + G)
+    plain = make_targets(g, 2, 5, C)
+    dup = plain.clone()
+    dup[3, 0] = dup[1, 0]; dup[3, 2:6] = dup[1, 2:6] * torch.tensor([1.0, 1.0, 1.02, 0.98])  # same cell+anchor, other box
+    dup[3, 1] = (dup[1, 1] + 1) % C                                                         # other label -> multi-hot
+    dup[7, 0] = dup[1, 0]; dup[7, 2:6] = dup[1, 2:6]                                         # exact duplicate, third writer
+    tie = plain.clone()
+    tie[0, 4:6] = torch.tensor([1.0, 1.0]) * 1e-9       # all anchor IoUs ~0 and equal -> first index
+    oor = plain.clone(); oor[4, 2] = 1.0                # gi == G -> guard 1 trips for everybody
+    oorb = plain.clone(); oorb[2, 0] = 2.0              # b == B
+    lab = plain.clone(); lab[6, 1] = float(C)           # guard 2 trips, guard 1 passes
+    neg = plain.clone(); neg[5, 1] = -1.0               # label -1 wraps to C-1
+    empty = plain[:0].clone()
+    edge = plain.clone(); edge[0, 2:4] = torch.tensor([0.0, 0.999999]); edge[1, 2:4] = torch.tensor([0.5, 0.5])
+    return dict(plain=plain, dup=dup, tie=tie, oor=oor, oorb=oorb, lab=lab, neg=neg, empty=empty, edge=edge)
+
+
+def group_yolo_assign(losses, accuracy):
+    """G1: build_targets, all ten outputs, edge cases."""
+    C, A, B = 4, 3, 2
+    arrays = {}
+    for G in (13, 26):
+        stride = 416 / G
+        anchors = torch.FloatTensor([(aw / stride, ah / stride) for aw, ah in V4_ANCHORS[3:6]])
+        g = torch.Generator().manual_seed(7 + G)
+        pb = torch.rand(B, A, G, G, 4, generator=g) * torch.tensor([G, G, 6.0, 6.0])
+        pc = torch.rand(B, A, G, G, C, generator=g)
+        arrays[f"G{G}_anchors"] = anchors
+        arrays[f"G{G}_pred_boxes"] = pb
+        arrays[f"G{G}_pred_cls"] = pc
+        for name, tgt in assign_cases(G, C).items():
+            outs = accuracy.build_targets(pb, pc, tgt, anchors, 0.5)
+            arrays[f"G{G}_{name}_target"] = tgt
+            for k, v in zip(("iou_scores", "class_mask", "obj_mask", "noobj_mask", "tx", "ty", "tw", "th", "tcls", "tconf"), outs):
+                arrays[f"G{G}_{name}_{k}"] = v
+    save("yolo_assign", **arrays)
+
+
+class _Args:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def group_yolo_loss(losses, accuracy):
+    """G2: RegionLoss_v4 / v3 / v2 forward 7 scalars + d loss / d head at small shapes."""
+    arrays = {}
+    C, B = 4, 2
+    for coord in ("smooth_l1_loss", "mse_loss"):
+        for cls in ("bce_loss", "ce_loss"):
+            args = _Args(model_name="YOLOv4", cls_criterion=cls, coord_criterion=coord)
+            crit = losses.configure_loss(args, None, V4_ANCHORS, V4_MASKS, C, 416)
+            g = torch.Generator().manual_seed(11)
+            heads = [torch.randn(B, 3 * (5 + C), G, G, generator=g).requires_grad_() for G in (52, 26, 13)]
+            for case in ("plain", "dup", "oor", "lab", "empty", "neg"):
+                tgt = assign_cases(26, C)[case]
+                for h in heads:
+                    h.grad = None
+                out = crit(heads, tgt)
+                tag = f"v4_{coord}_{cls}_{case}"
+                if case in ("plain", "dup", "lab", "neg", "oor", "empty"):
+                    out["loss"].backward()
+                for k, v in out.items():
+                    arrays[f"{tag}_{k}"] = v
+                for i, h in enumerate(heads):
+                    arrays[f"{tag}_grad{i}"] = h.grad if h.grad is not None else torch.zeros_like(h)
+                arrays[f"{tag}_target"] = tgt
+            for i, h in enumerate(heads):
+                arrays[f"v4_head{i}"] = h
+    # saturated logits: BCE log clamp / backward eps (SURVEY appendix A caveat i)
+    args = _Args(model_name="YOLOv4", cls_criterion="bce_loss", coord_criterion="smooth_l1_loss")
+    crit = losses.configure_loss(args, None, V4_ANCHORS, V4_MASKS, C, 416)
+    g = torch.Generator().manual_seed(12)
+    heads = [(torch.randn(B, 3 * (5 + C), G, G, generator=g) * 30).requires_grad_() for G in (52, 26, 13)]
+    tgt = assign_cases(26, C)["plain"]
+    out = crit(heads, tgt); out["loss"].backward()
+    for k, v in out.items():
+        arrays[f"v4_sat_{k}"] = v
+    for i, h in enumerate(heads):
+        arrays[f"v4_sat_head{i}"] = h
+        arrays[f"v4_sat_grad{i}"] = h.grad
+    arrays["v4_sat_target"] = tgt
+
+    # v3: anchors pre-divided by the stride in the model ctor (YOLOV3.py:54-56), coarse -> fine
+    sample = [[(116, 90), (156, 198), (373, 326)], [(30, 61), (62, 45), (59, 119)], [(10, 13), (16, 30), (33, 23)]]
+    v3_anchors = [[(a[0] / s, a[1] / s) for a in sample[i]] for i, s in enumerate((32, 16, 8))]
+    args = _Args(model_name="YOLOv3", cls_criterion="bce_loss", coord_criterion="mse_loss")
+    crit = losses.configure_loss(args, None, v3_anchors, None, C, 416)
+    g = torch.Generator().manual_seed(13)
+    heads = [torch.randn(B, 3 * (5 + C), G, G, generator=g).requires_grad_() for G in (13, 26, 52)]
+    tgt = assign_cases(13, C)["dup"]
+    out = crit(heads, tgt); out["loss"].backward()
+    for k, v in out.items():
+        arrays[f"v3_{k}"] = v
+    for i, h in enumerate(heads):
+        arrays[f"v3_head{i}"] = h
+        arrays[f"v3_grad{i}"] = h.grad
+    arrays["v3_target"] = tgt
+    arrays["v3_anchors"] = np.asarray(v3_anchors, dtype=np.float64)
+
+    # v2: 5 anchors in grid units, C=20, config-1 shape [2,125,9,9] at img 288
+    v2_anchors = [(1.3221, 1.73145), (3.19275, 4.00944), (5.05587, 8.09892), (9.47112, 4.84053), (11.2364, 10.0071)]
+    for img in (288, 416):
+        G = img // 32
+        args = _Args(model_name="YOLOv2", cls_criterion="bce_loss", coord_criterion="smooth_l1_loss")
+        crit = losses.configure_loss(args, None, v2_anchors, None, 20, img)
+        g = torch.Generator().manual_seed(14 + img)
+        head = torch.randn(2, 125, G, G, generator=g).requires_grad_()
+        tgt = make_targets(g, 2, 4, 20)
+        out = crit(head, tgt); out["loss"].backward()
+        for k, v in out.items():
+            arrays[f"v2_{img}_{k}"] = v
+        arrays[f"v2_{img}_head"] = head
+        arrays[f"v2_{img}_grad"] = head.grad
+        arrays[f"v2_{img}_target"] = tgt
+    save("yolo_loss", **arrays)
+
+
+def config2_inputs():
+    """targets from seed 1 (after x), heads randn seed 2."""
+    g = torch.Generator().manual_seed(1)
+    _x = torch.rand(16, 3, 416, 416, generator=g)      # drawn first, as in the recipe
+    tgt = make_targets(g, 16, 7, 80)
+    g2 = torch.Generator().manual_seed(2)
+    heads = [torch.randn(16, 255, G, G, generator=g2) for G in (52, 26, 13)]
+    return heads, tgt
+
+
+def group_yolo_config2(losses, accuracy):
+    """G3: MultiScaleRegionLoss_v4 at the BASELINE config-2 shape: scalars + gradient digests."""
+    heads, tgt = config2_inputs()
+    heads = [h.requires_grad_() for h in heads]
+    args = _Args(model_name="YOLOv4", cls_criterion="bce_loss", coord_criterion="smooth_l1_loss")
+    crit = losses.configure_loss(args, None, V4_ANCHORS, V4_MASKS, 80, 416)
+    out = crit(heads, tgt)
+    out["loss"].backward()
+    arrays = {f"out_{k}": v for k, v in out.items()}
+    arrays["target"] = tgt
+    for i, h in enumerate(heads):
+        gr = h.grad
+        arrays[f"head{i}_sum"] = h.detach().double().sum()
+        arrays[f"head{i}_first"] = h.detach().flatten()[:64]
+        arrays[f"grad{i}_sum"] = gr.double().sum()
+        arrays[f"grad{i}_abssum"] = gr.double().abs().sum()
+        arrays[f"grad{i}_sqsum"] = (gr.double() ** 2).sum()
+        nz = gr.flatten().nonzero().flatten()
+        arrays[f"grad{i}_nnz"] = torch.tensor(nz.numel())
+        # conf plane of image 0 / anchor 0 and the 64 largest-magnitude entries (index + value)
+        G = h.shape[2]
+        arrays[f"grad{i}_confplane"] = gr.view(16, 3, 85, G, G)[0, 0, 4]
+        top = gr.flatten().abs().topk(64)[1].sort()[0]
+        arrays[f"grad{i}_top_idx"] = top
+        arrays[f"grad{i}_top_val"] = gr.flatten()[top]
+    save("yolo_config2", **arrays)
+
+
+def group_iou(losses, accuracy):
+    """G4: the IoU family on 256 random valid boxes (+ degenerate rows)."""
+    g = torch.Generator().manual_seed(21)
+    n = 256
+    def boxes_xywh(scale):
+        wh = torch.rand(n, 2, generator=g) * 0.5 * scale + 0.01 * scale
+        xy = torch.rand(n, 2, generator=g) * scale
+        return torch.cat([xy, wh], 1)
+    a, b = boxes_xywh(416.0), boxes_xywh(416.0)
+    b[:32] = a[:32] * (1 + 0.1 * torch.rand(32, 4, generator=g))   # overlapping pairs
+    b[32:40] = a[32:40]                                            # identical
+    def to_xyxy(x):
+        return torch.cat([x[:, :2] - x[:, 2:] / 2, x[:, :2] + x[:, 2:] / 2], 1)
+    ax, bx = to_xyxy(a), to_xyxy(b)
+    arrays = dict(a_xywh=a, b_xywh=b, a_xyxy=ax, b_xyxy=bx)
+    arrays["bbox_iou_xyxy"] = accuracy.bbox_iou(ax, bx, x1y1x2y2=True)
+    arrays["bbox_iou_xywh"] = accuracy.bbox_iou(a, b, x1y1x2y2=False)
+    arrays["bbox_iou_bcast"] = accuracy.bbox_iou(ax[0:1], bx, x1y1x2y2=True)
+    for mode, kw in (("iou", {}), ("giou", dict(GIoU=True)), ("diou", dict(DIoU=True)), ("ciou", dict(CIoU=True))):
+        arrays[f"v5_{mode}_xywh"] = accuracy.bbox_iou_v5(a.t(), b.t(), x1y1x2y2=False, **kw)
+        arrays[f"v5_{mode}_xyxy"] = accuracy.bbox_iou_v5(ax.t(), bx.t(), x1y1x2y2=True, **kw)
+    anchors = torch.FloatTensor([(36 / 16, 75 / 16), (76 / 16, 55 / 16), (72 / 16, 146 / 16)])
+    gwh = a[:, 2:] / 16
+    arrays["wh_anchors"] = anchors
+    arrays["wh_gwh"] = gwh
+    arrays["wh_iou"] = torch.stack([accuracy.bbox_wh_iou(an, gwh) for an in anchors])
+    an = ax / 416.0; bn = bx / 416.0
+    arrays["corner_a"] = an; arrays["corner_b"] = bn
+    arrays["corner_iou"] = accuracy.iou(an, bn)
+    rl = losses.RetinaNetLoss(None, losses.focal_loss, nn.SmoothL1Loss, 4, 600)
+    arrays["retina_box_iou_xywh"] = rl.box_iou(a[:64], b[:16], order="xywh")
+    arrays["retina_box_iou_xyxy"] = rl.box_iou(ax[:64], bx[:16], order="xyxy")
+    save("iou", **arrays)
+
+
+GROUPS = {
+    "yolo_assign": group_yolo_assign,
+    "yolo_loss": group_yolo_loss,
+    "yolo_config2": group_yolo_config2,
+    "iou": group_iou,
+}
+
+
+def main(argv):
+    names = argv or list(GROUPS)
+    losses, accuracy = load_reference()
+    torch.set_num_threads(8)
+    for n in names:
+        GROUPS[n](losses, accuracy)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])
