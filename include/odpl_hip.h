@@ -1,0 +1,106 @@
+/*
+ * odpl_hip.h -- C ABI of libodpl_hip.so: the MI355X (gfx950) detector-math library.
+ *
+ * The reference (Leyan529/ObjectDetectionPL) has no FFI: its boundary is the Python API
+ * `LightningFunc.losses.configure_loss(...)` -> nn.Module.forward(output, target) -> dict
+ * (losses.py:9-35) plus the free functions of LightningFunc/accuracy.py.  Each entry point
+ * below replaces the eager-torch op sequence of one of those functions; the file:line it
+ * replaces is cited per entry.  The Python host in objectdetectionpl_amd/ binds these with
+ * ctypes (see INTEGRATION.md for the stub a reference maintainer would add).
+ *
+ * Conventions
+ *   - plain pointers + sizes only; every pointer is a DEVICE pointer unless named host_*;
+ *   - all tensors are dense, contiguous, row-major, fp32 unless stated; 16-byte aligned bases;
+ *   - `stream` is a hipStream_t passed as void*; every entry only ENQUEUES work on it
+ *     (no allocation, no synchronisation, graph-capturable);
+ *   - return 0 on success, ODPL_EINVAL (-1) on a bad argument, otherwise the hipError_t
+ *     of the failing enqueue.  Data errors follow the reference: out-of-range labels and
+ *     coordinates are not errors, they trip the reference's guards (accuracy.py:340-367).
+ */
+#ifndef ODPL_HIP_H
+#define ODPL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ODPL_ABI_VERSION 1
+#define ODPL_EINVAL (-1)
+#define ODPL_MAX_SCALES 4
+#define ODPL_MAX_ANCHORS 8
+
+/* coord_criterion (losses.py:17-18) and cls_criterion (losses.py:12-14) selectors */
+#define ODPL_COORD_MSE 0
+#define ODPL_COORD_SMOOTH_L1 1
+#define ODPL_CLS_BCE 0
+#define ODPL_CLS_CE 1
+
+int odpl_abi_version(void);
+
+/* ---- YOLO v2/v3/v4 region loss: losses.py:475-905 + accuracy.py:305-380 ------------------ */
+
+typedef struct {
+    const float* head;              /* [B, A*(5+C), G, G] raw head tensor, NCHW as the conv wrote it */
+    float* grad;                    /* d loss / d head, same shape; NULL = forward only (validation) */
+    int32_t G;                      /* grid size */
+    int32_t A;                      /* anchors of this scale (<= ODPL_MAX_ANCHORS) */
+    float anchor_w[ODPL_MAX_ANCHORS];   /* scaled anchors, grid units: f32(double(aw)/double(img/G)), */
+    float anchor_h[ODPL_MAX_ANCHORS];   /* the host table of losses.py:499-503 */
+} odpl_yolo_scale_t;
+
+typedef struct {
+    int32_t B;                      /* images in the batch */
+    int32_t C;                      /* classes */
+    int32_t nT;                     /* rows of `target` */
+    int32_t nscales;                /* 1 (v2) .. 3 (v3/v4) */
+    int32_t coord_mode;             /* ODPL_COORD_* */
+    int32_t cls_mode;               /* ODPL_CLS_* */
+    int32_t average;                /* 1: divide every output by nscales (losses.py:616-623); 0: v2 */
+    float ignore_thres;             /* 0.5, losses.py:483 */
+    float obj_scale;                /* 1,   losses.py:487 */
+    float noobj_scale;              /* 100, losses.py:488 */
+    const float* target;            /* [nT,6] (img, cls, x, y, w, h) normalised; may be NULL if nT==0 */
+    odpl_yolo_scale_t scale[ODPL_MAX_SCALES];
+} odpl_yolo_loss_desc_t;
+
+/* Bytes of scratch `odpl_yolo_region_loss` needs for this descriptor (host-side arithmetic only). */
+size_t odpl_yolo_region_loss_workspace_bytes(const odpl_yolo_loss_desc_t* desc);
+
+/*
+ * Replaces MultiScaleRegionLoss_v4.forward (losses.py:583-634), MultiScaleRegionLoss_v3.forward
+ * (744-795) and RegionLoss_v2.forward (830-905) INCLUDING their autograd backward:
+ * target assignment (accuracy.py:305-380), the seven loss terms, and d loss/d head for a unit
+ * upstream gradient, in one pass over the head tensors.
+ *   out7        [7]  loss, Localization, Size, Conf, Classification, Conf_obj, Conf_noobj
+ *   out_scales  [nscales*7] the per-scale 7-tuples before accumulation (may be NULL)
+ *   out_counts  [nscales*8] int32: nObj, nNoobj, guard1_tripped, guard2_tripped, status, 0,0,0 (may be NULL)
+ */
+int odpl_yolo_region_loss(const odpl_yolo_loss_desc_t* desc, void* workspace, size_t workspace_bytes,
+                          float* out7, float* out_scales, int32_t* out_counts, void* stream);
+
+/*
+ * autograd glue: grad[i] *= *scale unless *scale == 1.0f (decided on the device, no host sync).
+ * Used by the backward of the fused loss, whose gradient was produced for a unit upstream gradient.
+ */
+int odpl_scale_inplace_if_not_one(float* grad, size_t n, const float* scale, void* stream);
+
+/*
+ * Drop-in for accuracy.build_targets (accuracy.py:305-380): the reference's ten dense outputs.
+ *   pred_boxes [B,A,G,G,4], pred_cls [B,A,G,G,C], target [nT,6], anchors [A,2] (device, grid units)
+ *   obj_mask/noobj_mask uint8 [B,A,G,G]; iou_scores,class_mask,tx,ty,tw,th,tconf f32 [B,A,G,G];
+ *   tcls f32 [B,A,G,G,C].  `state` is int32 scratch [B*A*G*G].  status: int32[8] (device) as out_counts.
+ */
+int odpl_yolo_build_targets(const float* pred_boxes, const float* pred_cls, const float* target,
+                            const float* anchors, int32_t B, int32_t A, int32_t G, int32_t C, int32_t nT,
+                            float ignore_thres, int32_t* state,
+                            float* iou_scores, float* class_mask, uint8_t* obj_mask, uint8_t* noobj_mask,
+                            float* tx, float* ty, float* tw, float* th, float* tcls, float* tconf,
+                            int32_t* status, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ODPL_HIP_H */

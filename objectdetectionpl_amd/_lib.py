@@ -1,0 +1,87 @@
+"""ctypes binding of libodpl_hip.so (C ABI: include/odpl_hip.h).  Fails loudly when absent."""
+import ctypes
+import os
+from ctypes import POINTER, c_float, c_int32, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libodpl_hip.so")
+
+MAX_SCALES = 4
+MAX_ANCHORS = 8
+COORD_MODES = {"mse_loss": 0, "smooth_l1_loss": 1}
+CLS_MODES = {"bce_loss": 0, "ce_loss": 1}
+
+
+class OdplError(RuntimeError):
+    pass
+
+
+class YoloScale(ctypes.Structure):
+    _fields_ = [("head", c_void_p), ("grad", c_void_p), ("G", c_int32), ("A", c_int32),
+                ("anchor_w", c_float * MAX_ANCHORS), ("anchor_h", c_float * MAX_ANCHORS)]
+
+
+class YoloLossDesc(ctypes.Structure):
+    _fields_ = [("B", c_int32), ("C", c_int32), ("nT", c_int32), ("nscales", c_int32),
+                ("coord_mode", c_int32), ("cls_mode", c_int32), ("average", c_int32),
+                ("ignore_thres", c_float), ("obj_scale", c_float), ("noobj_scale", c_float),
+                ("target", c_void_p), ("scale", YoloScale * MAX_SCALES)]
+
+
+_lib = None
+
+# name -> (restype, argtypes); every symbol include/odpl_hip.h declares must be listed here
+# (tests/test_abi.py parses the header and checks both directions).
+SIGNATURES = {
+    "odpl_abi_version": (c_int32, []),
+    "odpl_yolo_region_loss_workspace_bytes": (c_size_t, [POINTER(YoloLossDesc)]),
+    "odpl_yolo_region_loss": (c_int32, [POINTER(YoloLossDesc), c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "odpl_scale_inplace_if_not_one": (c_int32, [c_void_p, c_size_t, c_void_p, c_void_p]),
+    "odpl_yolo_build_targets": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                          c_int32, c_float, c_void_p] + [c_void_p] * 10 + [c_void_p, c_void_p]),
+}
+
+
+def lib():
+    """The loaded library; raises OdplError (never falls back) when it is missing or stale."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OdplError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"or `make -C objectdetectionpl_amd/csrc` (hipcc --offload-arch=gfx950). "
+                f"objectdetectionpl_amd has no CPU fallback.")
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(l, name)
+            except AttributeError as e:
+                raise OdplError(f"{LIB_PATH} does not export {name}; rebuild the library") from e
+            fn.restype = res
+            fn.argtypes = args
+        if l.odpl_abi_version() != 1:
+            raise OdplError("libodpl_hip.so ABI version mismatch; rebuild")
+        _lib = l
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        raise OdplError(f"{what} failed with code {code}" + (" (bad argument)" if code == -1 else " (hipError_t)"))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def current_stream(device):
+    import torch
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise OdplError("objectdetectionpl_amd runs on the HIP device only (tensor is on "
+                            f"{t.device}); there is no CPU fallback -- move inputs to cuda")

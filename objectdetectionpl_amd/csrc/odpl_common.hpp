@@ -1,0 +1,86 @@
+// Shared device helpers for libodpl_hip (gfx950 only; wave = 64 lanes).
+// Built with -ffp-contract=off: index-feeding arithmetic (anchor IoU, cell indices) must round
+// exactly like the reference's separately-rounded fp32 torch ops.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define ODPL_WAVE 64
+
+#define ODPL_HIP_TRY(expr)                        \
+    do {                                          \
+        hipError_t _e = (expr);                   \
+        if (_e != hipSuccess) return (int)_e;     \
+    } while (0)
+
+namespace odpl {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// Block-wide sum of N floats per thread; result valid in thread 0. `sh` holds N*(blockDim/64) floats.
+// Fixed shuffle tree + fixed wave order => bitwise reproducible run to run.
+template <int N>
+__device__ __forceinline__ void block_sum(float (&v)[N], float* sh) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = wave_sum(v[i]);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) sh[wv * N + i] = v[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            float a = sh[i];
+            for (int w = 1; w < nw; ++w) a += sh[w * N + i];
+            v[i] = a;
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ float sigmoidf_(float z) { return 1.0f / (1.0f + expf(-z)); }
+
+// nn.BCELoss element (log clamped at -100; ATen uses log1p(-p) for the negative branch).
+__device__ __forceinline__ float bce_elem(float p, float t) {
+    return -(t * fmaxf(logf(p), -100.0f) + (1.0f - t) * fmaxf(log1pf(-p), -100.0f));
+}
+// d BCE / d logit through sigmoid, following autograd literally:
+// binary_cross_entropy_backward = (p - t) / max((1-p)p, 1e-12) * g ; sigmoid_backward = * (1-p) * p
+__device__ __forceinline__ float bce_grad_logit(float p, float t, float g) {
+    const float gp = (p - t) / fmaxf((1.0f - p) * p, 1e-12f) * g;
+    return gp * (1.0f - p) * p;
+}
+
+// coord criterion element + derivative: SmoothL1 (beta = 1) or MSE
+__device__ __forceinline__ float coord_elem(float d, int smooth_l1) {
+    if (smooth_l1) {
+        const float a = fabsf(d);
+        return a < 1.0f ? 0.5f * d * d : a - 0.5f;
+    }
+    return d * d;
+}
+__device__ __forceinline__ float coord_deriv(float d, int smooth_l1) {
+    if (smooth_l1) return fabsf(d) < 1.0f ? d : (d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f));
+    return 2.0f * d;
+}
+
+// torch `.long()` of an fp32 value: truncate toward zero.
+__device__ __forceinline__ long long trunc_ll(float v) { return (long long)v; }
+
+}  // namespace odpl

@@ -1,0 +1,495 @@
+// YOLO v2/v3/v4 region loss for MI355X (gfx950): target assignment + the seven loss terms +
+// d loss / d head, replacing losses.py:475-905 and accuracy.py:305-380 of the reference.
+//
+// Data layout in HBM.  The head tensor stays exactly as the 1x1 conv wrote it: [B, A*(5+C), G, G]
+// = R rows of G*G contiguous floats, row q = (b*A + a)*(5+C) + c.  The reference's
+// permute(0,1,3,4,2).contiguous() copy (losses.py:517-522) is never made.
+//
+// What the loss touches.  Given the assignment, every term is local to a cell, and all terms but the
+// confidence BCE live on the nObj <= nT "obj" cells only (losses.py:557-564).  So per call:
+//   assign   (1 workgroup / scale)  targets -> int32 cell-state map {-1 noobj, 0 ignored, t+1 obj},
+//                                   per-winner records (tx,ty,tw,th, class bitset, raster rank), counts
+//   dense    (one launch, all scales) "conf" blocks read the confidence row of every (b,a) plane + the
+//                                   state map and write its gradient; "fill" blocks stream zeros into the
+//                                   other 4+C rows of the gradient.  HBM-write bound: this is the kernel
+//                                   the roofline figure is quoted on.
+//   obj      (1 workgroup / target) gathers the 5+C logits of each obj cell (stride G*G), writes their
+//                                   gradients over the zeros, partial sums for x,y,w,h,cls and "Size"
+//   finalize (1 workgroup)          fixed-order reduction -> the reference's 7 scalars per scale and total
+// No atomics on floats anywhere: results are bitwise reproducible run to run.
+#include "odpl_common.hpp"
+#include "odpl_yolo_dev.hpp"
+#include "../../include/odpl_hip.h"
+
+namespace {
+using namespace odpl;
+
+constexpr int kAssignThreads = 1024;
+constexpr int kDenseThreads = 256;
+constexpr int kObjThreads = 128;
+constexpr int kFillF4PerBlock = 2048;   // 32 KiB of zeros per fill block (8 float4 stores / thread)
+
+struct Scale {
+    const float* head;
+    float* grad;
+    int* state;          // [B*A*G2]
+    float* rec;          // [nT*4]   tx,ty,tw,th of target t (meaningful for winners)
+    int* tcell;          // [nT]     linear cell (b,a,j,i) if target t owns its cell, else -1
+    int* trank;          // [nT]     raster rank of the cell among obj cells (winners)
+    unsigned* bits;      // [nT*W]   class bitset of the winner's cell (multi-hot on shared cells)
+    int* counts;         // [8]
+    float* conf_part;    // [conf_nblk*2]  (sum obj BCE, sum noobj BCE)
+    float* obj_part;     // [nT*8]   lx, ly, lw, lh, lcls, size, -, -
+    int G, G2, A;
+    int conf_blk0, conf_blk_per_row, conf_nblk, conf_vec;
+    int fill_blk0, fill_nblk, rows_per_fill_blk;
+    float aw[ODPL_MAX_ANCHORS], ah[ODPL_MAX_ANCHORS];
+};
+
+struct Params {
+    Scale s[ODPL_MAX_SCALES];
+    const float* target;
+    int nscales, B, C, CH, nT, W;
+    int coord_sl1, cls_mode, average;
+    float ignore_thres, obj_scale, noobj_scale, inv_S;
+    float* out7;
+    float* out_scales;
+    int* out_counts;
+};
+
+__global__ __launch_bounds__(kAssignThreads) void yolo_assign_kernel(const Params P) {
+    const Scale& S = P.s[blockIdx.x];
+    const int tid = threadIdx.x, nT = P.nT, G = S.G, A = S.A, B = P.B, C = P.C, W = P.W;
+    __shared__ int sh_i[2 * (kAssignThreads / 64)];
+
+    int f1 = 0, f2 = 0, bad = 0;
+    for (int t = tid; t < nT; t += kAssignThreads) {
+        const TDec d = decode_target(P.target + (size_t)t * 6, G, A, S.aw, S.ah, P.ignore_thres);
+        f1 |= (d.b >= B) | (d.best >= A) | (d.gj >= G) | (d.gi >= G);      // accuracy.py:340-343
+        f2 |= (d.lab >= C);                                               // accuracy.py:365
+        bad |= (d.b < -B) | (d.gj < -G) | (d.gi < -G) | (d.lab < -C);
+        S.tcell[t] = -1; S.trank[t] = 0;
+        for (int w = 0; w < W; ++w) S.bits[(size_t)t * W + w] = 0u;
+    }
+    const int g1 = __syncthreads_or(f1);
+    const int g2 = __syncthreads_or(f2) | g1;
+    const int st = __syncthreads_or(bad);
+
+    int left = 0, became = 0;
+    for (int t = tid; t < nT; t += kAssignThreads) {
+        const TDec d = decode_target(P.target + (size_t)t * 6, G, A, S.aw, S.ah, P.ignore_thres);
+        long long b = d.b, gj = d.gj, gi = d.gi;
+        const bool upper_ok = (d.b < B) & (d.gj < G) & (d.gi < G);       // per-target guard, accuracy.py:354-356
+        const bool ok = wrap_idx(b, B) & wrap_idx(gj, G) & wrap_idx(gi, G);
+        if (!ok) continue;
+        if (!g1) {                                                        // accuracy.py:344-346
+            const int cell = (((int)b * A + d.best) * G + (int)gj) * G + (int)gi;
+            const int old = atomicMax(&S.state[cell], t + 1);
+            left += (old == -1); became += (old < 1);
+        }
+        if (upper_ok) {                                                   // accuracy.py:349-358
+            for (int a = 0; a < A; ++a) if ((d.over >> a) & 1u) {
+                const int cell = (((int)b * A + a) * G + (int)gj) * G + (int)gi;
+                const int old = atomicMax(&S.state[cell], 0);
+                left += (old == -1);
+            }
+        }
+    }
+    __syncthreads();
+    if (!g1) {
+        for (int t = tid; t < nT; t += kAssignThreads) {
+            const TDec d = decode_target(P.target + (size_t)t * 6, G, A, S.aw, S.ah, P.ignore_thres);
+            long long b = d.b, gj = d.gj, gi = d.gi, lab = d.lab;
+            if (!(wrap_idx(b, B) & wrap_idx(gj, G) & wrap_idx(gi, G))) continue;
+            const int cell = (((int)b * A + d.best) * G + (int)gj) * G + (int)gi;
+            const int w = __hip_atomic_load(&S.state[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1;
+            if (w == t) {                                                 // last writer in row order wins
+                S.tcell[t] = cell;
+                float* r = S.rec + (size_t)t * 4;
+                if (!g2) {                                                // accuracy.py:368-372
+                    r[0] = d.gx - floorf(d.gx);
+                    r[1] = d.gy - floorf(d.gy);
+                    r[2] = logf(d.gw / S.aw[d.best] + 1e-16f);
+                    r[3] = logf(d.gh / S.ah[d.best] + 1e-16f);
+                } else { r[0] = r[1] = r[2] = r[3] = 0.f; }
+            }
+            if (!g2 && wrap_idx(lab, C))                                  // accuracy.py:374, multi-hot
+                atomicOr(&S.bits[(size_t)w * W + (int)(lab >> 5)], 1u << (int)(lab & 31));
+        }
+    }
+    __syncthreads();
+    // raster rank of every obj cell (order of pred_boxes[..., 2:4][obj_mask], losses.py:568)
+    for (int t = tid; t < nT; t += kAssignThreads) {
+        const int c = S.tcell[t];
+        if (c < 0) continue;
+        int r = 0;
+        for (int u = 0; u < nT; ++u) { const int cu = S.tcell[u]; r += (cu >= 0) & (cu < c); }
+        S.trank[t] = r;
+    }
+    // counts
+    left = wave_sum_i(left); became = wave_sum_i(became);
+    if ((tid & 63) == 0) { sh_i[(tid >> 6) * 2] = left; sh_i[(tid >> 6) * 2 + 1] = became; }
+    __syncthreads();
+    if (tid == 0) {
+        int L = 0, Bc = 0;
+        for (int w = 0; w < kAssignThreads / 64; ++w) { L += sh_i[w * 2]; Bc += sh_i[w * 2 + 1]; }
+        S.counts[0] = Bc;                       // nObj
+        S.counts[1] = B * A * S.G2 - L;         // nNoobj
+        S.counts[2] = g1 ? 1 : 0;
+        S.counts[3] = g2 ? 1 : 0;
+        S.counts[4] = st ? 1 : 0;
+        S.counts[5] = S.counts[6] = S.counts[7] = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dense kernel: confidence rows + zero fill of the rest of the gradient
+
+__device__ __forceinline__ void conf_cell(float z, int st, float w_obj, float w_noobj, float& g, float& lo, float& ln) {
+    const float p = sigmoidf_(z);
+    g = 0.f;
+    if (st > 0) {                                   // obj: BCE(p, 1)   losses.py:561
+        lo += -fmaxf(logf(p), -100.0f);
+        g = bce_grad_logit(p, 1.0f, w_obj);
+    } else if (st < 0) {                            // noobj: BCE(p, 0) losses.py:562
+        ln += -fmaxf(log1pf(-p), -100.0f);
+        g = bce_grad_logit(p, 0.0f, w_noobj);
+    }                                               // st == 0: ignored (anchor IoU > thres)
+}
+
+__device__ __forceinline__ void fill_zero(float* __restrict__ base, size_t lo, size_t hi) {
+    // zero base[lo, hi); base is 16-byte aligned, lo/hi arbitrary element offsets
+    const int tid = threadIdx.x;
+    size_t lo4 = (lo + 3) & ~(size_t)3; if (lo4 > hi) lo4 = hi;
+    size_t hi4 = hi & ~(size_t)3; if (hi4 < lo4) hi4 = lo4;
+    if ((size_t)tid < lo4 - lo) base[lo + tid] = 0.f;      // <= 3 head elements
+    if ((size_t)tid < hi - hi4) base[hi4 + tid] = 0.f;     // <= 3 tail elements
+    float4* p4 = reinterpret_cast<float4*>(base);
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (size_t i = lo4 / 4 + tid; i < hi4 / 4; i += kDenseThreads) p4[i] = z;
+}
+
+__global__ __launch_bounds__(kDenseThreads) void yolo_dense_kernel(const Params P) {
+    __shared__ float sh[2 * (kDenseThreads / 64)];
+    const int bid = blockIdx.x, tid = threadIdx.x;
+    int si = 0;
+    bool is_conf = false;
+    for (int i = 0; i < P.nscales; ++i) {
+        const Scale& T = P.s[i];
+        if (bid >= T.conf_blk0 && bid < T.conf_blk0 + T.conf_nblk) { si = i; is_conf = true; }
+        if (bid >= T.fill_blk0 && bid < T.fill_blk0 + T.fill_nblk) { si = i; is_conf = false; }
+    }
+    const Scale& S = P.s[si];
+    const int G2 = S.G2, CH = P.CH;
+    if (is_conf) {
+        const int local = bid - S.conf_blk0;
+        const int plane = local / S.conf_blk_per_row, part = local - plane * S.conf_blk_per_row;
+        const size_t rowoff = ((size_t)plane * CH + 4) * G2;
+        const float* __restrict__ z = S.head + rowoff;
+        float* __restrict__ g = S.grad ? S.grad + rowoff : nullptr;
+        const int* __restrict__ st = S.state + (size_t)plane * G2;
+        const float w_obj = P.obj_scale * P.inv_S / (float)S.counts[0];
+        const float w_noobj = P.noobj_scale * P.inv_S / (float)S.counts[1];
+        float acc[2] = {0.f, 0.f};
+        if (S.conf_vec) {
+            const int i4 = part * kDenseThreads + tid;
+            if (i4 < G2 / 4) {
+                const float4 zv = reinterpret_cast<const float4*>(z)[i4];
+                const int4 sv = reinterpret_cast<const int4*>(st)[i4];
+                float4 gv;
+                conf_cell(zv.x, sv.x, w_obj, w_noobj, gv.x, acc[0], acc[1]);
+                conf_cell(zv.y, sv.y, w_obj, w_noobj, gv.y, acc[0], acc[1]);
+                conf_cell(zv.z, sv.z, w_obj, w_noobj, gv.z, acc[0], acc[1]);
+                conf_cell(zv.w, sv.w, w_obj, w_noobj, gv.w, acc[0], acc[1]);
+                if (g) reinterpret_cast<float4*>(g)[i4] = gv;
+            }
+        } else {
+            const int i = part * kDenseThreads + tid;
+            if (i < G2) {
+                float gv;
+                conf_cell(z[i], st[i], w_obj, w_noobj, gv, acc[0], acc[1]);
+                if (g) g[i] = gv;
+            }
+        }
+        block_sum<2>(acc, sh);
+        if (tid == 0) { S.conf_part[local * 2] = acc[0]; S.conf_part[local * 2 + 1] = acc[1]; }
+    } else {
+        // rows [r0, r1) of this scale, skipping the confidence row (c == 4) of every plane
+        const int R = P.B * S.A * CH;
+        int r0 = (bid - S.fill_blk0) * S.rows_per_fill_blk;
+        int r1 = r0 + S.rows_per_fill_blk; if (r1 > R) r1 = R;
+        int cur = r0;
+        while (cur < r1) {
+            int c = cur % CH;
+            int next_conf = cur + ((4 - c) % CH + CH) % CH;     // first row >= cur with c == 4
+            int seg_end = next_conf < r1 ? next_conf : r1;
+            if (seg_end > cur) fill_zero(S.grad, (size_t)cur * G2, (size_t)seg_end * G2);
+            cur = seg_end + (next_conf < r1 ? 1 : 0);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// obj kernel: one workgroup per target that owns an obj cell
+
+__global__ __launch_bounds__(kObjThreads) void yolo_obj_kernel(const Params P) {
+    __shared__ float sh[8 * (kObjThreads / 64)];
+    __shared__ float sh_bc[2];
+    const Scale& S = P.s[blockIdx.y];
+    const int t = blockIdx.x, tid = threadIdx.x, CH = P.CH, C = P.C, G2 = S.G2;
+    float* part = S.obj_part + (size_t)t * 8;
+    const int cell = S.tcell[t];
+    if (cell < 0) { if (tid < 8) part[tid] = 0.f; return; }
+    const int plane = cell / G2, s = cell - plane * G2, a = plane % S.A;
+    const size_t base = (size_t)plane * CH * G2 + s;
+    const float* __restrict__ zp = S.head + base;
+    float* __restrict__ gp = S.grad ? S.grad + base : nullptr;
+    const int nObj = S.counts[0];
+    const float w = P.inv_S / (float)nObj;                 // mean over nObj, then the 1/len(output)
+    const float* r = S.rec + (size_t)t * 4;
+    const unsigned* bits = S.bits + (size_t)t * P.W;
+    const int sl1 = P.coord_sl1;
+
+    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};        // lx, ly, lw, lh, lcls, size
+    // CE over the sigmoid outputs needs the row's log-sum-exp first (nn.CrossEntropyLoss, prob targets)
+    float lse = 0.f, tsum = 0.f;
+    if (P.cls_mode == ODPL_CLS_CE) {
+        float m = -INFINITY, ts = 0.f;
+        for (int k = tid; k < C; k += kObjThreads) {
+            m = fmaxf(m, sigmoidf_(zp[(size_t)(5 + k) * G2]));
+            ts += (float)((bits[k >> 5] >> (k & 31)) & 1u);
+        }
+        m = wave_max(m);
+        if ((tid & 63) == 0) sh[tid >> 6] = m;
+        __syncthreads();
+        m = sh[0]; for (int i = 1; i < kObjThreads / 64; ++i) m = fmaxf(m, sh[i]);
+        __syncthreads();
+        float e[2] = {0.f, ts};
+        for (int k = tid; k < C; k += kObjThreads) e[0] += expf(sigmoidf_(zp[(size_t)(5 + k) * G2]) - m);
+        block_sum<2>(e, sh);
+        if (tid == 0) { sh_bc[0] = m + logf(e[0]); sh_bc[1] = e[1]; }
+        __syncthreads();
+        lse = sh_bc[0]; tsum = sh_bc[1];
+    }
+    for (int c = tid; c < CH; c += kObjThreads) {
+        if (c == 4) continue;                              // confidence: dense kernel
+        const float z = zp[(size_t)c * G2];
+        float g;
+        if (c < 2) {                                       // losses.py:557-558
+            const float p = sigmoidf_(z), d = p - r[c];
+            acc[c] += coord_elem(d, sl1);
+            g = coord_deriv(d, sl1) * w * (1.0f - p) * p;
+        } else if (c < 4) {                                // losses.py:559-560 (raw, no sigmoid)
+            const float d = z - r[c];
+            acc[c] += coord_elem(d, sl1);
+            g = coord_deriv(d, sl1) * w;
+        } else {                                           // losses.py:564
+            const int k = c - 5;
+            const float tk = (float)((bits[k >> 5] >> (k & 31)) & 1u);
+            const float p = sigmoidf_(z);
+            if (P.cls_mode == ODPL_CLS_CE) {
+                const float lsm = p - lse;
+                acc[4] += -tk * lsm;
+                g = (expf(lsm) * tsum - tk) * w * (1.0f - p) * p;
+            } else {
+                acc[4] += bce_elem(p, tk);
+                g = bce_grad_logit(p, tk, w / (float)C);
+            }
+        }
+        if (gp) gp[(size_t)c * G2] = g;
+    }
+    // "Size" metric (losses.py:568-573): obj cells in raster order vs target COLUMNS 3:5 of row `rank`
+    if (tid == 0) {
+        const int k = nObj < P.nT ? nObj : P.nT, rk = S.trank[t];
+        if (rk < k) {
+            const float pw = expf(zp[(size_t)2 * G2]) * S.aw[a], ph = expf(zp[(size_t)3 * G2]) * S.ah[a];
+            const float* yr = P.target + (size_t)rk * 6;
+            const float d0 = sqrtf(fabsf(pw) + 1e-32f) - sqrtf(fabsf(yr[3]) + 1e-32f);
+            const float d1 = sqrtf(fabsf(ph) + 1e-32f) - sqrtf(fabsf(yr[4]) + 1e-32f);
+            acc[5] = coord_elem(d0, sl1) + coord_elem(d1, sl1);
+        }
+    }
+    block_sum<6>(acc, sh);
+    if (tid == 0) {
+        for (int i = 0; i < 6; ++i) part[i] = acc[i];
+        part[6] = part[7] = 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void yolo_finalize_kernel(const Params P) {
+    __shared__ double shd[8 * 4];
+    __shared__ float res[ODPL_MAX_SCALES][7];
+    const int tid = threadIdx.x;
+    for (int si = 0; si < P.nscales; ++si) {
+        const Scale& S = P.s[si];
+        double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};          // lx ly lw lh lcls size conf_obj conf_noobj
+        for (int t = tid; t < P.nT; t += 256) {
+            const float* p = S.obj_part + (size_t)t * 8;
+            for (int i = 0; i < 6; ++i) a[i] += (double)p[i];
+        }
+        for (int b = tid; b < S.conf_nblk; b += 256) {
+            a[6] += (double)S.conf_part[b * 2];
+            a[7] += (double)S.conf_part[b * 2 + 1];
+        }
+        for (int i = 0; i < 8; ++i) {
+            double v = a[i];
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+            a[i] = v;
+        }
+        if ((tid & 63) == 0) for (int i = 0; i < 8; ++i) shd[(tid >> 6) * 8 + i] = a[i];
+        __syncthreads();
+        if (tid == 0) {
+            float s[8];
+            for (int i = 0; i < 8; ++i) s[i] = (float)(shd[i] + shd[8 + i] + shd[16 + i] + shd[24 + i]);
+            const int nObj = S.counts[0], nNoobj = S.counts[1];
+            const float fo = (float)nObj;
+            const float lx = s[0] / fo, ly = s[1] / fo, lw = s[2] / fo, lh = s[3] / fo;
+            const float lcls = P.cls_mode == ODPL_CLS_CE ? s[4] / fo : s[4] / (fo * (float)P.C);
+            const float lobj = s[6] / fo, lnoobj = s[7] / (float)nNoobj;
+            const float lconf = P.obj_scale * lobj + P.noobj_scale * lnoobj;          // losses.py:563
+            const int k = nObj < P.nT ? nObj : P.nT;
+            const float size = s[5] / (float)(2 * k);
+            res[si][0] = lx + ly + lw + lh + lconf + lcls;                            // losses.py:566
+            res[si][1] = lx + ly; res[si][2] = size; res[si][3] = lconf; res[si][4] = lcls;
+            res[si][5] = lobj; res[si][6] = lnoobj;
+            if (P.out_scales) for (int i = 0; i < 7; ++i) P.out_scales[si * 7 + i] = res[si][i];
+            if (P.out_counts) for (int i = 0; i < 8; ++i) P.out_counts[si * 8 + i] = S.counts[i];
+        }
+        __syncthreads();
+    }
+    if (tid < 7) {
+        float acc = 0.f;
+        for (int si = 0; si < P.nscales; ++si) acc += res[si][tid];                    // losses.py:606-612
+        P.out7[tid] = P.average ? acc / (float)P.nscales : acc;                        // losses.py:616-623
+    }
+}
+
+__global__ void scale_if_not_one_kernel(float* __restrict__ g, size_t n, const float* __restrict__ s) {
+    const float f = *s;
+    if (f == 1.0f) return;
+    const size_t n4 = n / 4, stride = (size_t)gridDim.x * blockDim.x;
+    float4* g4 = reinterpret_cast<float4*>(g);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 v = g4[i]; v.x *= f; v.y *= f; v.z *= f; v.w *= f; g4[i] = v;
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) g[i] *= f;
+}
+
+// ------------------------------------------------------------------------------------------------
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Plan {
+    size_t state_off[ODPL_MAX_SCALES], rec_off[ODPL_MAX_SCALES], tcell_off[ODPL_MAX_SCALES],
+        trank_off[ODPL_MAX_SCALES], bits_off[ODPL_MAX_SCALES], counts_off[ODPL_MAX_SCALES],
+        confp_off[ODPL_MAX_SCALES], objp_off[ODPL_MAX_SCALES];
+    size_t state_bytes_total, total;
+    int conf_blk_per_row[ODPL_MAX_SCALES], conf_nblk[ODPL_MAX_SCALES], conf_vec[ODPL_MAX_SCALES];
+    int fill_nblk[ODPL_MAX_SCALES], rows_per_fill_blk[ODPL_MAX_SCALES];
+    int W;
+};
+
+bool make_plan(const odpl_yolo_loss_desc_t* d, Plan* p) {
+    if (!d || d->nscales < 1 || d->nscales > ODPL_MAX_SCALES || d->B < 1 || d->C < 1 || d->nT < 0) return false;
+    const int CH = 5 + d->C;
+    p->W = (d->C + 31) / 32;
+    size_t off = 0;
+    // all state maps first, contiguous: one memset(0xFF) resets them
+    for (int i = 0; i < d->nscales; ++i) {
+        const odpl_yolo_scale_t& s = d->scale[i];
+        if (s.G < 1 || s.A < 1 || s.A > ODPL_MAX_ANCHORS || !s.head) return false;
+        if ((long long)d->B * s.A * CH * s.G * s.G > 0x7fffffffLL) return false;
+        p->state_off[i] = off;
+        off += align_up((size_t)d->B * s.A * s.G * s.G * sizeof(int), 256);
+    }
+    p->state_bytes_total = off;
+    const size_t nT = (size_t)(d->nT > 0 ? d->nT : 1);
+    for (int i = 0; i < d->nscales; ++i) {
+        const odpl_yolo_scale_t& s = d->scale[i];
+        const int G2 = s.G * s.G;
+        p->conf_vec[i] = (G2 % 4 == 0) ? 1 : 0;
+        const int units = p->conf_vec[i] ? G2 / 4 : G2;
+        p->conf_blk_per_row[i] = (units + kDenseThreads - 1) / kDenseThreads;
+        p->conf_nblk[i] = d->B * s.A * p->conf_blk_per_row[i];
+        int rows = (kFillF4PerBlock * 4 + G2 - 1) / G2; if (rows < 1) rows = 1;
+        p->rows_per_fill_blk[i] = rows;
+        const int R = d->B * s.A * CH;
+        p->fill_nblk[i] = s.grad ? (R + rows - 1) / rows : 0;
+        p->rec_off[i] = off;    off += align_up(nT * 4 * sizeof(float), 256);
+        p->tcell_off[i] = off;  off += align_up(nT * sizeof(int), 256);
+        p->trank_off[i] = off;  off += align_up(nT * sizeof(int), 256);
+        p->bits_off[i] = off;   off += align_up(nT * p->W * sizeof(unsigned), 256);
+        p->counts_off[i] = off; off += 256;
+        p->confp_off[i] = off;  off += align_up((size_t)p->conf_nblk[i] * 2 * sizeof(float), 256);
+        p->objp_off[i] = off;   off += align_up(nT * 8 * sizeof(float), 256);
+    }
+    p->total = off;
+    return true;
+}
+}  // namespace
+
+extern "C" int odpl_abi_version(void) { return ODPL_ABI_VERSION; }
+
+extern "C" size_t odpl_yolo_region_loss_workspace_bytes(const odpl_yolo_loss_desc_t* desc) {
+    Plan p;
+    return make_plan(desc, &p) ? p.total : 0;
+}
+
+extern "C" int odpl_yolo_region_loss(const odpl_yolo_loss_desc_t* d, void* workspace, size_t workspace_bytes,
+                                     float* out7, float* out_scales, int32_t* out_counts, void* stream_) {
+    Plan pl;
+    if (!make_plan(d, &pl) || !workspace || workspace_bytes < pl.total || !out7) return ODPL_EINVAL;
+    if (d->nT > 0 && !d->target) return ODPL_EINVAL;
+    if (((uintptr_t)workspace & 15) != 0) return ODPL_EINVAL;
+    hipStream_t stream = (hipStream_t)stream_;
+    char* ws = (char*)workspace;
+    Params P;
+    P.target = d->target; P.nscales = d->nscales; P.B = d->B; P.C = d->C; P.CH = 5 + d->C; P.nT = d->nT; P.W = pl.W;
+    P.coord_sl1 = d->coord_mode == ODPL_COORD_SMOOTH_L1; P.cls_mode = d->cls_mode; P.average = d->average;
+    P.ignore_thres = d->ignore_thres; P.obj_scale = d->obj_scale; P.noobj_scale = d->noobj_scale;
+    P.inv_S = d->average ? 1.0f / (float)d->nscales : 1.0f;
+    P.out7 = out7; P.out_scales = out_scales; P.out_counts = out_counts;
+    int nblk = 0;
+    bool any_grad = false;
+    for (int i = 0; i < d->nscales; ++i) {          // confidence blocks first: latency-bound, start early
+        const odpl_yolo_scale_t& s = d->scale[i];
+        Scale& S = P.s[i];
+        if (((uintptr_t)s.head & 15) != 0 || ((uintptr_t)s.grad & 15) != 0) return ODPL_EINVAL;
+        S.head = s.head; S.grad = s.grad; S.G = s.G; S.G2 = s.G * s.G; S.A = s.A;
+        S.state = (int*)(ws + pl.state_off[i]); S.rec = (float*)(ws + pl.rec_off[i]);
+        S.tcell = (int*)(ws + pl.tcell_off[i]); S.trank = (int*)(ws + pl.trank_off[i]);
+        S.bits = (unsigned*)(ws + pl.bits_off[i]); S.counts = (int*)(ws + pl.counts_off[i]);
+        S.conf_part = (float*)(ws + pl.confp_off[i]); S.obj_part = (float*)(ws + pl.objp_off[i]);
+        for (int a = 0; a < ODPL_MAX_ANCHORS; ++a) { S.aw[a] = s.anchor_w[a]; S.ah[a] = s.anchor_h[a]; }
+        S.conf_blk_per_row = pl.conf_blk_per_row[i]; S.conf_nblk = pl.conf_nblk[i]; S.conf_vec = pl.conf_vec[i];
+        S.conf_blk0 = nblk; nblk += S.conf_nblk;
+        any_grad |= s.grad != nullptr;
+    }
+    for (int i = 0; i < d->nscales; ++i) {
+        Scale& S = P.s[i];
+        S.fill_nblk = pl.fill_nblk[i]; S.rows_per_fill_blk = pl.rows_per_fill_blk[i];
+        S.fill_blk0 = nblk; nblk += S.fill_nblk;
+    }
+    (void)any_grad;
+    ODPL_HIP_TRY(hipMemsetAsync(ws, 0xFF, pl.state_bytes_total, stream));
+    hipLaunchKernelGGL(yolo_assign_kernel, dim3(d->nscales), dim3(kAssignThreads), 0, stream, P);
+    ODPL_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(yolo_dense_kernel, dim3(nblk), dim3(kDenseThreads), 0, stream, P);
+    ODPL_HIP_TRY(hipGetLastError());
+    if (d->nT > 0) {
+        hipLaunchKernelGGL(yolo_obj_kernel, dim3(d->nT, d->nscales), dim3(kObjThreads), 0, stream, P);
+        ODPL_HIP_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(yolo_finalize_kernel, dim3(1), dim3(256), 0, stream, P);
+    ODPL_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int odpl_scale_inplace_if_not_one(float* grad, size_t n, const float* scale, void* stream_) {
+    if (!grad || !scale || ((uintptr_t)grad & 15) != 0) return ODPL_EINVAL;
+    if (n == 0) return 0;
+    size_t blocks = (n / 4 + 255) / 256; if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(scale_if_not_one_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, grad, n, scale);
+    ODPL_HIP_TRY(hipGetLastError());
+    return 0;
+}

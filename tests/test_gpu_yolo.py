@@ -1,0 +1,200 @@
+"""GPU parity: the HIP YOLO path (through the C ABI) vs the CPU oracle and the reference's golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import yolo as oracle_yolo
+
+pytestmark = pytest.mark.gpu
+
+V4_ANCHORS = [[12, 16], [19, 36], [40, 28], [36, 75], [76, 55], [72, 146], [142, 110], [192, 243], [459, 401]]
+V4_MASKS = [[0, 1, 2], [3, 4, 5], [6, 7, 8]]
+CASES = ("plain", "dup", "tie", "oor", "oorb", "lab", "neg", "empty", "edge")
+DENSE = ("iou_scores", "class_mask", "obj_mask", "noobj_mask", "tx", "ty", "tw", "th", "tcls", "tconf")
+EXACT = ("class_mask", "obj_mask", "noobj_mask", "tcls", "tconf", "tx", "ty")   # index/mask work + exact fp32 subtraction
+RTOL, ATOL = 1e-4, 1e-6     # north_star: fp32 losses within 1e-4 relative
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("G", [13, 26])
+@pytest.mark.parametrize("case", CASES)
+def test_build_targets_vs_golden(golden, G, case):
+    from objectdetectionpl_amd.LightningFunc.accuracy import build_targets
+    g = golden("yolo_assign")
+    d = dev()
+    outs = build_targets(T(g[f"G{G}_pred_boxes"]).to(d), T(g[f"G{G}_pred_cls"]).to(d), T(g[f"G{G}_{case}_target"]).to(d),
+                         T(g[f"G{G}_anchors"]).to(d), 0.5)
+    for k, v in zip(DENSE, outs):
+        ref = g[f"G{G}_{case}_{k}"]
+        got = v.cpu().numpy()
+        assert got.dtype == ref.dtype and got.shape == ref.shape, k
+        if k in EXACT:
+            assert np.array_equal(got, ref), (k, int((got != ref).sum()))
+        else:
+            assert np.allclose(got, ref, rtol=1e-5, atol=1e-6), k
+            assert np.array_equal(got != 0, ref != 0), k        # same cells written
+
+
+def _check_dict(out, ref, rtol=RTOL, atol=ATOL):
+    for k, v in ref.items():
+        a = out[k].item()
+        b = float(np.asarray(v))
+        if np.isnan(b):
+            assert np.isnan(a), (k, a, b)
+        else:
+            assert abs(a - b) <= rtol * abs(b) + atol, (k, a, b)
+
+
+def _check_grad(got, ref, rtol=RTOL):
+    got = got.cpu().numpy().astype(np.float64)
+    ref = np.asarray(ref, np.float64)
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    scale = np.abs(ref[~np.isnan(ref)]).max() if ref.size else 0.0
+    assert np.allclose(got, ref, rtol=rtol, atol=1e-6 * max(scale, 1e-30) + 1e-12, equal_nan=True), \
+        float(np.nanmax(np.abs(got - ref)))
+    assert np.array_equal(got == 0, ref == 0) or np.allclose(got, ref, rtol=rtol, atol=1e-12, equal_nan=True)
+
+
+@pytest.mark.parametrize("coord", ["smooth_l1_loss", "mse_loss"])
+@pytest.mark.parametrize("cls", ["bce_loss", "ce_loss"])
+@pytest.mark.parametrize("case", ["plain", "dup", "oor", "lab", "empty", "neg"])
+def test_v4_loss_and_grad_vs_golden(golden, coord, cls, case):
+    from objectdetectionpl_amd.LightningFunc.losses import MultiScaleRegionLoss_v4
+    g = golden("yolo_loss")
+    d = dev()
+    heads = [T(g[f"v4_head{i}"]).to(d).requires_grad_() for i in range(3)]
+    tag = f"v4_{coord}_{cls}_{case}"
+    crit = MultiScaleRegionLoss_v4(V4_ANCHORS, V4_MASKS, cls, coord, "bce_loss", 4, 416)
+    out = crit(heads, T(g[f"{tag}_target"]).to(d))
+    out["loss"].backward()
+    _check_dict(out, {k: g[f"{tag}_{k}"] for k in oracle_yolo.KEYS})
+    for i, h in enumerate(heads):
+        _check_grad(h.grad, g[f"{tag}_grad{i}"])
+
+
+def test_v4_saturated_logits(golden):
+    from objectdetectionpl_amd.LightningFunc.losses import MultiScaleRegionLoss_v4
+    g = golden("yolo_loss")
+    d = dev()
+    heads = [T(g[f"v4_sat_head{i}"]).to(d).requires_grad_() for i in range(3)]
+    crit = MultiScaleRegionLoss_v4(V4_ANCHORS, V4_MASKS, "bce_loss", "smooth_l1_loss", "bce_loss", 4, 416)
+    out = crit(heads, T(g["v4_sat_target"]).to(d))
+    out["loss"].backward()
+    _check_dict(out, {k: g[f"v4_sat_{k}"] for k in oracle_yolo.KEYS})
+    for i, h in enumerate(heads):
+        _check_grad(h.grad, g[f"v4_sat_grad{i}"])
+
+
+def test_v3_vs_golden(golden):
+    from objectdetectionpl_amd.LightningFunc.losses import MultiScaleRegionLoss_v3
+    g = golden("yolo_loss")
+    d = dev()
+    heads = [T(g[f"v3_head{i}"]).to(d).requires_grad_() for i in range(3)]
+    anchors = [[tuple(a) for a in s] for s in g["v3_anchors"].tolist()]
+    crit = MultiScaleRegionLoss_v3(anchors, "bce_loss", "mse_loss", "bce_loss", 4, 416)
+    out = crit(heads, T(g["v3_target"]).to(d))
+    out["loss"].backward()
+    _check_dict(out, {k: g[f"v3_{k}"] for k in oracle_yolo.KEYS})
+    for i, h in enumerate(heads):
+        _check_grad(h.grad, g[f"v3_grad{i}"])
+
+
+@pytest.mark.parametrize("img", [288, 416])
+def test_v2_vs_golden(golden, img):
+    from objectdetectionpl_amd.LightningFunc.losses import RegionLoss_v2
+    g = golden("yolo_loss")
+    d = dev()
+    anchors = [(1.3221, 1.73145), (3.19275, 4.00944), (5.05587, 8.09892), (9.47112, 4.84053), (11.2364, 10.0071)]
+    head = T(g[f"v2_{img}_head"]).to(d).requires_grad_()
+    crit = RegionLoss_v2(anchors, "bce_loss", "smooth_l1_loss", "bce_loss", 20, img)
+    out = crit(head, T(g[f"v2_{img}_target"]).to(d))
+    out["loss"].backward()
+    _check_dict(out, {k: g[f"v2_{img}_{k}"] for k in oracle_yolo.KEYS})
+    _check_grad(head.grad, g[f"v2_{img}_grad"])
+
+
+def _config2_inputs():
+    gen = torch.Generator().manual_seed(1)
+    _x = torch.rand(16, 3, 416, 416, generator=gen)
+    n = 112
+    b = torch.arange(16).repeat_interleave(7).float()
+    cls = torch.randint(0, 80, (n,), generator=gen).float()
+    wh = torch.rand(n, 2, generator=gen) * 0.48 + 0.02
+    xy = torch.rand(n, 2, generator=gen) * (1 - wh)
+    tgt = torch.cat([b[:, None], cls[:, None], xy, wh], 1)
+    g2 = torch.Generator().manual_seed(2)
+    heads = [torch.randn(16, 255, G, G, generator=g2) for G in (52, 26, 13)]
+    return heads, tgt
+
+
+def test_config2_full_size_vs_golden_and_oracle(golden):
+    """BASELINE config 2 (B=16, C=80, 416^2): scalars vs the reference's golden digests, full gradient vs the oracle."""
+    from objectdetectionpl_amd.LightningFunc.losses import MultiScaleRegionLoss_v4
+    g = golden("yolo_config2")
+    heads, tgt = _config2_inputs()
+    assert np.array_equal(tgt.numpy(), g["target"])
+    for i, h in enumerate(heads):
+        assert np.array_equal(h.flatten()[:64].numpy(), g[f"head{i}_first"])
+    d = dev()
+    dheads = [h.to(d).requires_grad_() for h in heads]
+    crit = MultiScaleRegionLoss_v4(V4_ANCHORS, V4_MASKS, "bce_loss", "smooth_l1_loss", "bce_loss", 80, 416)
+    out = crit(dheads, tgt.to(d))
+    out["loss"].backward()
+    _check_dict(out, {k: g[f"out_{k}"] for k in oracle_yolo.KEYS})
+    for i, h in enumerate(dheads):
+        gr = h.grad.cpu()
+        assert int((gr != 0).sum()) == int(g[f"grad{i}_nnz"])
+        for name, val in (("sum", gr.double().sum()), ("abssum", gr.double().abs().sum()), ("sqsum", (gr.double() ** 2).sum())):
+            ref = float(g[f"grad{i}_{name}"])
+            assert abs(val.item() - ref) <= 1e-4 * abs(ref) + 1e-9, (i, name, val.item(), ref)
+        G = h.shape[2]
+        assert np.allclose(gr.view(16, 3, 85, G, G)[0, 0, 4].numpy(), g[f"grad{i}_confplane"], rtol=1e-4, atol=1e-9)
+        idx = T(g[f"grad{i}_top_idx"])
+        assert np.allclose(gr.flatten()[idx].numpy(), g[f"grad{i}_top_val"], rtol=1e-4, atol=1e-9)
+    # and the full gradient against the oracle
+    oheads = [h.clone().requires_grad_() for h in heads]
+    ref = oracle_yolo.multiscale_region_loss_v4(oheads, tgt, V4_ANCHORS, V4_MASKS, 80, 416)
+    ref["loss"].backward()
+    for h, o in zip(dheads, oheads):
+        _check_grad(h.grad, o.grad.numpy())
+
+
+def test_forward_only_and_grad_scale():
+    """no-grad call writes no gradient; a non-unit upstream gradient scales the stored one (autograd contract)."""
+    from objectdetectionpl_amd.LightningFunc.losses import MultiScaleRegionLoss_v4
+    d = dev()
+    gen = torch.Generator().manual_seed(5)
+    heads = [torch.randn(2, 27, G, G, generator=gen) for G in (52, 26, 13)]
+    tgt = torch.tensor([[0, 1, 0.3, 0.4, 0.2, 0.3], [1, 3, 0.6, 0.5, 0.1, 0.2]])
+    crit = MultiScaleRegionLoss_v4(V4_ANCHORS, V4_MASKS, "bce_loss", "smooth_l1_loss", "bce_loss", 4, 416)
+    with torch.no_grad():
+        o0 = crit([h.to(d) for h in heads], tgt.to(d))
+    h1 = [h.to(d).requires_grad_() for h in heads]
+    o1 = crit(h1, tgt.to(d)); o1["loss"].backward()
+    h2 = [h.to(d).requires_grad_() for h in heads]
+    o2 = crit(h2, tgt.to(d)); (o2["loss"] * 3.0).backward()
+    for k in o0:
+        assert o0[k].item() == o1[k].item() == o2[k].item()
+    for a, b in zip(h1, h2):
+        assert torch.allclose(a.grad * 3.0, b.grad, rtol=1e-6, atol=0)
+    # run-to-run bitwise reproducibility (no float atomics)
+    h3 = [h.to(d).requires_grad_() for h in heads]
+    o3 = crit(h3, tgt.to(d)); o3["loss"].backward()
+    for a, b in zip(h1, h3):
+        assert torch.equal(a.grad, b.grad)
+    assert all(o1[k].item() == o3[k].item() for k in o1)
+
+
+def test_cpu_tensor_is_rejected():
+    from objectdetectionpl_amd.LightningFunc.losses import MultiScaleRegionLoss_v4
+    from objectdetectionpl_amd._lib import OdplError
+    crit = MultiScaleRegionLoss_v4(V4_ANCHORS, V4_MASKS, "bce_loss", "smooth_l1_loss", "bce_loss", 4, 416)
+    with pytest.raises(OdplError):
+        crit([torch.zeros(1, 27, G, G) for G in (52, 26, 13)], torch.zeros(1, 6))
