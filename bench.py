@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric: images/sec of the YOLOv4 416x416 bs=16/GPU training step.
+
+One "step" = forward (CSPDarknet53/PAN convs on MIOpen) + the HIP region loss (libodpl_hip.so:
+assignment, 7 loss terms and d loss/d head) + backward + Adam, on one synthetic COCO-shaped batch
+resident in HBM.  N>1: one process per GPU (torchrun), DDP over RCCL/xGMI, weak scaling.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) carrying
+  roofline     : the dense kernel of the loss (yolo_dense_kernel), timed with HIP events on its launch stream
+  cpu_baseline : the same training step on the host cores with the CPU oracle as the loss (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+V4_ANCHORS = [[12, 16], [19, 36], [40, 28], [36, 75], [76, 55], [72, 146], [142, 110], [192, 243], [459, 401]]
+V4_MASKS = [[0, 1, 2], [3, 4, 5], [6, 7, 8]]
+
+
+class Args:
+    model_name = "YOLOv4"
+    cls_criterion = "bce_loss"          # configs/config.yaml:30
+    coord_criterion = "smooth_l1_loss"  # configs/config.yaml:31-32 (last key wins)
+    data_module = "synthetic"
+    optimizer = "Adam"
+    lr = 1e-3
+    weight_decay = 1e-5
+
+
+def synthetic_batch(seed, B, C, img, device):
+    """x ~ U[0,1), 7 targets per image, every index in range."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(B, 3, img, img, generator=g)
+    n = B * 7
+    b = torch.arange(B).repeat_interleave(7).float()
+    cls = torch.randint(0, C, (n,), generator=g).float()
+    wh = torch.rand(n, 2, generator=g) * 0.48 + 0.02
+    xy = torch.rand(n, 2, generator=g) * (1 - wh)
+    y = torch.cat([b[:, None], cls[:, None], xy, wh], 1)
+    return x.to(device), y.to(device)
+
+
+def cpu_baseline(B_sample, C, img, steps):
+    """The reference's CPU path restated: same network on torch-CPU + the oracle loss, timed on the host."""
+    from oracle import yolo as oracle_yolo
+    from objectdetectionpl_amd.model.YOLOV4 import YOLOv4
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:  # noqa: BLE001
+        pass
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    model = YOLOv4([str(i) for i in range(C)], Args()).train()
+    opt = torch.optim.Adam(model.parameters(), lr=Args.lr, weight_decay=Args.weight_decay)
+    x, y = synthetic_batch(1, B_sample, C, img, "cpu")
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = model(x)
+        t0 = time.perf_counter()
+        d = oracle_yolo.multiscale_region_loss_v4(out, y, V4_ANCHORS, V4_MASKS, C, img)
+        t1 = time.perf_counter()
+        d["loss"].backward()
+        opt.step()
+        return t1 - t0
+
+    t0 = time.perf_counter()
+    loss_s = 0.0
+    for _ in range(steps):
+        loss_s += step()
+    dt = time.perf_counter() - t0
+    return {"value": round(B_sample * steps / dt, 3), "unit": "img/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} training step(s) of bs={B_sample} (same net on torch-CPU fp32, oracle loss, Adam), "
+                      f"{dt:.1f} s; oracle loss forward alone {1e3 * loss_s / steps:.0f} ms/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU")
+    ap.add_argument("--classes", type=int, default=80)
+    ap.add_argument("--img", type=int, default=416)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-batch", type=int, default=8)
+    ap.add_argument("--cpu-sample-steps", type=int, default=2)
+    ap.add_argument("--bucket-mb", type=int, default=48)
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        sys.exit(f"--gpus {a.gpus} needs `python -m torch.distributed.run --nproc-per-node {a.gpus} bench.py ...` "
+                 f"(WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from objectdetectionpl_amd import _lib
+    from objectdetectionpl_amd.model.YOLOV4 import YOLOv4
+    from objectdetectionpl_amd.parallel import wrap_data_parallel
+
+    torch.manual_seed(0)
+    model = YOLOv4([str(i) for i in range(a.classes)], Args()).to(dev).train()
+    crit = model.criterion
+    net = wrap_data_parallel(model, dev, bucket_mb=a.bucket_mb) if world > 1 else model
+    opt = torch.optim.Adam(model.parameters(), lr=Args.lr, weight_decay=Args.weight_decay)
+    x, y = synthetic_batch(1 + rank, a.batch, a.classes, a.img, dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = net(x)
+        d = crit(out, y)
+        d["loss"].backward()
+        opt.step()
+        return d
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    _lib.profile_enable("yolo_dense", True)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        d = step()
+    fence()
+    dt = time.perf_counter() - t0
+    _lib.profile_enable("yolo_dense", False)
+    dense_ms = _lib.profile_collect("yolo_dense")
+    loss_val = float(d["loss"].item())
+
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+
+    if rank == 0:
+        CH = 5 + a.classes
+        cells = sum(a.batch * 3 * G * G for G in (a.img // 8, a.img // 16, a.img // 32))
+        # as-built algorithmic bytes of yolo_dense_kernel per launch (DESIGN.md "Kernels"):
+        # write every gradient element once + read the confidence row and the int32 state map once
+        alg_bytes = 4 * cells * CH + 4 * cells + 4 * cells
+        avg_ms = sum(dense_ms) / max(len(dense_ms), 1)
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if dense_ms else None
+        res = {
+            "metric": "images/sec training step (YOLOv4 416x416, bs=16/GPU)",
+            "value": round(a.batch * world * a.steps / dt, 2), "unit": "img/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(1e3 * dt / a.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"YOLOv4 COCO-synthetic {a.img}x{a.img} bs={a.batch}/GPU training step "
+                                   f"(fwd + HIP region loss + bwd + Adam), {a.classes} classes, 7 targets/img",
+                       "global_batch": a.batch * world, "parallelism": f"dp{world}", "loss_last": round(loss_val, 4)},
+            "roofline": {"kernel": "yolo_dense_kernel", "bound": "hbm",
+                         "achieved": None if achieved is None else round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "avg_kernel_us": round(avg_ms * 1e3, 2), "launches": len(dense_ms),
+                         "algorithmic_bytes": alg_bytes, "survey_8d_bytes": 2 * 4 * cells * CH},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(a.cpu_sample_batch, a.classes, a.img, a.cpu_sample_steps)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -100,6 +100,19 @@ int odpl_yolo_build_targets(const float* pred_boxes, const float* pred_cls, cons
                             float* tx, float* ty, float* tw, float* th, float* tcls, float* tconf,
                             int32_t* status, void* stream);
 
+/* ---- in-library kernel timing (bench.py roofline leg) ------------------------------------------
+ * HIP events recorded on the launch stream immediately around the named kernel of every later call.
+ * No counterpart in the reference (it has no benchmark); host_ms is a HOST buffer.               */
+#define ODPL_PROF_YOLO_DENSE 0
+#define ODPL_PROF_YOLO_ASSIGN 1
+#define ODPL_PROF_YOLO_OBJ 2
+#define ODPL_PROF_YOLO_FINALIZE 3
+#define ODPL_PROF_NUM_KERNELS 16
+int odpl_profile_enable(int32_t kernel_id, int32_t on);
+/* Synchronises the recorded events, writes up to max_n durations (ms) and returns how many launches
+ * were recorded since the last collect (negative: ODPL_EINVAL). */
+int odpl_profile_collect(int32_t kernel_id, float* host_ms, int32_t max_n);
+
 #ifdef __cplusplus
 }
 #endif

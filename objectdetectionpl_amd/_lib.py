@@ -37,6 +37,8 @@ SIGNATURES = {
     "odpl_yolo_region_loss_workspace_bytes": (c_size_t, [POINTER(YoloLossDesc)]),
     "odpl_yolo_region_loss": (c_int32, [POINTER(YoloLossDesc), c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
     "odpl_scale_inplace_if_not_one": (c_int32, [c_void_p, c_size_t, c_void_p, c_void_p]),
+    "odpl_profile_enable": (c_int32, [c_int32, c_int32]),
+    "odpl_profile_collect": (c_int32, [c_int32, POINTER(c_float), c_int32]),
     "odpl_yolo_build_targets": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                           c_int32, c_float, c_void_p] + [c_void_p] * 10 + [c_void_p, c_void_p]),
 }
@@ -85,3 +87,19 @@ def require_cuda(*tensors):
         if t is not None and not t.is_cuda:
             raise OdplError("objectdetectionpl_amd runs on the HIP device only (tensor is on "
                             f"{t.device}); there is no CPU fallback -- move inputs to cuda")
+
+
+PROF_IDS = {"yolo_dense": 0, "yolo_assign": 1, "yolo_obj": 2, "yolo_finalize": 3}
+
+
+def profile_enable(name, on=True):
+    check(lib().odpl_profile_enable(PROF_IDS[name], 1 if on else 0), "odpl_profile_enable")
+
+
+def profile_collect(name, max_n=4096):
+    """Durations (ms) of the named kernel's launches since the last collect (HIP events on the launch stream)."""
+    buf = (c_float * max_n)()
+    n = lib().odpl_profile_collect(PROF_IDS[name], buf, max_n)
+    if n < 0:
+        raise OdplError("odpl_profile_collect failed")
+    return [buf[i] for i in range(min(n, max_n))]

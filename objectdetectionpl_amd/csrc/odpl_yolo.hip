@@ -19,6 +19,7 @@
 // No atomics on floats anywhere: results are bitwise reproducible run to run.
 #include "odpl_common.hpp"
 #include "odpl_yolo_dev.hpp"
+#include "odpl_profile.hpp"
 #include "../../include/odpl_hip.h"
 
 namespace {
@@ -472,15 +473,23 @@ extern "C" int odpl_yolo_region_loss(const odpl_yolo_loss_desc_t* d, void* works
     }
     (void)any_grad;
     ODPL_HIP_TRY(hipMemsetAsync(ws, 0xFF, pl.state_bytes_total, stream));
+    prof_begin(ODPL_PROF_YOLO_ASSIGN, stream);
     hipLaunchKernelGGL(yolo_assign_kernel, dim3(d->nscales), dim3(kAssignThreads), 0, stream, P);
+    prof_end(ODPL_PROF_YOLO_ASSIGN, stream);
     ODPL_HIP_TRY(hipGetLastError());
+    prof_begin(ODPL_PROF_YOLO_DENSE, stream);
     hipLaunchKernelGGL(yolo_dense_kernel, dim3(nblk), dim3(kDenseThreads), 0, stream, P);
+    prof_end(ODPL_PROF_YOLO_DENSE, stream);
     ODPL_HIP_TRY(hipGetLastError());
     if (d->nT > 0) {
+        prof_begin(ODPL_PROF_YOLO_OBJ, stream);
         hipLaunchKernelGGL(yolo_obj_kernel, dim3(d->nT, d->nscales), dim3(kObjThreads), 0, stream, P);
+        prof_end(ODPL_PROF_YOLO_OBJ, stream);
         ODPL_HIP_TRY(hipGetLastError());
     }
+    prof_begin(ODPL_PROF_YOLO_FINALIZE, stream);
     hipLaunchKernelGGL(yolo_finalize_kernel, dim3(1), dim3(256), 0, stream, P);
+    prof_end(ODPL_PROF_YOLO_FINALIZE, stream);
     ODPL_HIP_TRY(hipGetLastError());
     return 0;
 }

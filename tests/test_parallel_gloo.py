@@ -1,0 +1,82 @@
+"""world_size-2 gloo test of the data-parallel host (CPU): DDP-averaged gradients == mean of per-rank gradients."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _tiny_net():
+    torch.manual_seed(3)
+    return torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, 2, 1), torch.nn.BatchNorm2d(8), torch.nn.LeakyReLU(0.1),
+                               torch.nn.Conv2d(8, 27, 3, 2, 1))
+
+
+def _loss(net, x, y):
+    from oracle import yolo
+    out = net(x)
+    return yolo.region_loss(out, y, [(36, 75), (76, 55), (72, 146)], 4, 64)[0]
+
+
+def _batch():
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(4, 3, 64, 64, generator=g)
+    y = torch.tensor([[0, 1, .3, .3, .2, .3], [1, 2, .6, .5, .3, .2], [2, 0, .4, .7, .5, .4], [3, 3, .5, .5, .6, .6],
+                      [3, 1, .2, .2, .1, .2]])
+    return x, y
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    from objectdetectionpl_amd.parallel import init_process_group_from_env, shard_batch, wrap_data_parallel
+    init_process_group_from_env(None)
+    net = _tiny_net()
+    ddp = wrap_data_parallel(net, None, bucket_mb=1)
+    x, y = _batch()
+    xs, ys = shard_batch(x, y, rank, world)
+    _loss(ddp, xs, ys).backward()
+    grads = [p.grad.clone() for p in net.parameters()]
+    if rank == 0:
+        q.put([g.numpy() for g in grads])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_two_ranks_matches_mean_of_rank_gradients():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    sys.path.insert(0, REPO)
+    from objectdetectionpl_amd.parallel import shard_batch
+    x, y = _batch()
+    ref = None
+    for r in range(2):
+        net = _tiny_net()
+        xs, ys = shard_batch(x, y, r, 2)
+        _loss(net, xs, ys).backward()
+        gs = [p.grad for p in net.parameters()]
+        ref = gs if ref is None else [a + b for a, b in zip(ref, gs)]
+    for a, b in zip(got, ref):
+        assert torch.allclose(torch.from_numpy(a), b / 2, rtol=1e-4, atol=1e-6)
+
+
+def test_shard_batch_rebases_image_index():
+    from objectdetectionpl_amd.parallel import shard_batch
+    x, y = _batch()
+    xs, ys = shard_batch(x, y, 1, 2)
+    assert xs.shape[0] == 2 and ys[:, 0].tolist() == [0.0, 1.0, 1.0]
+    with pytest.raises(ValueError):
+        shard_batch(x[:3], y, 0, 2)
