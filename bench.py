@@ -59,6 +59,7 @@ def cpu_baseline(B_sample, C, img, steps):
         cores = len(os.sched_getaffinity(0))
     except Exception:  # noqa: BLE001
         pass
+    cores = min(cores, 16)      # one GPU's share of the host (the box exposes all 256 cores)
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     model = YOLOv4([str(i) for i in range(C)], Args()).train()
@@ -95,10 +96,14 @@ def main():
     ap.add_argument("--img", type=int, default=416)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-batch", type=int, default=8)
-    ap.add_argument("--cpu-sample-steps", type=int, default=2)
+    ap.add_argument("--cpu-sample-steps", type=int, default=4)
     ap.add_argument("--bucket-mb", type=int, default=48)
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="libodpl_hip tunable, e.g. yolo_fill_nt=1")
+    ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark=True (MIOpen find)")
+    ap.add_argument("--channels-last", action="store_true", help="run the network in NHWC memory format")
     a = ap.parse_args()
 
+    t_start = time.perf_counter()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -117,12 +122,20 @@ def main():
     from objectdetectionpl_amd.model.YOLOV4 import YOLOv4
     from objectdetectionpl_amd.parallel import wrap_data_parallel
 
+    for kv in a.tune:
+        k, v = kv.split("=")
+        _lib.tune_set(k, int(v))
+    torch.backends.cudnn.benchmark = bool(a.miopen_find)
     torch.manual_seed(0)
     model = YOLOv4([str(i) for i in range(a.classes)], Args()).to(dev).train()
+    if a.channels_last:
+        model = model.to(memory_format=torch.channels_last)
     crit = model.criterion
     net = wrap_data_parallel(model, dev, bucket_mb=a.bucket_mb) if world > 1 else model
     opt = torch.optim.Adam(model.parameters(), lr=Args.lr, weight_decay=Args.weight_decay)
     x, y = synthetic_batch(1 + rank, a.batch, a.classes, a.img, dev)
+    if a.channels_last:
+        x = x.contiguous(memory_format=torch.channels_last)
 
     def step():
         opt.zero_grad(set_to_none=True)
@@ -137,8 +150,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
+    def log(msg):
+        if rank == 0:
+            print(f"[bench {time.perf_counter() - t_start:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+    for i in range(a.warmup):
         step()
+        torch.cuda.synchronize()
+        log(f"warmup step {i + 1}/{a.warmup} done")     # the first step includes MIOpen solver selection / kernel builds
     fence()
     _lib.profile_enable("yolo_dense", True)
     t0 = time.perf_counter()
@@ -147,7 +166,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     _lib.profile_enable("yolo_dense", False)
-    dense_ms = _lib.profile_collect("yolo_dense")
+    dense_ms, dense_raw_ms = _lib.profile_collect("yolo_dense")
     loss_val = float(d["loss"].item())
 
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -158,9 +177,17 @@ def main():
     if rank == 0:
         CH = 5 + a.classes
         cells = sum(a.batch * 3 * G * G for G in (a.img // 8, a.img // 16, a.img // 32))
-        # as-built algorithmic bytes of yolo_dense_kernel per launch (DESIGN.md "Kernels"):
-        # write every gradient element once + read the confidence row and the int32 state map once
-        alg_bytes = 4 * cells * CH + 4 * cells + 4 * cells
+        # as-built algorithmic bytes of yolo_dense_kernel per launch (DESIGN.md "Kernels"): write every gradient
+        # element once + read the confidence row and the int32 state map once + reset the state map
+        alg_bytes = 4 * cells * CH + 4 * cells + 4 * cells + 4 * cells
+        traffic = None
+        try:        # PMC counters cannot be collected from inside this process: committed rocprofv3 --pmc passes
+            with open(os.path.join(REPO, "profiles", "pmc_traffic.json")) as f:
+                pmc = json.load(f)
+            if pmc["workload"] == {"batch": a.batch, "classes": a.classes, "img": a.img}:
+                traffic = pmc["yolo_dense_kernel"]["hbm_bytes"]
+        except Exception:  # noqa: BLE001
+            pass
         avg_ms = sum(dense_ms) / max(len(dense_ms), 1)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if dense_ms else None
         res = {
@@ -175,8 +202,10 @@ def main():
                        "global_batch": a.batch * world, "parallelism": f"dp{world}", "loss_last": round(loss_val, 4)},
             "roofline": {"kernel": "yolo_dense_kernel", "bound": "hbm",
                          "achieved": None if achieved is None else round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "avg_kernel_us": round(avg_ms * 1e3, 2), "launches": len(dense_ms),
+                         "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "avg_kernel_us": round(avg_ms * 1e3, 2),
+                         "avg_event_pair_us_uncorrected": round(1e3 * sum(dense_raw_ms) / max(len(dense_raw_ms), 1), 2),
+                         "launches": len(dense_ms),
                          "algorithmic_bytes": alg_bytes, "survey_8d_bytes": 2 * 4 * cells * CH},
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -59,12 +59,18 @@ typedef struct {
     int32_t coord_mode;             /* ODPL_COORD_* */
     int32_t cls_mode;               /* ODPL_CLS_* */
     int32_t average;                /* 1: divide every output by nscales (losses.py:616-623); 0: v2 */
+    int32_t flags;                  /* ODPL_YOLO_* bits */
     float ignore_thres;             /* 0.5, losses.py:483 */
     float obj_scale;                /* 1,   losses.py:487 */
     float noobj_scale;              /* 100, losses.py:488 */
     const float* target;            /* [nT,6] (img, cls, x, y, w, h) normalised; may be NULL if nT==0 */
     odpl_yolo_scale_t scale[ODPL_MAX_SCALES];
 } odpl_yolo_loss_desc_t;
+
+/* flags.  STATE_CLEAN: the caller promises that the last use of this workspace was a successful
+ * odpl_yolo_region_loss call with the same B, A, G per scale (the call leaves its cell-state maps,
+ * which sit first in the workspace, reset); the initial memset is then skipped. */
+#define ODPL_YOLO_STATE_CLEAN 1
 
 /* Bytes of scratch `odpl_yolo_region_loss` needs for this descriptor (host-side arithmetic only). */
 size_t odpl_yolo_region_loss_workspace_bytes(const odpl_yolo_loss_desc_t* desc);
@@ -100,6 +106,11 @@ int odpl_yolo_build_targets(const float* pred_boxes, const float* pred_cls, cons
                             float* tx, float* ty, float* tw, float* th, float* tcls, float* tconf,
                             int32_t* status, void* stream);
 
+/* launch-geometry knobs (process-wide; defaults are the tuned values) */
+#define ODPL_TUNE_YOLO_FILL_F4_PER_BLOCK 0
+#define ODPL_TUNE_YOLO_FILL_NT 1
+int odpl_tune_set(int32_t key, int32_t value);
+
 /* ---- in-library kernel timing (bench.py roofline leg) ------------------------------------------
  * HIP events recorded on the launch stream immediately around the named kernel of every later call.
  * No counterpart in the reference (it has no benchmark); host_ms is a HOST buffer.               */
@@ -110,8 +121,10 @@ int odpl_yolo_build_targets(const float* pred_boxes, const float* pred_cls, cons
 #define ODPL_PROF_NUM_KERNELS 16
 int odpl_profile_enable(int32_t kernel_id, int32_t on);
 /* Synchronises the recorded events, writes up to max_n durations (ms) and returns how many launches
- * were recorded since the last collect (negative: ODPL_EINVAL). */
-int odpl_profile_collect(int32_t kernel_id, float* host_ms, int32_t max_n);
+ * were recorded since the last collect (negative: ODPL_EINVAL).  Three events per launch: an empty
+ * pre->start interval prices the event pair itself; host_ms = (stop-start) - (start-pre), raw_ms
+ * (may be NULL) = stop-start uncorrected. */
+int odpl_profile_collect(int32_t kernel_id, float* host_ms, float* raw_ms, int32_t max_n);
 
 #ifdef __cplusplus
 }

@@ -91,6 +91,7 @@ class _RegionLossBase(nn.Module):
         self._cls_name = _criterion_name(cls_criterion, _lib.CLS_MODES)
         self._coord_name = _criterion_name(coord_criterion, _lib.COORD_MODES)
         self._ws = None
+        self._ws_clean_key = None        # (device, shapes) for which the workspace's state maps are known clean
         self.last_counts = None          # int32 [nscales, 8] on device: nObj, nNoobj, guard1, guard2, status
 
     # -- one C-ABI call -------------------------------------------------------------------------
@@ -139,10 +140,15 @@ class _RegionLossBase(nn.Module):
             raise OdplError("odpl_yolo_region_loss_workspace_bytes rejected the descriptor")
         if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
             self._ws = torch.empty(int(need * 1.25) + 4096, dtype=torch.uint8, device=dev)
+            self._ws_clean_key = None
+        key = (dev, torch.cuda.current_stream(dev).cuda_stream, d.B, tuple((s.G, s.A) for s in d.scale[:d.nscales]))
+        d.flags = _lib.YOLO_STATE_CLEAN if self._ws_clean_key == key else 0
+        self._ws_clean_key = None        # stays None if the call below raises
         out7 = torch.empty(7, dtype=torch.float32, device=dev)
         counts = torch.empty(d.nscales, 8, dtype=torch.int32, device=dev)
         _lib.check(L.odpl_yolo_region_loss(ctypes.byref(d), _lib.ptr(self._ws), self._ws.numel(), _lib.ptr(out7),
                                            None, _lib.ptr(counts), _lib.current_stream(dev)), "odpl_yolo_region_loss")
+        self._ws_clean_key = key         # the dense kernel reset every cell it read
         self.last_counts = counts
         return out7, counts
 

@@ -23,7 +23,7 @@ class YoloScale(ctypes.Structure):
 
 class YoloLossDesc(ctypes.Structure):
     _fields_ = [("B", c_int32), ("C", c_int32), ("nT", c_int32), ("nscales", c_int32),
-                ("coord_mode", c_int32), ("cls_mode", c_int32), ("average", c_int32),
+                ("coord_mode", c_int32), ("cls_mode", c_int32), ("average", c_int32), ("flags", c_int32),
                 ("ignore_thres", c_float), ("obj_scale", c_float), ("noobj_scale", c_float),
                 ("target", c_void_p), ("scale", YoloScale * MAX_SCALES)]
 
@@ -37,8 +37,9 @@ SIGNATURES = {
     "odpl_yolo_region_loss_workspace_bytes": (c_size_t, [POINTER(YoloLossDesc)]),
     "odpl_yolo_region_loss": (c_int32, [POINTER(YoloLossDesc), c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
     "odpl_scale_inplace_if_not_one": (c_int32, [c_void_p, c_size_t, c_void_p, c_void_p]),
+    "odpl_tune_set": (c_int32, [c_int32, c_int32]),
     "odpl_profile_enable": (c_int32, [c_int32, c_int32]),
-    "odpl_profile_collect": (c_int32, [c_int32, POINTER(c_float), c_int32]),
+    "odpl_profile_collect": (c_int32, [c_int32, POINTER(c_float), POINTER(c_float), c_int32]),
     "odpl_yolo_build_targets": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                           c_int32, c_float, c_void_p] + [c_void_p] * 10 + [c_void_p, c_void_p]),
 }
@@ -89,6 +90,14 @@ def require_cuda(*tensors):
                             f"{t.device}); there is no CPU fallback -- move inputs to cuda")
 
 
+YOLO_STATE_CLEAN = 1
+TUNE_KEYS = {"yolo_fill_f4_per_block": 0, "yolo_fill_nt": 1}
+
+
+def tune_set(name, value):
+    check(lib().odpl_tune_set(TUNE_KEYS[name], int(value)), "odpl_tune_set")
+
+
 PROF_IDS = {"yolo_dense": 0, "yolo_assign": 1, "yolo_obj": 2, "yolo_finalize": 3}
 
 
@@ -99,7 +108,9 @@ def profile_enable(name, on=True):
 def profile_collect(name, max_n=4096):
     """Durations (ms) of the named kernel's launches since the last collect (HIP events on the launch stream)."""
     buf = (c_float * max_n)()
-    n = lib().odpl_profile_collect(PROF_IDS[name], buf, max_n)
+    raw = (c_float * max_n)()
+    n = lib().odpl_profile_collect(PROF_IDS[name], buf, raw, max_n)
     if n < 0:
         raise OdplError("odpl_profile_collect failed")
-    return [buf[i] for i in range(min(n, max_n))]
+    n = min(n, max_n)
+    return [buf[i] for i in range(n)], [raw[i] for i in range(n)]

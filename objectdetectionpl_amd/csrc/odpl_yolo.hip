@@ -25,10 +25,16 @@
 namespace {
 using namespace odpl;
 
-constexpr int kAssignThreads = 1024;
+constexpr int kAssignThreads = 256;
+constexpr int kAssignRankCap = 4096;    // winners' cells staged in LDS for the raster-rank pass
 constexpr int kDenseThreads = 256;
 constexpr int kObjThreads = 128;
-constexpr int kFillF4PerBlock = 2048;   // 32 KiB of zeros per fill block (8 float4 stores / thread)
+
+// tunables (odpl_tune_set): defaults chosen on MI355X, see DESIGN.md "Kernels"
+int g_fill_f4_per_block = 2048;         // float4 stores per fill block (x16 B)
+int g_fill_nt = 1;                      // 1: non-temporal stores for the zero fill (in-step: 11.4 vs 12.1 us)
+
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 struct Scale {
     const float* head;
@@ -46,12 +52,13 @@ struct Scale {
     int fill_blk0, fill_nblk, rows_per_fill_blk;
     float aw[ODPL_MAX_ANCHORS], ah[ODPL_MAX_ANCHORS];
 };
+// state map encoding: kept at -1 ("clean") between calls: the dense kernel resets every cell it reads
 
 struct Params {
     Scale s[ODPL_MAX_SCALES];
     const float* target;
     int nscales, B, C, CH, nT, W;
-    int coord_sl1, cls_mode, average;
+    int coord_sl1, cls_mode, average, fill_nt;
     float ignore_thres, obj_scale, noobj_scale, inv_S;
     float* out7;
     float* out_scales;
@@ -62,23 +69,36 @@ __global__ __launch_bounds__(kAssignThreads) void yolo_assign_kernel(const Param
     const Scale& S = P.s[blockIdx.x];
     const int tid = threadIdx.x, nT = P.nT, G = S.G, A = S.A, B = P.B, C = P.C, W = P.W;
     __shared__ int sh_i[2 * (kAssignThreads / 64)];
+    __shared__ int s_cell[kAssignRankCap];
+    __shared__ float s_aw[ODPL_MAX_ANCHORS], s_ah[ODPL_MAX_ANCHORS];
+    __shared__ int s_flags;
+    if (tid < ODPL_MAX_ANCHORS) { s_aw[tid] = S.aw[tid]; s_ah[tid] = S.ah[tid]; }
+    if (tid == 0) s_flags = 0;
+    __syncthreads();
+    // target `tid` stays decoded in registers (the common nT <= 256 case never decodes twice)
+    TDec d0;
+    if (tid < nT) d0 = decode_target(P.target + (size_t)tid * 6, G, A, s_aw, s_ah, P.ignore_thres);
+    auto dec = [&](int t) { return t == tid ? d0 : decode_target(P.target + (size_t)t * 6, G, A, s_aw, s_ah, P.ignore_thres); };
 
-    int f1 = 0, f2 = 0, bad = 0;
+    int flags = 0;
     for (int t = tid; t < nT; t += kAssignThreads) {
-        const TDec d = decode_target(P.target + (size_t)t * 6, G, A, S.aw, S.ah, P.ignore_thres);
-        f1 |= (d.b >= B) | (d.best >= A) | (d.gj >= G) | (d.gi >= G);      // accuracy.py:340-343
-        f2 |= (d.lab >= C);                                               // accuracy.py:365
-        bad |= (d.b < -B) | (d.gj < -G) | (d.gi < -G) | (d.lab < -C);
+        const TDec d = dec(t);
+        flags |= ((d.b >= B) | (d.best >= A) | (d.gj >= G) | (d.gi >= G)) ? 1 : 0;      // accuracy.py:340-343
+        flags |= (d.lab >= C) ? 2 : 0;                                                   // accuracy.py:365
+        flags |= ((d.b < -B) | (d.gj < -G) | (d.gi < -G) | (d.lab < -C)) ? 4 : 0;
         S.tcell[t] = -1; S.trank[t] = 0;
         for (int w = 0; w < W; ++w) S.bits[(size_t)t * W + w] = 0u;
+        if (t < kAssignRankCap) s_cell[t] = -1;
     }
-    const int g1 = __syncthreads_or(f1);
-    const int g2 = __syncthreads_or(f2) | g1;
-    const int st = __syncthreads_or(bad);
+    // one barrier publishes all three flags
+    if (flags) atomicOr(&s_flags, flags);
+    __syncthreads();
+    flags = s_flags;
+    const int g1 = flags & 1 ? 1 : 0, g2 = (flags & 3) ? 1 : 0, st = flags & 4 ? 1 : 0;
 
     int left = 0, became = 0;
     for (int t = tid; t < nT; t += kAssignThreads) {
-        const TDec d = decode_target(P.target + (size_t)t * 6, G, A, S.aw, S.ah, P.ignore_thres);
+        const TDec d = dec(t);
         long long b = d.b, gj = d.gj, gi = d.gi;
         const bool upper_ok = (d.b < B) & (d.gj < G) & (d.gi < G);       // per-target guard, accuracy.py:354-356
         const bool ok = wrap_idx(b, B) & wrap_idx(gj, G) & wrap_idx(gi, G);
@@ -99,19 +119,20 @@ __global__ __launch_bounds__(kAssignThreads) void yolo_assign_kernel(const Param
     __syncthreads();
     if (!g1) {
         for (int t = tid; t < nT; t += kAssignThreads) {
-            const TDec d = decode_target(P.target + (size_t)t * 6, G, A, S.aw, S.ah, P.ignore_thres);
+            const TDec d = dec(t);
             long long b = d.b, gj = d.gj, gi = d.gi, lab = d.lab;
             if (!(wrap_idx(b, B) & wrap_idx(gj, G) & wrap_idx(gi, G))) continue;
             const int cell = (((int)b * A + d.best) * G + (int)gj) * G + (int)gi;
             const int w = __hip_atomic_load(&S.state[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1;
             if (w == t) {                                                 // last writer in row order wins
                 S.tcell[t] = cell;
+                if (t < kAssignRankCap) s_cell[t] = cell;
                 float* r = S.rec + (size_t)t * 4;
                 if (!g2) {                                                // accuracy.py:368-372
                     r[0] = d.gx - floorf(d.gx);
                     r[1] = d.gy - floorf(d.gy);
-                    r[2] = logf(d.gw / S.aw[d.best] + 1e-16f);
-                    r[3] = logf(d.gh / S.ah[d.best] + 1e-16f);
+                    r[2] = logf(d.gw / s_aw[d.best] + 1e-16f);
+                    r[3] = logf(d.gh / s_ah[d.best] + 1e-16f);
                 } else { r[0] = r[1] = r[2] = r[3] = 0.f; }
             }
             if (!g2 && wrap_idx(lab, C))                                  // accuracy.py:374, multi-hot
@@ -121,10 +142,12 @@ __global__ __launch_bounds__(kAssignThreads) void yolo_assign_kernel(const Param
     __syncthreads();
     // raster rank of every obj cell (order of pred_boxes[..., 2:4][obj_mask], losses.py:568)
     for (int t = tid; t < nT; t += kAssignThreads) {
-        const int c = S.tcell[t];
+        const int c = t < kAssignRankCap ? s_cell[t] : S.tcell[t];
         if (c < 0) continue;
         int r = 0;
-        for (int u = 0; u < nT; ++u) { const int cu = S.tcell[u]; r += (cu >= 0) & (cu < c); }
+        const int nl = nT < kAssignRankCap ? nT : kAssignRankCap;
+        for (int u = 0; u < nl; ++u) { const int cu = s_cell[u]; r += (cu >= 0) & (cu < c); }
+        for (int u = kAssignRankCap; u < nT; ++u) { const int cu = S.tcell[u]; r += (cu >= 0) & (cu < c); }
         S.trank[t] = r;
     }
     // counts
@@ -136,9 +159,9 @@ __global__ __launch_bounds__(kAssignThreads) void yolo_assign_kernel(const Param
         for (int w = 0; w < kAssignThreads / 64; ++w) { L += sh_i[w * 2]; Bc += sh_i[w * 2 + 1]; }
         S.counts[0] = Bc;                       // nObj
         S.counts[1] = B * A * S.G2 - L;         // nNoobj
-        S.counts[2] = g1 ? 1 : 0;
-        S.counts[3] = g2 ? 1 : 0;
-        S.counts[4] = st ? 1 : 0;
+        S.counts[2] = g1;
+        S.counts[3] = g2;
+        S.counts[4] = st;
         S.counts[5] = S.counts[6] = S.counts[7] = 0;
     }
 }
@@ -158,6 +181,7 @@ __device__ __forceinline__ void conf_cell(float z, int st, float w_obj, float w_
     }                                               // st == 0: ignored (anchor IoU > thres)
 }
 
+template <bool NT>
 __device__ __forceinline__ void fill_zero(float* __restrict__ base, size_t lo, size_t hi) {
     // zero base[lo, hi); base is 16-byte aligned, lo/hi arbitrary element offsets
     const int tid = threadIdx.x;
@@ -165,9 +189,24 @@ __device__ __forceinline__ void fill_zero(float* __restrict__ base, size_t lo, s
     size_t hi4 = hi & ~(size_t)3; if (hi4 < lo4) hi4 = lo4;
     if ((size_t)tid < lo4 - lo) base[lo + tid] = 0.f;      // <= 3 head elements
     if ((size_t)tid < hi - hi4) base[hi4 + tid] = 0.f;     // <= 3 tail elements
-    float4* p4 = reinterpret_cast<float4*>(base);
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (size_t i = lo4 / 4 + tid; i < hi4 / 4; i += kDenseThreads) p4[i] = z;
+    v4f* p4 = reinterpret_cast<v4f*>(base);
+    const v4f z = {0.f, 0.f, 0.f, 0.f};
+    size_t i = lo4 / 4 + tid;
+    const size_t e = hi4 / 4;
+    // 4 independent 1-KiB-per-wave stores in flight per iteration
+    for (; i + 3 * kDenseThreads < e; i += 4 * kDenseThreads) {
+        if (NT) {
+            __builtin_nontemporal_store(z, p4 + i);
+            __builtin_nontemporal_store(z, p4 + i + kDenseThreads);
+            __builtin_nontemporal_store(z, p4 + i + 2 * kDenseThreads);
+            __builtin_nontemporal_store(z, p4 + i + 3 * kDenseThreads);
+        } else {
+            p4[i] = z; p4[i + kDenseThreads] = z; p4[i + 2 * kDenseThreads] = z; p4[i + 3 * kDenseThreads] = z;
+        }
+    }
+    for (; i < e; i += kDenseThreads) {
+        if (NT) __builtin_nontemporal_store(z, p4 + i); else p4[i] = z;
+    }
 }
 
 __global__ __launch_bounds__(kDenseThreads) void yolo_dense_kernel(const Params P) {
@@ -188,7 +227,7 @@ __global__ __launch_bounds__(kDenseThreads) void yolo_dense_kernel(const Params 
         const size_t rowoff = ((size_t)plane * CH + 4) * G2;
         const float* __restrict__ z = S.head + rowoff;
         float* __restrict__ g = S.grad ? S.grad + rowoff : nullptr;
-        const int* __restrict__ st = S.state + (size_t)plane * G2;
+        int* __restrict__ st = S.state + (size_t)plane * G2;
         const float w_obj = P.obj_scale * P.inv_S / (float)S.counts[0];
         const float w_noobj = P.noobj_scale * P.inv_S / (float)S.counts[1];
         float acc[2] = {0.f, 0.f};
@@ -203,6 +242,7 @@ __global__ __launch_bounds__(kDenseThreads) void yolo_dense_kernel(const Params 
                 conf_cell(zv.z, sv.z, w_obj, w_noobj, gv.z, acc[0], acc[1]);
                 conf_cell(zv.w, sv.w, w_obj, w_noobj, gv.w, acc[0], acc[1]);
                 if (g) reinterpret_cast<float4*>(g)[i4] = gv;
+                reinterpret_cast<int4*>(st)[i4] = make_int4(-1, -1, -1, -1);      // leave the map clean for the next call
             }
         } else {
             const int i = part * kDenseThreads + tid;
@@ -210,6 +250,7 @@ __global__ __launch_bounds__(kDenseThreads) void yolo_dense_kernel(const Params 
                 float gv;
                 conf_cell(z[i], st[i], w_obj, w_noobj, gv, acc[0], acc[1]);
                 if (g) g[i] = gv;
+                st[i] = -1;
             }
         }
         block_sum<2>(acc, sh);
@@ -224,7 +265,7 @@ __global__ __launch_bounds__(kDenseThreads) void yolo_dense_kernel(const Params 
             int c = cur % CH;
             int next_conf = cur + ((4 - c) % CH + CH) % CH;     // first row >= cur with c == 4
             int seg_end = next_conf < r1 ? next_conf : r1;
-            if (seg_end > cur) fill_zero(S.grad, (size_t)cur * G2, (size_t)seg_end * G2);
+            if (seg_end > cur) { if (P.fill_nt) fill_zero<true>(S.grad, (size_t)cur * G2, (size_t)seg_end * G2); else fill_zero<false>(S.grad, (size_t)cur * G2, (size_t)seg_end * G2); }
             cur = seg_end + (next_conf < r1 ? 1 : 0);
         }
     }
@@ -318,32 +359,35 @@ __global__ __launch_bounds__(kObjThreads) void yolo_obj_kernel(const Params P) {
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void yolo_finalize_kernel(const Params P) {
-    __shared__ double shd[8 * 4];
-    __shared__ float res[ODPL_MAX_SCALES][7];
-    const int tid = threadIdx.x;
-    for (int si = 0; si < P.nscales; ++si) {
+__global__ __launch_bounds__(64 * ODPL_MAX_SCALES) void yolo_finalize_kernel(const Params P) {
+    // wave w reduces scale w (fixed lane-strided order + fixed shuffle tree => reproducible);
+    // then lanes 0..6 of wave 0 add the scales in order (losses.py:606-612)
+    __shared__ float res[ODPL_MAX_SCALES][8];
+    const int tid = threadIdx.x, lane = tid & 63, si = tid >> 6;
+    if (si < P.nscales) {
         const Scale& S = P.s[si];
+        const int nObj = S.counts[0], nNoobj = S.counts[1];
         double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};          // lx ly lw lh lcls size conf_obj conf_noobj
-        for (int t = tid; t < P.nT; t += 256) {
-            const float* p = S.obj_part + (size_t)t * 8;
-            for (int i = 0; i < 6; ++i) a[i] += (double)p[i];
+        for (int t = lane; t < P.nT; t += 64) {
+            const float4* p = reinterpret_cast<const float4*>(S.obj_part + (size_t)t * 8);
+            const float4 u = p[0], v = p[1];
+            a[0] += (double)u.x; a[1] += (double)u.y; a[2] += (double)u.z; a[3] += (double)u.w;
+            a[4] += (double)v.x; a[5] += (double)v.y;
         }
-        for (int b = tid; b < S.conf_nblk; b += 256) {
-            a[6] += (double)S.conf_part[b * 2];
-            a[7] += (double)S.conf_part[b * 2 + 1];
+        for (int b = lane; b < S.conf_nblk; b += 64) {
+            const float2 c = reinterpret_cast<const float2*>(S.conf_part)[b];
+            a[6] += (double)c.x; a[7] += (double)c.y;
         }
+#pragma unroll
         for (int i = 0; i < 8; ++i) {
             double v = a[i];
+#pragma unroll
             for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
             a[i] = v;
         }
-        if ((tid & 63) == 0) for (int i = 0; i < 8; ++i) shd[(tid >> 6) * 8 + i] = a[i];
-        __syncthreads();
-        if (tid == 0) {
+        if (lane == 0) {
             float s[8];
-            for (int i = 0; i < 8; ++i) s[i] = (float)(shd[i] + shd[8 + i] + shd[16 + i] + shd[24 + i]);
-            const int nObj = S.counts[0], nNoobj = S.counts[1];
+            for (int i = 0; i < 8; ++i) s[i] = (float)a[i];
             const float fo = (float)nObj;
             const float lx = s[0] / fo, ly = s[1] / fo, lw = s[2] / fo, lh = s[3] / fo;
             const float lcls = P.cls_mode == ODPL_CLS_CE ? s[4] / fo : s[4] / (fo * (float)P.C);
@@ -351,18 +395,18 @@ __global__ __launch_bounds__(256) void yolo_finalize_kernel(const Params P) {
             const float lconf = P.obj_scale * lobj + P.noobj_scale * lnoobj;          // losses.py:563
             const int k = nObj < P.nT ? nObj : P.nT;
             const float size = s[5] / (float)(2 * k);
-            res[si][0] = lx + ly + lw + lh + lconf + lcls;                            // losses.py:566
-            res[si][1] = lx + ly; res[si][2] = size; res[si][3] = lconf; res[si][4] = lcls;
-            res[si][5] = lobj; res[si][6] = lnoobj;
-            if (P.out_scales) for (int i = 0; i < 7; ++i) P.out_scales[si * 7 + i] = res[si][i];
+            float r[7];
+            r[0] = lx + ly + lw + lh + lconf + lcls;                                  // losses.py:566
+            r[1] = lx + ly; r[2] = size; r[3] = lconf; r[4] = lcls; r[5] = lobj; r[6] = lnoobj;
+            for (int i = 0; i < 7; ++i) { res[si][i] = r[i]; if (P.out_scales) P.out_scales[si * 7 + i] = r[i]; }
             if (P.out_counts) for (int i = 0; i < 8; ++i) P.out_counts[si * 8 + i] = S.counts[i];
         }
-        __syncthreads();
     }
+    __syncthreads();
     if (tid < 7) {
         float acc = 0.f;
-        for (int si = 0; si < P.nscales; ++si) acc += res[si][tid];                    // losses.py:606-612
-        P.out7[tid] = P.average ? acc / (float)P.nscales : acc;                        // losses.py:616-623
+        for (int i = 0; i < P.nscales; ++i) acc += res[i][tid];                       // losses.py:606-612
+        P.out7[tid] = P.average ? acc / (float)P.nscales : acc;                       // losses.py:616-623
     }
 }
 
@@ -412,7 +456,7 @@ bool make_plan(const odpl_yolo_loss_desc_t* d, Plan* p) {
         const int units = p->conf_vec[i] ? G2 / 4 : G2;
         p->conf_blk_per_row[i] = (units + kDenseThreads - 1) / kDenseThreads;
         p->conf_nblk[i] = d->B * s.A * p->conf_blk_per_row[i];
-        int rows = (kFillF4PerBlock * 4 + G2 - 1) / G2; if (rows < 1) rows = 1;
+        int rows = (g_fill_f4_per_block * 4 + G2 - 1) / G2; if (rows < 1) rows = 1;
         p->rows_per_fill_blk[i] = rows;
         const int R = d->B * s.A * CH;
         p->fill_nblk[i] = s.grad ? (R + rows - 1) / rows : 0;
@@ -449,6 +493,7 @@ extern "C" int odpl_yolo_region_loss(const odpl_yolo_loss_desc_t* d, void* works
     P.coord_sl1 = d->coord_mode == ODPL_COORD_SMOOTH_L1; P.cls_mode = d->cls_mode; P.average = d->average;
     P.ignore_thres = d->ignore_thres; P.obj_scale = d->obj_scale; P.noobj_scale = d->noobj_scale;
     P.inv_S = d->average ? 1.0f / (float)d->nscales : 1.0f;
+    P.fill_nt = g_fill_nt;
     P.out7 = out7; P.out_scales = out_scales; P.out_counts = out_counts;
     int nblk = 0;
     bool any_grad = false;
@@ -472,7 +517,7 @@ extern "C" int odpl_yolo_region_loss(const odpl_yolo_loss_desc_t* d, void* works
         S.fill_blk0 = nblk; nblk += S.fill_nblk;
     }
     (void)any_grad;
-    ODPL_HIP_TRY(hipMemsetAsync(ws, 0xFF, pl.state_bytes_total, stream));
+    if (!(d->flags & ODPL_YOLO_STATE_CLEAN)) ODPL_HIP_TRY(hipMemsetAsync(ws, 0xFF, pl.state_bytes_total, stream));
     prof_begin(ODPL_PROF_YOLO_ASSIGN, stream);
     hipLaunchKernelGGL(yolo_assign_kernel, dim3(d->nscales), dim3(kAssignThreads), 0, stream, P);
     prof_end(ODPL_PROF_YOLO_ASSIGN, stream);
@@ -488,10 +533,18 @@ extern "C" int odpl_yolo_region_loss(const odpl_yolo_loss_desc_t* d, void* works
         ODPL_HIP_TRY(hipGetLastError());
     }
     prof_begin(ODPL_PROF_YOLO_FINALIZE, stream);
-    hipLaunchKernelGGL(yolo_finalize_kernel, dim3(1), dim3(256), 0, stream, P);
+    hipLaunchKernelGGL(yolo_finalize_kernel, dim3(1), dim3(64 * ODPL_MAX_SCALES), 0, stream, P);
     prof_end(ODPL_PROF_YOLO_FINALIZE, stream);
     ODPL_HIP_TRY(hipGetLastError());
     return 0;
+}
+
+extern "C" int odpl_tune_set(int32_t key, int32_t value) {
+    switch (key) {
+        case ODPL_TUNE_YOLO_FILL_F4_PER_BLOCK: if (value < 64 || value > (1 << 20)) return ODPL_EINVAL; g_fill_f4_per_block = value; return 0;
+        case ODPL_TUNE_YOLO_FILL_NT: g_fill_nt = value ? 1 : 0; return 0;
+        default: return ODPL_EINVAL;
+    }
 }
 
 extern "C" int odpl_scale_inplace_if_not_one(float* grad, size_t n, const float* scale, void* stream_) {
