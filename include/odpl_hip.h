@@ -106,6 +106,42 @@ int odpl_yolo_build_targets(const float* pred_boxes, const float* pred_cls, cons
                             float* tx, float* ty, float* tw, float* th, float* tcls, float* tconf,
                             int32_t* status, void* stream);
 
+/* ---- RetinaNet loss: losses.py:351-472 (+ focal_loss 317-349) ------------------------------ */
+
+typedef struct {
+    const float* loc;               /* [B, An, 4] predicted offsets */
+    const float* cls;               /* [B, An, C] class logits (softmax focal) */
+    float* grad_loc;                /* d loss/d loc, or NULL (then grad_cls must be NULL too): forward only */
+    float* grad_cls;                /* d loss/d cls */
+    const float* anchors;           /* [An, 4] (cx, cy, w, h) pixels: RetinaUtils.get_anchor_boxes */
+    const float* target;            /* [nT, 6] (img, cls, cx, cy, w, h) normalised */
+    int32_t B, An, C, nT;
+    int32_t coord_mode;             /* ODPL_COORD_*: nn.SmoothL1Loss / nn.MSELoss, reduction='sum' */
+    int32_t flags;                  /* ODPL_RETINA_STATE_CLEAN */
+    float img_size;                 /* scalar target scale, losses.py:425 */
+} odpl_retina_loss_desc_t;
+
+/* the caller promises the last use of this workspace was a successful odpl_retina_loss call */
+#define ODPL_RETINA_STATE_CLEAN 1
+
+size_t odpl_retina_loss_workspace_bytes(const odpl_retina_loss_desc_t* desc);
+
+/*
+ * Replaces RetinaNetLoss.forward (losses.py:405-472) including autograd backward for a unit upstream
+ * gradient.  out3: loss, Localization, Classification.  out_counts int32[4]: num_pos, status
+ * (bit0: an image has no box -- the reference raises there, we return NaN; bit1: label >= C), nGT, 0.
+ */
+int odpl_retina_loss(const odpl_retina_loss_desc_t* desc, void* workspace, size_t workspace_bytes,
+                     float* out3, int32_t* out_counts, void* stream);
+
+/*
+ * RetinaUtils.get_anchor_boxes (RetinaUtils.py:6-31) as a device table.  Per level i (P3..P7) the host
+ * passes fm_w, fm_h (int) and grid_w, grid_h (f32 = input/fm, computed in f32 as the reference does) and
+ * the [5][9][2] f32 (w,h) table (double maths rounded once).  out: [sum fm_h*fm_w*9, 4] (cx,cy,w,h).
+ */
+int odpl_retina_anchors(const int32_t* host_fm_wh /*[5][2]*/, const float* host_grid_wh /*[5][2]*/,
+                        const float* host_anchor_wh /*[5][9][2]*/, float* out, int64_t n_out, void* stream);
+
 /* launch-geometry knobs (process-wide; defaults are the tuned values) */
 #define ODPL_TUNE_YOLO_FILL_F4_PER_BLOCK 0
 #define ODPL_TUNE_YOLO_FILL_NT 1
@@ -118,6 +154,8 @@ int odpl_tune_set(int32_t key, int32_t value);
 #define ODPL_PROF_YOLO_ASSIGN 1
 #define ODPL_PROF_YOLO_OBJ 2
 #define ODPL_PROF_YOLO_FINALIZE 3
+#define ODPL_PROF_RETINA_ASSIGN 4
+#define ODPL_PROF_RETINA_MAIN 5
 #define ODPL_PROF_NUM_KERNELS 16
 int odpl_profile_enable(int32_t kernel_id, int32_t on);
 /* Synchronises the recorded events, writes up to max_n durations (ms) and returns how many launches

@@ -1,0 +1,137 @@
+"""Host-side mirrors of the anchor-dense criteria of `LightningFunc/losses.py`: RetinaNetLoss
+(losses.py:351-472), focal_loss (317-349), SSDLoss (159-315), MultiScaleRegionLoss_v5 (70-156).
+Each forward is one C-ABI call into libodpl_hip.so; there is no CPU fallback."""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from .._lib import OdplError
+
+
+class focal_loss(nn.Module):
+    """Marker + standalone module for the reference's SOFTMAX focal loss (losses.py:317-349).
+    `configure_loss` passes this CLASS as cls_criterion, exactly like the reference."""
+
+    def __init__(self, num_classes, reduction="sum"):
+        super().__init__()
+        self.num_classes = num_classes
+        self.reduction = reduction
+
+
+def _coord_name(c):
+    if isinstance(c, str):
+        return c
+    return {nn.MSELoss: "mse_loss", nn.SmoothL1Loss: "smooth_l1_loss"}[c]
+
+
+class _RetinaLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, owner, target, loc, cls):
+        need = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
+        loc_c, cls_c = loc.contiguous(), cls.contiguous()
+        g_loc = torch.empty_like(loc_c) if need else None
+        g_cls = torch.empty_like(cls_c) if need else None
+        out3, counts = owner._launch(loc_c, cls_c, g_loc, g_cls, target)
+        ctx.grads = (g_loc, g_cls)
+        ctx.used = False
+        metrics = out3[1:]
+        ctx.mark_non_differentiable(metrics, counts)
+        return out3[0], metrics, counts
+
+    @staticmethod
+    def backward(ctx, g_loss, _gm, _gc):
+        if ctx.used:
+            raise RuntimeError("the fused RetinaNet loss frees its gradient buffers after the first backward")
+        ctx.used = True
+        g_loc, g_cls = ctx.grads
+        ctx.grads = None
+        g = g_loss.contiguous().float()
+        L = _lib.lib()
+        for gr in (g_loc, g_cls):
+            if gr is not None:
+                _lib.check(L.odpl_scale_inplace_if_not_one(_lib.ptr(gr), gr.numel(), _lib.ptr(g),
+                                                           _lib.current_stream(gr.device)), "odpl_scale_inplace_if_not_one")
+        return None, None, g_loc, g_cls
+
+
+class RetinaNetLoss(nn.Module):
+    """losses.py:351-472.  ctor `(iou_boxes, cls_criterion, coord_criterion, num_classes, img_size)`;
+    forward((loc_preds, cls_preds), targets) -> {"loss", "Localization", "Classification"}.
+    An image without any box makes the reference raise (max over an empty dim): here the three scalars
+    come back NaN and `last_counts[1] & 1` is set (no host sync on the hot path)."""
+
+    def __init__(self, iou_boxes, cls_criterion, coord_criterion, num_classes=20, img_size=600):
+        super().__init__()
+        self.num_classes = num_classes
+        self.img_size = img_size
+        self.iou_boxes = iou_boxes
+        if not (cls_criterion is focal_loss or getattr(cls_criterion, "__name__", cls_criterion) == "focal_loss"):
+            # the reference calls cls_criterion(num_classes, reduction='sum'): only focal_loss has that signature
+            raise TypeError("RetinaNetLoss needs cls_criterion=focal_loss (nn.BCELoss/nn.CrossEntropyLoss reject "
+                            "(num_classes, reduction=...) positional arguments in the reference too)")
+        self._coord_name = _coord_name(coord_criterion)
+        self._ws = None
+        self._clean_key = None
+        self._anchors_dev = None
+        self.last_counts = None
+
+    def _anchors_on(self, dev):
+        a = self._anchors_dev
+        if a is None or a.device != dev:
+            a = torch.as_tensor(self.iou_boxes, dtype=torch.float32).to(dev).contiguous()
+            self._anchors_dev = a
+        return a
+
+    def _launch(self, loc, cls, g_loc, g_cls, target):
+        _lib.require_cuda(loc, cls, target)
+        L = _lib.lib()
+        dev = loc.device
+        if loc.dtype != torch.float32 or cls.dtype != torch.float32:
+            raise TypeError("loc/cls predictions must be fp32")
+        anchors = self._anchors_on(dev)
+        B, An = loc.shape[0], loc.shape[1]
+        C = self.num_classes
+        if loc.shape != (B, An, 4) or cls.shape != (B, An, C) or anchors.shape != (An, 4):
+            raise ValueError(f"shape mismatch: loc {tuple(loc.shape)}, cls {tuple(cls.shape)}, anchors {tuple(anchors.shape)}")
+        tgt = target.float().contiguous()
+        d = _lib.RetinaLossDesc()
+        d.loc, d.cls = loc.data_ptr(), cls.data_ptr()
+        d.grad_loc = g_loc.data_ptr() if g_loc is not None else None
+        d.grad_cls = g_cls.data_ptr() if g_cls is not None else None
+        d.anchors = anchors.data_ptr()
+        d.target = tgt.data_ptr() if tgt.shape[0] else None
+        d.B, d.An, d.C, d.nT = B, An, C, tgt.shape[0]
+        d.coord_mode = _lib.COORD_MODES[self._coord_name]
+        d.img_size = float(self.img_size)
+        need = L.odpl_retina_loss_workspace_bytes(ctypes.byref(d))
+        if need == 0:
+            raise OdplError("odpl_retina_loss_workspace_bytes rejected the descriptor")
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = torch.empty(int(need * 1.25) + 4096, dtype=torch.uint8, device=dev)
+            self._clean_key = None
+        key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+        d.flags = _lib.RETINA_STATE_CLEAN if self._clean_key == key else 0
+        self._clean_key = None
+        out3 = torch.empty(3, dtype=torch.float32, device=dev)
+        counts = torch.empty(4, dtype=torch.int32, device=dev)
+        _lib.check(L.odpl_retina_loss(ctypes.byref(d), _lib.ptr(self._ws), self._ws.numel(), _lib.ptr(out3),
+                                      _lib.ptr(counts), _lib.current_stream(dev)), "odpl_retina_loss")
+        self._clean_key = key
+        self.last_counts = counts
+        return out3, counts
+
+    def forward(self, outputs, targets):
+        loc_preds, cls_preds = outputs
+        loss, metrics, _ = _RetinaLossFn.apply(self, targets, loc_preds, cls_preds)
+        return {"loss": loss, "Localization": metrics[0], "Classification": metrics[1]}
+
+
+def configure(args, iou_boxes, anchors, anch_masks, num_classes, img_size):
+    """The RetinaNet / SSD / YOLOv5 arms of configure_loss (losses.py:23-28)."""
+    cls = {"focal_loss": focal_loss, "ce_loss": nn.CrossEntropyLoss, "bce_loss": nn.BCELoss}[args.cls_criterion]
+    coord = {"mse_loss": nn.MSELoss, "smooth_l1_loss": nn.SmoothL1Loss}[args.coord_criterion]
+    if args.model_name == "RetinaNet":
+        return RetinaNetLoss(iou_boxes, cls, coord, num_classes, img_size)
+    raise NotImplementedError(f"{args.model_name}: criterion not built yet (DESIGN.md section 7)")

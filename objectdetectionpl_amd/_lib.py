@@ -28,6 +28,13 @@ class YoloLossDesc(ctypes.Structure):
                 ("target", c_void_p), ("scale", YoloScale * MAX_SCALES)]
 
 
+class RetinaLossDesc(ctypes.Structure):
+    _fields_ = [("loc", c_void_p), ("cls", c_void_p), ("grad_loc", c_void_p), ("grad_cls", c_void_p),
+                ("anchors", c_void_p), ("target", c_void_p),
+                ("B", c_int32), ("An", c_int32), ("C", c_int32), ("nT", c_int32),
+                ("coord_mode", c_int32), ("flags", c_int32), ("img_size", c_float)]
+
+
 _lib = None
 
 # name -> (restype, argtypes); every symbol include/odpl_hip.h declares must be listed here
@@ -37,6 +44,9 @@ SIGNATURES = {
     "odpl_yolo_region_loss_workspace_bytes": (c_size_t, [POINTER(YoloLossDesc)]),
     "odpl_yolo_region_loss": (c_int32, [POINTER(YoloLossDesc), c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
     "odpl_scale_inplace_if_not_one": (c_int32, [c_void_p, c_size_t, c_void_p, c_void_p]),
+    "odpl_retina_loss_workspace_bytes": (c_size_t, [POINTER(RetinaLossDesc)]),
+    "odpl_retina_loss": (c_int32, [POINTER(RetinaLossDesc), c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "odpl_retina_anchors": (c_int32, [POINTER(c_int32), POINTER(c_float), POINTER(c_float), c_void_p, ctypes.c_int64, c_void_p]),
     "odpl_tune_set": (c_int32, [c_int32, c_int32]),
     "odpl_profile_enable": (c_int32, [c_int32, c_int32]),
     "odpl_profile_collect": (c_int32, [c_int32, POINTER(c_float), POINTER(c_float), c_int32]),
@@ -91,6 +101,7 @@ def require_cuda(*tensors):
 
 
 YOLO_STATE_CLEAN = 1
+RETINA_STATE_CLEAN = 1
 TUNE_KEYS = {"yolo_fill_f4_per_block": 0, "yolo_fill_nt": 1}
 
 
@@ -98,7 +109,7 @@ def tune_set(name, value):
     check(lib().odpl_tune_set(TUNE_KEYS[name], int(value)), "odpl_tune_set")
 
 
-PROF_IDS = {"yolo_dense": 0, "yolo_assign": 1, "yolo_obj": 2, "yolo_finalize": 3}
+PROF_IDS = {"yolo_dense": 0, "yolo_assign": 1, "yolo_obj": 2, "yolo_finalize": 3, "retina_assign": 4, "retina_main": 5}
 
 
 def profile_enable(name, on=True):

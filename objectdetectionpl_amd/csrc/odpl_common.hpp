@@ -80,6 +80,37 @@ __device__ __forceinline__ float coord_deriv(float d, int smooth_l1) {
     return 2.0f * d;
 }
 
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// Zero base[lo, hi) with the whole workgroup (THREADS threads): 16-B stores on the aligned middle,
+// <=3 scalar stores at each end.  base must be 16-byte aligned; lo/hi are element offsets.
+// NT: non-temporal stores (streaming zeros that nobody in this kernel re-reads).
+template <bool NT, int THREADS>
+__device__ __forceinline__ void fill_zero(float* __restrict__ base, size_t lo, size_t hi) {
+    const int tid = threadIdx.x;
+    size_t lo4 = (lo + 3) & ~(size_t)3; if (lo4 > hi) lo4 = hi;
+    size_t hi4 = hi & ~(size_t)3; if (hi4 < lo4) hi4 = lo4;
+    if ((size_t)tid < lo4 - lo) base[lo + tid] = 0.f;
+    if ((size_t)tid < hi - hi4) base[hi4 + tid] = 0.f;
+    v4f* p4 = reinterpret_cast<v4f*>(base);
+    const v4f z = {0.f, 0.f, 0.f, 0.f};
+    size_t i = lo4 / 4 + tid;
+    const size_t e = hi4 / 4;
+    for (; i + 3 * THREADS < e; i += 4 * THREADS) {      // 4 independent 1-KiB-per-wave stores in flight
+        if (NT) {
+            __builtin_nontemporal_store(z, p4 + i);
+            __builtin_nontemporal_store(z, p4 + i + THREADS);
+            __builtin_nontemporal_store(z, p4 + i + 2 * THREADS);
+            __builtin_nontemporal_store(z, p4 + i + 3 * THREADS);
+        } else {
+            p4[i] = z; p4[i + THREADS] = z; p4[i + 2 * THREADS] = z; p4[i + 3 * THREADS] = z;
+        }
+    }
+    for (; i < e; i += THREADS) {
+        if (NT) __builtin_nontemporal_store(z, p4 + i); else p4[i] = z;
+    }
+}
+
 // torch `.long()` of an fp32 value: truncate toward zero.
 __device__ __forceinline__ long long trunc_ll(float v) { return (long long)v; }
 

@@ -260,11 +260,100 @@ def group_iou(losses, accuracy):
     save("iou", **arrays)
 
 
+def load_retina_utils():
+    from LightningFunc.utils import RetinaUtils, SSDUtils
+    return RetinaUtils, SSDUtils
+
+
+def group_anchors(losses, accuracy):
+    """G5: anchor / prior tables (bit-exact targets) + YOLO scaled anchors."""
+    import hashlib
+    RetinaUtils, SSDUtils = load_retina_utils()
+    arrays = {}
+    for w, h in ((600, 600), (1333, 800), (128, 128), (96, 160)):
+        t = RetinaUtils.get_anchor_boxes(torch.Tensor([w, h]))
+        tag = f"retina_{w}x{h}"
+        arrays[tag + "_n"] = torch.tensor(t.shape[0])
+        arrays[tag + "_sha256"] = np.frombuffer(hashlib.sha256(t.numpy().tobytes()).digest(), dtype=np.uint8)
+        arrays[tag + "_head"] = t[:64]
+        arrays[tag + "_tail"] = t[-64:]
+        if w <= 160:
+            arrays[tag + "_full"] = t
+    arrays["retina_wh_table"] = RetinaUtils.get_anchor_wh([32*32., 64*64., 128*128., 256*256., 512*512.], [1/2., 1/1., 2/1.], [1., pow(2,1/3.), pow(2,2/3.)])
+    arrays["ssd_dboxes"] = SSDUtils.get_dboxes()
+    for name, anchors, img in (("v4s0", V4_ANCHORS[0:3], 416), ("v4s1", V4_ANCHORS[3:6], 416), ("v4s2", V4_ANCHORS[6:9], 416),
+                               ("v2", [(1.3221, 1.73145), (3.19275, 4.00944), (5.05587, 8.09892), (9.47112, 4.84053), (11.2364, 10.0071)], 416)):
+        for G in (9, 13, 26, 52):
+            stride = img / G
+            arrays[f"yolo_{name}_G{G}"] = torch.FloatTensor([(aw / stride, ah / stride) for aw, ah in anchors])
+    save("anchors", **arrays)
+
+
+def retina_inputs(seed, B, C, W, H, n_gt, scale=0.3):
+    RetinaUtils, _ = load_retina_utils()
+    g = torch.Generator().manual_seed(seed)
+    anchors = RetinaUtils.get_anchor_boxes(torch.Tensor([W, H]))
+    An = anchors.shape[0]
+    loc = torch.randn(B, An, 4, generator=g) * scale
+    cls = torch.randn(B, An, C, generator=g)
+    n = B * n_gt
+    b = torch.arange(B).repeat_interleave(n_gt).float()
+    lab = torch.randint(0, C, (n,), generator=g).float()
+    wh = torch.rand(n, 2, generator=g) * 0.45 + 0.25
+    xy = torch.rand(n, 2, generator=g) * 0.6 + 0.2          # centres (the loss reads x,y as centres)
+    tgt = torch.cat([b[:, None], lab[:, None], xy, wh], 1)
+    return anchors, loc, cls, tgt
+
+
+def group_retina(losses, accuracy):
+    """G6: RetinaNetLoss (+ focal_loss alone) forward and gradients at 128x128 anchors."""
+    arrays = {}
+    C = 4
+    for coord_name, coord in (("smooth_l1_loss", nn.SmoothL1Loss), ("mse_loss", nn.MSELoss)):
+        anchors, loc, cls, tgt = retina_inputs(31, 2, C, 128, 128, 3)
+        loc.requires_grad_(); cls.requires_grad_()
+        crit = losses.RetinaNetLoss(anchors, losses.focal_loss, coord, C, 128)
+        out = crit((loc, cls), tgt)
+        out["loss"].backward()
+        tag = f"r128_{coord_name}"
+        for k, v in out.items():
+            arrays[f"{tag}_{k}"] = v
+        arrays[f"{tag}_grad_loc"] = loc.grad
+        arrays[f"{tag}_grad_cls"] = cls.grad
+    arrays["r128_anchors"] = anchors; arrays["r128_loc"] = loc; arrays["r128_cls"] = cls; arrays["r128_target"] = tgt
+    # the encoded targets themselves (index work)
+    crit = losses.RetinaNetLoss(anchors, losses.focal_loss, nn.SmoothL1Loss, C, 128)
+    for bid in range(2):
+        boxes = tgt[tgt[:, 0] == bid][:, 2:] * 128
+        ious = crit.box_iou(anchors, boxes, order="xywh")
+        mi, mid = ious.max(1)
+        arrays[f"r128_maxiou_{bid}"] = mi; arrays[f"r128_maxid_{bid}"] = mid
+    # saturated / clamped logits for the softmax clamp(1e-7, 1-1e-7) branch
+    anchors, loc, cls, tgt = retina_inputs(32, 2, C, 96, 160, 2)
+    cls = (cls * 12).requires_grad_(); loc.requires_grad_()
+    crit = losses.RetinaNetLoss(anchors, losses.focal_loss, nn.SmoothL1Loss, C, 128)
+    out = crit((loc, cls), tgt); out["loss"].backward()
+    for k, v in out.items():
+        arrays[f"rsat_{k}"] = v
+    arrays["rsat_anchors"] = anchors; arrays["rsat_loc"] = loc; arrays["rsat_cls"] = cls; arrays["rsat_target"] = tgt
+    arrays["rsat_grad_loc"] = loc.grad; arrays["rsat_grad_cls"] = cls.grad
+    # focal_loss alone
+    g = torch.Generator().manual_seed(33)
+    x = (torch.randn(64, 6, generator=g) * 3).requires_grad_()
+    y = torch.randint(0, 7, (64,), generator=g)
+    fl = losses.focal_loss(6, reduction="sum")(x, y); fl.backward()
+    arrays["focal_x"] = x; arrays["focal_y"] = y; arrays["focal_sum"] = fl; arrays["focal_grad"] = x.grad
+    arrays["focal_none"] = losses.focal_loss(6, reduction="none")(x.detach(), y)
+    save("retina", **arrays)
+
+
 GROUPS = {
     "yolo_assign": group_yolo_assign,
     "yolo_loss": group_yolo_loss,
     "yolo_config2": group_yolo_config2,
     "iou": group_iou,
+    "anchors": group_anchors,
+    "retina": group_retina,
 }
 
 

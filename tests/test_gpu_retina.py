@@ -1,0 +1,116 @@
+"""GPU parity: RetinaNet anchors + loss (through the C ABI) vs the reference's golden vectors and the oracle."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import retina as oracle_retina
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("wh", [(600, 600), (1333, 800), (128, 128), (96, 160)])
+def test_anchor_table_bit_exact(golden, wh):
+    from objectdetectionpl_amd.LightningFunc.utils.RetinaUtils import get_anchor_boxes
+    g = golden("anchors")
+    t = get_anchor_boxes(torch.Tensor(list(wh)), dev()).cpu()
+    tag = f"retina_{wh[0]}x{wh[1]}"
+    assert t.shape[0] == int(g[tag + "_n"])
+    assert np.array_equal(np.frombuffer(hashlib.sha256(t.numpy().tobytes()).digest(), dtype=np.uint8), g[tag + "_sha256"])
+
+
+def _check(out, g, tag, loc, cls, rtol=1e-4):
+    for k in ("loss", "Localization", "Classification"):
+        a, b = out[k].item(), float(g[f"{tag}_{k}"])
+        assert abs(a - b) <= rtol * abs(b) + 1e-6, (k, a, b)
+    for got, name in ((loc.grad, "grad_loc"), (cls.grad, "grad_cls")):
+        ref = g[f"{tag}_{name}"]
+        got = got.cpu().numpy()
+        assert np.array_equal(got != 0, ref != 0), name
+        scale = np.abs(ref).max()
+        assert np.allclose(got, ref, rtol=rtol, atol=1e-6 * scale + 1e-12), (name, np.abs(got - ref).max())
+
+
+@pytest.mark.parametrize("coord", ["smooth_l1_loss", "mse_loss"])
+def test_retina_loss_vs_golden(golden, coord):
+    from objectdetectionpl_amd.LightningFunc.losses_dense import RetinaNetLoss, focal_loss
+    g = golden("retina")
+    d = dev()
+    loc = T(g["r128_loc"]).to(d).requires_grad_()
+    cls = T(g["r128_cls"]).to(d).requires_grad_()
+    crit = RetinaNetLoss(T(g["r128_anchors"]), focal_loss, coord, 4, 128)
+    out = crit((loc, cls), T(g["r128_target"]).to(d))
+    out["loss"].backward()
+    _check(out, g, f"r128_{coord}", loc, cls)
+    assert int(crit.last_counts[0]) > 0 and int(crit.last_counts[1]) == 0
+    # second call on the same (clean) workspace gives the same bits
+    loc2 = loc.detach().clone().requires_grad_(); cls2 = cls.detach().clone().requires_grad_()
+    out2 = crit((loc2, cls2), T(g["r128_target"]).to(d)); out2["loss"].backward()
+    assert out2["loss"].item() == out["loss"].item() and torch.equal(cls2.grad, cls.grad) and torch.equal(loc2.grad, loc.grad)
+
+
+def test_retina_saturated_vs_golden(golden):
+    from objectdetectionpl_amd.LightningFunc.losses_dense import RetinaNetLoss, focal_loss
+    g = golden("retina")
+    d = dev()
+    loc = T(g["rsat_loc"]).to(d).requires_grad_()
+    cls = T(g["rsat_cls"]).to(d).requires_grad_()
+    crit = RetinaNetLoss(T(g["rsat_anchors"]), focal_loss, "smooth_l1_loss", 4, 128)
+    out = crit((loc, cls), T(g["rsat_target"]).to(d))
+    out["loss"].backward()
+    _check(out, g, "rsat", loc, cls)
+
+
+def test_retina_600_vs_oracle_and_properties():
+    """Reference-native 600x600 size (67 995 anchors), C=80, B=2: full parity against the oracle."""
+    from objectdetectionpl_amd.LightningFunc.losses_dense import RetinaNetLoss, focal_loss
+    from objectdetectionpl_amd.LightningFunc.utils.RetinaUtils import get_anchor_boxes
+    d = dev()
+    anchors = get_anchor_boxes([600, 600], d)
+    An, C, B = anchors.shape[0], 80, 2
+    assert An == 67995
+    g = torch.Generator().manual_seed(41)
+    loc = torch.randn(B, An, 4, generator=g) * 0.3
+    cls = torch.randn(B, An, C, generator=g)
+    n = B * 8
+    wh = torch.rand(n, 2, generator=g) * 0.45 + 0.05
+    tgt = torch.cat([torch.arange(B).repeat_interleave(8).float()[:, None], torch.randint(0, C, (n, 1), generator=g).float(),
+                     torch.rand(n, 2, generator=g) * 0.6 + 0.2, wh], 1)
+    lo = loc.clone().requires_grad_(); co = cls.clone().requires_grad_()
+    ref = oracle_retina.retina_loss(lo, co, tgt, anchors.cpu(), C, 600)
+    ref["loss"].backward()
+    ld = loc.to(d).requires_grad_(); cd = cls.to(d).requires_grad_()
+    crit = RetinaNetLoss(anchors, focal_loss, "smooth_l1_loss", C, 600)
+    out = crit((ld, cd), tgt.to(d)); out["loss"].backward()
+    for k in ref:
+        assert abs(out[k].item() - ref[k].item()) <= 1e-4 * abs(ref[k].item()) + 1e-6, k
+    assert torch.equal(cd.grad.cpu() != 0, co.grad != 0) and torch.equal(ld.grad.cpu() != 0, lo.grad != 0)
+    assert torch.allclose(cd.grad.cpu(), co.grad, rtol=1e-4, atol=1e-9)
+    assert torch.allclose(ld.grad.cpu(), lo.grad, rtol=1e-4, atol=1e-9)
+    # num_pos is index work: exact
+    _, cls_t = oracle_retina.encode_targets(anchors.cpu(), tgt, B, 600)
+    assert int(crit.last_counts[0]) == int((cls_t > 0).sum())
+    # forward only: same scalars, no gradient buffers
+    with torch.no_grad():
+        o2 = crit((ld.detach(), cd.detach()), tgt.to(d))
+    assert o2["loss"].item() == out["loss"].item()
+
+
+def test_image_without_boxes_gives_nan_and_status():
+    from objectdetectionpl_amd.LightningFunc.losses_dense import RetinaNetLoss, focal_loss
+    from objectdetectionpl_amd.LightningFunc.utils.RetinaUtils import get_anchor_boxes
+    d = dev()
+    anchors = get_anchor_boxes([128, 128], d)
+    crit = RetinaNetLoss(anchors, focal_loss, "smooth_l1_loss", 4, 128)
+    loc = torch.zeros(2, anchors.shape[0], 4, device=d); cls = torch.zeros(2, anchors.shape[0], 4, device=d)
+    out = crit((loc, cls), torch.tensor([[0, 1, .5, .5, .4, .4]], device=d))
+    assert np.isnan(out["loss"].item()) and int(crit.last_counts[1]) & 1
