@@ -145,6 +145,7 @@ int odpl_retina_anchors(const int32_t* host_fm_wh /*[5][2]*/, const float* host_
 /* launch-geometry knobs (process-wide; defaults are the tuned values) */
 #define ODPL_TUNE_YOLO_FILL_F4_PER_BLOCK 0
 #define ODPL_TUNE_YOLO_FILL_NT 1
+#define ODPL_TUNE_RETINA_FILL_NT 2
 int odpl_tune_set(int32_t key, int32_t value);
 
 /* ---- in-library kernel timing (bench.py roofline leg) ------------------------------------------

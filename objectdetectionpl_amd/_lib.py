@@ -102,7 +102,7 @@ def require_cuda(*tensors):
 
 YOLO_STATE_CLEAN = 1
 RETINA_STATE_CLEAN = 1
-TUNE_KEYS = {"yolo_fill_f4_per_block": 0, "yolo_fill_nt": 1}
+TUNE_KEYS = {"yolo_fill_f4_per_block": 0, "yolo_fill_nt": 1, "retina_fill_nt": 2}
 
 
 def tune_set(name, value):

@@ -21,156 +21,161 @@
 
 namespace {
 using namespace odpl;
-constexpr int kT = 256;           // anchors per workgroup
-constexpr int kGtTile = 256;      // GT boxes staged per LDS tile
-
-struct GtRec { float x1, y1, x2, y2, area, cx, cy, w, h; int label; };   // 40 B
+constexpr int kT = 256;           // anchors per tile / workgroup
+constexpr int kRowWGs = 512;      // workgroups of the main launch that walk the positive rows (4 waves each)
+}
+namespace odpl { int g_retina_fill_nt = 1; }
+namespace {
 
 struct RParams {
     const float* loc; const float* cls; float* grad_loc; float* grad_cls;
     const float* anchors; const float* target;
-    int B, An, C, nT, coord_sl1, nblk_x;
+    int B, An, C, nT, coord_sl1, nblk_x, ntiles;
     float img_size;
-    GtRec* gt; int* gt_off;        // [nT], [B+1]
-    int* code;                     // [B*An]
-    int* counters;                 // [0] num_pos (kept 0 between calls), [1] status
-    float* part;                   // [B*nblk_x*2] loc_sum, cls_sum
+    int* code;                     // [B*An]  -1 ignore, 0 background, (target_row << 12 | label+1) positive
+    int* tile_cnt;                 // [ntiles] positives per tile
+    int* tile_off;                 // [ntiles+1] exclusive scan; tile_off[ntiles] = num_pos
+    int* row_tile;                 // [B*An] (first num_pos used): tile of positive row r
+    unsigned char* tile_pos;       // [ntiles*256] (first tile_cnt used): local index of the k-th positive of a tile
+    int* status;                   // [0] status bits (kept 0 between calls)
+    float* part;                   // [B*An*2] (first num_pos*2 used): loc term, cls term per positive row
     float* out3; int* out_counts;
 };
 
-__global__ __launch_bounds__(256) void retina_gt_kernel(const RParams P) {
-    // one thread per image: count, then fill in row order (losses.py:425-426)
-    __shared__ int s_cnt[1024];
-    const int tid = threadIdx.x;
-    int bad = 0;
-    for (int b = tid; b < P.B; b += 256) {
-        int c = 0;
-        for (int t = 0; t < P.nT; ++t) c += (P.target[(size_t)t * 6] == (float)b);
-        s_cnt[b] = c;
-        bad |= (c == 0);           // the reference raises on an image without boxes (max over an empty dim)
-    }
-    bad = __syncthreads_or(bad);
-    if (tid == 0) {
-        int o = 0;
-        for (int b = 0; b < P.B; ++b) { P.gt_off[b] = o; o += s_cnt[b]; }
-        P.gt_off[P.B] = o;
-        if (bad) atomicOr(&P.counters[1], 1);
-    }
-    __syncthreads();
-    for (int b = tid; b < P.B; b += 256) {
-        int o = P.gt_off[b];
-        for (int t = 0; t < P.nT; ++t) {
-            const float* y = P.target + (size_t)t * 6;
-            if (y[0] != (float)b) continue;
-            GtRec r;
-            r.cx = y[2] * P.img_size; r.cy = y[3] * P.img_size; r.w = y[4] * P.img_size; r.h = y[5] * P.img_size;
-            r.x1 = r.cx - r.w / 2.0f; r.y1 = r.cy - r.h / 2.0f;            // change_box_order, losses.py:373
-            r.x2 = r.cx + r.w / 2.0f; r.y2 = r.cy + r.h / 2.0f;
-            r.area = (r.x2 - r.x1 + 1.0f) * (r.y2 - r.y1 + 1.0f);          // losses.py:401
-            r.label = (int)trunc_ll(y[1]);
-            P.gt[o++] = r;
-        }
-    }
-}
+// ---- assign: thread = anchor; the image's boxes come straight from the target rows, compacted in row
+// order through LDS 256 rows at a time (losses.py:425-441)
+struct GtLds { float x1, y1, x2, y2, area; int row; int label; };
 
 __global__ __launch_bounds__(kT) void retina_assign_kernel(const RParams P) {
-    __shared__ GtRec s_gt[kGtTile];
-    __shared__ int s_red[kT / 64];
-    const int b = blockIdx.y, tid = threadIdx.x, a = blockIdx.x * kT + tid;
+    __shared__ GtLds s_gt[kT];
+    __shared__ int s_wcnt[kT / 64];
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, a = blockIdx.x * kT + tid;
     const bool live = a < P.An;
     Box4 ab; float a_area = 0.f;
     if (live) {
         const float4 an = reinterpret_cast<const float4*>(P.anchors)[a];
-        ab.x1 = an.x - an.z / 2.0f; ab.y1 = an.y - an.w / 2.0f;
+        ab.x1 = an.x - an.z / 2.0f; ab.y1 = an.y - an.w / 2.0f;          // change_box_order, losses.py:373
         ab.x2 = an.x + an.z / 2.0f; ab.y2 = an.y + an.w / 2.0f;
-        a_area = (ab.x2 - ab.x1 + 1.0f) * (ab.y2 - ab.y1 + 1.0f);
+        a_area = (ab.x2 - ab.x1 + 1.0f) * (ab.y2 - ab.y1 + 1.0f);        // losses.py:400
     }
-    const int g0 = P.gt_off[b], M = P.gt_off[b + 1] - g0;
-    float best = 0.f; int bi = 0;
-    for (int base = 0; base < M; base += kGtTile) {
-        const int n = (M - base) < kGtTile ? (M - base) : kGtTile;
+    float best = 0.f; int best_row = -1, best_label = 0, M = 0;
+    for (int base = 0; base < P.nT; base += kT) {
+        const int t = base + tid;
+        bool match = false;
+        float y1 = 0, y2 = 0, y3 = 0, y4 = 0, y5 = 0;
+        if (t < P.nT) {
+            const float* y = P.target + (size_t)t * 6;
+            match = (y[0] == (float)b);
+            y1 = y[1]; y2 = y[2]; y3 = y[3]; y4 = y[4]; y5 = y[5];
+        }
+        const unsigned long long mk = __ballot(match);
+        __syncthreads();                                   // previous chunk fully consumed
+        if (lane == 0) s_wcnt[wv] = __popcll(mk);
         __syncthreads();
-        if (tid < n) s_gt[tid] = P.gt[g0 + base + tid];
+        int off = 0, n = 0;
+        for (int w = 0; w < kT / 64; ++w) { if (w < wv) off += s_wcnt[w]; n += s_wcnt[w]; }
+        if (match) {
+            GtLds r;
+            const float cx = y2 * P.img_size, cy = y3 * P.img_size, w = y4 * P.img_size, h = y5 * P.img_size;
+            r.x1 = cx - w / 2.0f; r.y1 = cy - h / 2.0f; r.x2 = cx + w / 2.0f; r.y2 = cy + h / 2.0f;
+            r.area = (r.x2 - r.x1 + 1.0f) * (r.y2 - r.y1 + 1.0f);         // losses.py:401
+            r.row = t; r.label = (int)trunc_ll(y1);
+            s_gt[off + __popcll(mk & ((1ull << lane) - 1ull))] = r;
+        }
         __syncthreads();
         if (live) {
             for (int j = 0; j < n; ++j) {
-                const GtRec& r = s_gt[j];
+                const GtLds& r = s_gt[j];
                 // losses.py:394-402: lt = max, rb = min, wh = (rb - lt + 1).clamp(0)
                 const float w = fmaxf(fminf(ab.x2, r.x2) - fmaxf(ab.x1, r.x1) + 1.0f, 0.0f);
                 const float h = fmaxf(fminf(ab.y2, r.y2) - fmaxf(ab.y1, r.y1) + 1.0f, 0.0f);
                 const float inter = w * h;
                 const float v = inter / (a_area + r.area - inter);
-                const int m = base + j;
-                if (m == 0) { best = v; bi = 0; }
-                else if (best == best && (v > best || v != v)) { best = v; bi = m; }   // first index on ties
+                if (M + j == 0 || (best == best && (v > best || v != v))) {   // first index on ties
+                    best = v; best_row = r.row; best_label = r.label;
+                }
             }
         }
-    }
-    int code = 0, pos = 0;
-    if (live && M > 0) {
-        const int cls_t = 1 + P.gt[g0 + bi].label;                         // losses.py:437
-        if (best < 0.5f) code = 0; else code = cls_t;                      // :439
-        if (best > 0.4f && best < 0.5f) code = -1;                         // :440-441
-        if (code > 0) {
-            if (code > P.C || bi > 32767) { atomicOr(&P.counters[1], 2); code = 0; }   // eye(C+1)[y] IndexError upstream
-            else { code = (bi << 16) | code; pos = 1; }
-        }
-    }
-    if (live) P.code[(size_t)b * P.An + a] = code;
-    pos = wave_sum_i(pos);
-    if ((tid & 63) == 0) s_red[tid >> 6] = pos;
-    __syncthreads();
-    if (tid == 0) {
-        int n = 0;
-        for (int w = 0; w < kT / 64; ++w) n += s_red[w];
-        if (n) atomicAdd(&P.counters[0], n);
-    }
-}
-
-template <bool NT>
-__global__ __launch_bounds__(kT) void retina_main_kernel(const RParams P) {
-    __shared__ int s_pos[kT];
-    __shared__ int s_wcnt[kT / 64];
-    __shared__ float s_part[2 * (kT / 64)];
-    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int a0 = blockIdx.x * kT, na = (P.An - a0) < kT ? (P.An - a0) : kT;
-    const int C = P.C;
-    const bool want_grad = P.grad_cls != nullptr;
-    if (want_grad) {
-        const size_t r0 = (size_t)b * P.An + a0;
-        fill_zero<NT, kT>(P.grad_cls, r0 * C, (r0 + na) * C);
-        fill_zero<NT, kT>(P.grad_loc, r0 * 4, (r0 + na) * 4);
+        M += n;
     }
     int code = 0;
-    if (tid < na) code = P.code[(size_t)b * P.An + a0 + tid];
-    // positive rows of the tile in ascending order (ballot + popcount prefix): fixed summation order
-    const unsigned long long mk = __ballot(code > 0);
-    if (lane == 0) s_wcnt[wv] = __popcll(mk);
-    __syncthreads();                                          // also orders the zero stores before the row stores
-    int off = 0, npos_blk = 0;
-    for (int w = 0; w < kT / 64; ++w) { if (w < wv) off += s_wcnt[w]; npos_blk += s_wcnt[w]; }
-    if (code > 0) s_pos[off + __popcll(mk & ((1ull << lane) - 1ull))] = tid;
+    if (live && M > 0) {
+        const int cls_t = 1 + best_label;                                  // losses.py:437
+        code = best < 0.5f ? 0 : cls_t;                                    // :439
+        if (best > 0.4f && best < 0.5f) code = -1;                         // :440-441
+        if (code > 0) {
+            if (code > P.C) { atomicOr(&P.status[0], 2); code = 0; }       // eye(C+1)[y] IndexError upstream
+            else code = (best_row << 12) | code;
+        }
+    }
+    if (M == 0 && tid == 0) atomicOr(&P.status[0], 1);                     // image without boxes: reference raises
+    if (live) P.code[(size_t)b * P.An + a] = code;
+    // positives of this tile, ascending local index
+    const unsigned long long pk = __ballot(code > 0);
     __syncthreads();
-    float acc_loc = 0.f, acc_cls = 0.f;
-    if (npos_blk > 0) {
-        const float npos = fmaxf(1.0f, (float)P.counters[0]);  // losses.py:469
+    if (lane == 0) s_wcnt[wv] = __popcll(pk);
+    __syncthreads();
+    int off = 0, n = 0;
+    for (int w = 0; w < kT / 64; ++w) { if (w < wv) off += s_wcnt[w]; n += s_wcnt[w]; }
+    const int tile = b * P.nblk_x + blockIdx.x;
+    if (code > 0) P.tile_pos[(size_t)tile * kT + off + __popcll(pk & ((1ull << lane) - 1ull))] = (unsigned char)tid;
+    if (tid == 0) P.tile_cnt[tile] = n;
+}
+
+// ---- scan: exclusive scan of the per-tile counts (1 WG), num_pos, and the row -> tile map
+__global__ __launch_bounds__(1024) void retina_scan_kernel(const RParams P) {
+    __shared__ int s_w[16];
+    __shared__ int s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < P.ntiles; base += 1024) {
+        const int i = base + tid;
+        const int c = i < P.ntiles ? P.tile_cnt[i] : 0;
+        int v = c;                                          // inclusive wave scan
+        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(v, o, 64); if (lane >= o) v += u; }
+        if (lane == 63) s_w[wv] = v;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wv; ++w) woff += s_w[w];
+        const int excl = s_carry + woff + v - c;
+        if (i < P.ntiles) {
+            P.tile_off[i] = excl;
+            for (int k = 0; k < c; ++k) P.row_tile[excl + k] = i;
+        }
+        __syncthreads();
+        if (tid == 1023) s_carry = excl + c;
+        __syncthreads();
+    }
+    if (tid == 0) P.tile_off[P.ntiles] = s_carry;
+}
+
+// ---- main: WGs [0, kRowWGs) walk the positive rows (one wave per row); the rest zero-fill the tiles
+template <bool NT>
+__global__ __launch_bounds__(kT) void retina_main_kernel(const RParams P) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, C = P.C;
+    const bool want_grad = P.grad_cls != nullptr;
+    if ((int)blockIdx.x < kRowWGs) {
+        const int num_pos = P.tile_off[P.ntiles];
+        const float npos = fmaxf(1.0f, (float)num_pos);                    // losses.py:469
         const float inv = 1.0f / npos;
-        const int g0 = P.gt_off[b];
-        for (int i = wv; i < npos_blk; i += kT / 64) {
-            const int row = s_pos[i];
-            const size_t ga = (size_t)b * P.An + a0 + row;
+        for (int r = blockIdx.x * (kT / 64) + wv; r < num_pos; r += kRowWGs * (kT / 64)) {
+            const int tile = P.row_tile[r];
+            const int local = P.tile_pos[(size_t)tile * kT + (r - P.tile_off[tile])];
+            const int b = tile / P.nblk_x, a = (tile - b * P.nblk_x) * kT + local;
+            const size_t ga = (size_t)b * P.An + a;
             const int cd = P.code[ga];
-            const int m = cd >> 16, label = (cd & 0xffff) - 1;
-            const GtRec r = P.gt[g0 + m];
-            const float4 an = reinterpret_cast<const float4*>(P.anchors)[a0 + row];
+            const int trow = cd >> 12, label = (cd & 0xfff) - 1;
+            const float* y = P.target + (size_t)trow * 6;
+            const float4 an = reinterpret_cast<const float4*>(P.anchors)[a];
             // ---- localisation (losses.py:434-436, 458-461), lanes 0..3
             float l_loc = 0.f;
             if (lane < 4) {
                 float tgt;
-                if (lane == 0) tgt = (r.cx - an.x) / an.z;
-                else if (lane == 1) tgt = (r.cy - an.y) / an.w;
-                else if (lane == 2) tgt = logf(r.w / an.z);
-                else tgt = logf(r.h / an.w);
+                if (lane == 0) tgt = (y[2] * P.img_size - an.x) / an.z;
+                else if (lane == 1) tgt = (y[3] * P.img_size - an.y) / an.w;
+                else if (lane == 2) tgt = logf(y[4] * P.img_size / an.z);
+                else tgt = logf(y[5] * P.img_size / an.w);
                 const float d = P.loc[ga * 4 + lane] - tgt;
                 l_loc = coord_elem(d, P.coord_sl1);
                 if (want_grad) P.grad_loc[ga * 4 + lane] = coord_deriv(d, P.coord_sl1) * inv;
@@ -198,22 +203,32 @@ __global__ __launch_bounds__(kT) void retina_main_kernel(const RParams P) {
                 }
             }
             l_loc = wave_sum(l_loc);
-            if (lane == 0) { acc_loc += l_loc; acc_cls += l_cls; }
+            if (lane == 0) { P.part[(size_t)r * 2] = l_loc; P.part[(size_t)r * 2 + 1] = l_cls; }
         }
+        return;
     }
-    if (lane == 0) { s_part[wv * 2] = acc_loc; s_part[wv * 2 + 1] = acc_cls; }
-    __syncthreads();
-    if (tid == 0) {
-        float a = 0.f, c = 0.f;
-        for (int w = 0; w < kT / 64; ++w) { a += s_part[w * 2]; c += s_part[w * 2 + 1]; }
-        const size_t pb = ((size_t)b * P.nblk_x + blockIdx.x) * 2;
-        P.part[pb] = a; P.part[pb + 1] = c;
+    if (!want_grad) return;
+    // ---- zero fill of one tile; tiles that own positive rows leave those rows to the row waves
+    const int tile = blockIdx.x - kRowWGs;
+    const int b = tile / P.nblk_x, a0 = (tile - b * P.nblk_x) * kT;
+    const int na = (P.An - a0) < kT ? (P.An - a0) : kT;
+    const size_t r0 = (size_t)b * P.An + a0;
+    if (P.tile_cnt[tile] == 0) {
+        fill_zero<NT, kT>(P.grad_cls, r0 * C, (r0 + na) * C);
+        fill_zero<NT, kT>(P.grad_loc, r0 * 4, (r0 + na) * 4);
+    } else {
+        if (tid < na && P.code[r0 + tid] <= 0) reinterpret_cast<float4*>(P.grad_loc)[r0 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int row = wv; row < na; row += kT / 64) {
+            if (P.code[r0 + row] > 0) continue;
+            float* gx = P.grad_cls + (r0 + row) * C;
+            for (int k = lane; k < C; k += 64) gx[k] = 0.f;
+        }
     }
 }
 
 __global__ __launch_bounds__(256) void retina_finalize_kernel(const RParams P) {
     __shared__ double sh[2 * 4];
-    const int tid = threadIdx.x, n = P.B * P.nblk_x;
+    const int tid = threadIdx.x, n = P.tile_off[P.ntiles];
     double a = 0, c = 0;
     for (int i = tid; i < n; i += 256) { a += (double)P.part[(size_t)i * 2]; c += (double)P.part[(size_t)i * 2 + 1]; }
     for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); c += __shfl_down(c, o, 64); }
@@ -221,33 +236,37 @@ __global__ __launch_bounds__(256) void retina_finalize_kernel(const RParams P) {
     __syncthreads();
     if (tid == 0) {
         const float loc = (float)(sh[0] + sh[2] + sh[4] + sh[6]), cls = (float)(sh[1] + sh[3] + sh[5] + sh[7]);
-        const int np = P.counters[0], st = P.counters[1];
-        const float npos = fmaxf(1.0f, (float)np);
+        const int st = P.status[0];
+        const float npos = fmaxf(1.0f, (float)n);
         const bool bad = st & 1;                              // an image without boxes: the reference raises
         P.out3[0] = bad ? NAN : (loc + cls) / npos;           // losses.py:471
         P.out3[1] = bad ? NAN : loc / npos;
         P.out3[2] = bad ? NAN : cls / npos;
-        if (P.out_counts) { P.out_counts[0] = np; P.out_counts[1] = st; P.out_counts[2] = P.gt_off[P.B]; P.out_counts[3] = 0; }
-        P.counters[0] = 0; P.counters[1] = 0;                 // clean for the next call
+        if (P.out_counts) { P.out_counts[0] = n; P.out_counts[1] = st; P.out_counts[2] = 0; P.out_counts[3] = 0; }
+        P.status[0] = 0;                                      // clean for the next call
     }
 }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-struct RPlan { size_t counters, gt, gt_off, code, part, total; int nblk_x; };
+struct RPlan { size_t status, code, tile_cnt, tile_off, row_tile, tile_pos, part, total; int nblk_x, ntiles; };
 
 bool make_rplan(const odpl_retina_loss_desc_t* d, RPlan* p) {
-    if (!d || d->B < 1 || d->B > 1024 || d->An < 1 || d->C < 1 || d->C > 65535 || d->nT < 0) return false;
+    if (!d || d->B < 1 || d->An < 1 || d->C < 1 || d->C > 4094 || d->nT < 0 || d->nT > (1 << 19)) return false;
     if (!d->loc || !d->cls || !d->anchors || (d->nT > 0 && !d->target)) return false;
     if ((d->grad_loc == nullptr) != (d->grad_cls == nullptr)) return false;
+    if ((long long)d->B * d->An * d->C > 0x7fffffffLL * 4) return false;
     p->nblk_x = (d->An + kT - 1) / kT;
-    const size_t nT = d->nT > 0 ? d->nT : 1;
+    p->ntiles = p->nblk_x * d->B;
+    const size_t cells = (size_t)d->B * d->An;
     size_t off = 0;
-    p->counters = off; off += 256;              // first: kept zero between calls
-    p->gt = off;       off += align_up(nT * sizeof(GtRec), 256);
-    p->gt_off = off;   off += align_up(((size_t)d->B + 1) * sizeof(int), 256);
-    p->code = off;     off += align_up((size_t)d->B * d->An * sizeof(int), 256);
-    p->part = off;     off += align_up((size_t)d->B * p->nblk_x * 2 * sizeof(float), 256);
+    p->status = off;   off += 256;              // first: kept zero between calls
+    p->code = off;     off += align_up(cells * sizeof(int), 256);
+    p->tile_cnt = off; off += align_up((size_t)p->ntiles * sizeof(int), 256);
+    p->tile_off = off; off += align_up(((size_t)p->ntiles + 1) * sizeof(int), 256);
+    p->row_tile = off; off += align_up(cells * sizeof(int), 256);
+    p->tile_pos = off; off += align_up((size_t)p->ntiles * kT, 256);
+    p->part = off;     off += align_up(cells * 2 * sizeof(float), 256);
     p->total = off;
     return true;
 }
@@ -270,20 +289,23 @@ extern "C" int odpl_retina_loss(const odpl_retina_loss_desc_t* d, void* workspac
     P.loc = d->loc; P.cls = d->cls; P.grad_loc = d->grad_loc; P.grad_cls = d->grad_cls;
     P.anchors = d->anchors; P.target = d->target;
     P.B = d->B; P.An = d->An; P.C = d->C; P.nT = d->nT; P.coord_sl1 = d->coord_mode == ODPL_COORD_SMOOTH_L1;
-    P.nblk_x = pl.nblk_x; P.img_size = d->img_size;
-    P.gt = (GtRec*)(ws + pl.gt); P.gt_off = (int*)(ws + pl.gt_off); P.code = (int*)(ws + pl.code);
-    P.counters = (int*)(ws + pl.counters); P.part = (float*)(ws + pl.part);
+    P.nblk_x = pl.nblk_x; P.ntiles = pl.ntiles; P.img_size = d->img_size;
+    P.code = (int*)(ws + pl.code); P.tile_cnt = (int*)(ws + pl.tile_cnt); P.tile_off = (int*)(ws + pl.tile_off);
+    P.row_tile = (int*)(ws + pl.row_tile); P.tile_pos = (unsigned char*)(ws + pl.tile_pos);
+    P.status = (int*)(ws + pl.status); P.part = (float*)(ws + pl.part);
     P.out3 = out3; P.out_counts = out_counts;
-    if (!(d->flags & ODPL_RETINA_STATE_CLEAN)) ODPL_HIP_TRY(hipMemsetAsync(P.counters, 0, 256, stream));
-    hipLaunchKernelGGL(retina_gt_kernel, dim3(1), dim3(256), 0, stream, P);
-    ODPL_HIP_TRY(hipGetLastError());
+    if (!(d->flags & ODPL_RETINA_STATE_CLEAN)) ODPL_HIP_TRY(hipMemsetAsync(P.status, 0, 256, stream));
     const dim3 grid(pl.nblk_x, d->B);
     prof_begin(ODPL_PROF_RETINA_ASSIGN, stream);
     hipLaunchKernelGGL(retina_assign_kernel, grid, dim3(kT), 0, stream, P);
     prof_end(ODPL_PROF_RETINA_ASSIGN, stream);
     ODPL_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(retina_scan_kernel, dim3(1), dim3(1024), 0, stream, P);
+    ODPL_HIP_TRY(hipGetLastError());
+    const int nmain = kRowWGs + (d->grad_cls ? pl.ntiles : 0);
     prof_begin(ODPL_PROF_RETINA_MAIN, stream);
-    hipLaunchKernelGGL(retina_main_kernel<true>, grid, dim3(kT), 0, stream, P);
+    if (g_retina_fill_nt) hipLaunchKernelGGL(retina_main_kernel<true>, dim3(nmain), dim3(kT), 0, stream, P);
+    else hipLaunchKernelGGL(retina_main_kernel<false>, dim3(nmain), dim3(kT), 0, stream, P);
     prof_end(ODPL_PROF_RETINA_MAIN, stream);
     ODPL_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(retina_finalize_kernel, dim3(1), dim3(256), 0, stream, P);

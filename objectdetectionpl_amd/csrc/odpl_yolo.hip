@@ -510,8 +510,11 @@ extern "C" int odpl_yolo_region_loss(const odpl_yolo_loss_desc_t* d, void* works
     return 0;
 }
 
+namespace odpl { extern int g_retina_fill_nt; }
+
 extern "C" int odpl_tune_set(int32_t key, int32_t value) {
     switch (key) {
+        case ODPL_TUNE_RETINA_FILL_NT: odpl::g_retina_fill_nt = value ? 1 : 0; return 0;
         case ODPL_TUNE_YOLO_FILL_F4_PER_BLOCK: if (value < 64 || value > (1 << 20)) return ODPL_EINVAL; g_fill_f4_per_block = value; return 0;
         case ODPL_TUNE_YOLO_FILL_NT: g_fill_nt = value ? 1 : 0; return 0;
         default: return ODPL_EINVAL;
