@@ -142,6 +142,24 @@ int odpl_retina_loss(const odpl_retina_loss_desc_t* desc, void* workspace, size_
 int odpl_retina_anchors(const int32_t* host_fm_wh /*[5][2]*/, const float* host_grid_wh /*[5][2]*/,
                         const float* host_anchor_wh /*[5][9][2]*/, float* out, int64_t n_out, void* stream);
 
+/* ---- IoU family: accuracy.py:6-114, 289-303; losses.py:375-403 ------------------------------- */
+
+/* kind: 0 bbox_iou (accuracy.py:39-69, "+1" pixels, union+1e-16; GIoU/DIoU/CIoU kwargs ignored there),
+ *       1 IoU / 2 GIoU / 3 DIoU / 4 CIoU of bbox_iou_v5 (accuracy.py:71-114), 5 iou (accuracy.py:6-37).
+ * box1 is [n1,4] with n1 == n or 1 (broadcast), box2 [n,4]; layout_4xn: both stored transposed [4,n]
+ * (bbox_iou_v5's convention).  x1y1x2y2 == 0: boxes are (cx,cy,w,h). */
+int odpl_pair_iou(const float* box1, const float* box2, float* out, int64_t n, int64_t n1, int32_t kind,
+                  int32_t x1y1x2y2, int32_t layout_4xn, void* stream);
+/* bbox_wh_iou stacked over anchors (accuracy.py:297-303, 331): anchors [A,2], gwh [nT,2] -> out [A,nT] */
+int odpl_bbox_wh_iou(const float* anchors, const float* gwh, float* out, int32_t A, int64_t nT, void* stream);
+/* RetinaNetLoss.box_iou (losses.py:375-403): [N,4] x [M,4] -> [N,M]; xywh != 0: order='xywh' */
+int odpl_box_iou_matrix(const float* box1, const float* box2, float* out, int64_t N, int32_t M, int32_t xywh, void* stream);
+/* xywh2xyxy (accuracy.py:289-295) on [n,4] */
+int odpl_xywh2xyxy(const float* in, float* out, int64_t n, void* stream);
+/* get_dboxes (SSDUtils.py:5-27): host passes fks[6], boxes-per-cell[6] (= num_boxes+1) and the per-level
+ * (w,h) table [6][6][2] (double maths rounded once); out [sum fk*fk*per, 4], clamped to <= 1. */
+int odpl_ssd_priors(const int32_t* host_fk, const int32_t* host_per_cell, const float* host_wh, float* out, int64_t n_out, void* stream);
+
 /* launch-geometry knobs (process-wide; defaults are the tuned values) */
 #define ODPL_TUNE_YOLO_FILL_F4_PER_BLOCK 0
 #define ODPL_TUNE_YOLO_FILL_NT 1

@@ -47,6 +47,11 @@ SIGNATURES = {
     "odpl_retina_loss_workspace_bytes": (c_size_t, [POINTER(RetinaLossDesc)]),
     "odpl_retina_loss": (c_int32, [POINTER(RetinaLossDesc), c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "odpl_retina_anchors": (c_int32, [POINTER(c_int32), POINTER(c_float), POINTER(c_float), c_void_p, ctypes.c_int64, c_void_p]),
+    "odpl_pair_iou": (c_int32, [c_void_p, c_void_p, c_void_p, ctypes.c_int64, ctypes.c_int64, c_int32, c_int32, c_int32, c_void_p]),
+    "odpl_bbox_wh_iou": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, ctypes.c_int64, c_void_p]),
+    "odpl_box_iou_matrix": (c_int32, [c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_int32, c_int32, c_void_p]),
+    "odpl_xywh2xyxy": (c_int32, [c_void_p, c_void_p, ctypes.c_int64, c_void_p]),
+    "odpl_ssd_priors": (c_int32, [POINTER(c_int32), POINTER(c_int32), POINTER(c_float), c_void_p, ctypes.c_int64, c_void_p]),
     "odpl_tune_set": (c_int32, [c_int32, c_int32]),
     "odpl_profile_enable": (c_int32, [c_int32, c_int32]),
     "odpl_profile_collect": (c_int32, [c_int32, POINTER(c_float), POINTER(c_float), c_int32]),
