@@ -160,6 +160,48 @@ int odpl_xywh2xyxy(const float* in, float* out, int64_t n, void* stream);
  * (w,h) table [6][6][2] (double maths rounded once); out [sum fk*fk*per, 4], clamped to <= 1. */
 int odpl_ssd_priors(const int32_t* host_fk, const int32_t* host_per_cell, const float* host_wh, float* out, int64_t n_out, void* stream);
 
+/* ---- batched NMS ------------------------------------------------------------------------------ */
+
+#define ODPL_NMS_STATE_CLEAN 1      /* last use of the workspace was a successful call of the same entry */
+
+typedef struct {
+    const float* head[ODPL_MAX_SCALES];   /* raw heads [B, A*no, G, G] exactly as forward() returns them */
+    int32_t G[ODPL_MAX_SCALES];
+    int32_t nscales, B, A, no;            /* no = 5 + C ("answers", YOLOV4.py:240) */
+    float conf_thres;                     /* -0.0151: YOLOV4.py:228 overwrites the argument */
+    float nms_thres;                      /* 0.4 */
+    int32_t flags;
+} odpl_yolo_nms_desc_t;
+
+size_t odpl_yolo_nms_workspace_bytes(const odpl_yolo_nms_desc_t* desc);
+/*
+ * YOLO confidence-weighted merge NMS, model/YOLOV4.py:221-283 (== YOLOV3.py:273-335, YOLOV2.py:159-222 with
+ * A = 5, YOLOV5.py:157-218: pass its [B,3,G,G,no] buffer as-is with A = 3 -- the reference reinterprets that
+ * memory as [B,3,no,G,G]).  out_dets [B, N, 7] (x1,y1,x2,y2,conf,cls_conf,cls_pred), N = sum A*G*G; the first
+ * out_counts[b] rows of image b are valid; out_counts[b] == -1 <=> the reference leaves output[b] = None.
+ */
+int odpl_yolo_nms(const odpl_yolo_nms_desc_t* desc, void* workspace, size_t workspace_bytes,
+                  float* out_dets, int32_t* out_counts, void* stream);
+
+typedef struct {
+    const float* loc;                     /* [B, An, 4] */
+    const float* cls;                     /* [B, An, C] logits */
+    const float* anchors;                 /* [An, 4] cx,cy,w,h */
+    int32_t B, An, C, topk;               /* topk = 100 */
+    float nms_thresh;                     /* 0.5 */
+    float class_thresh;                   /* 0.45 */
+    int32_t flags;
+} odpl_greedy_nms_desc_t;
+
+size_t odpl_greedy_nms_workspace_bytes(const odpl_greedy_nms_desc_t* desc);
+/*
+ * RetinaNet / SSD non_max_suppression, model/RetinaNet.py:117-178 == model/SSD.py:249-310 (mode='union').
+ * out_dets [B, topk, 7] (x1,y1,x2,y2,0,score,label); out_counts[b*2] = kept rows, out_counts[b*2+1] = number of
+ * candidates above class_thresh (the reference raises IndexError when that is exactly 1).
+ */
+int odpl_greedy_nms(const odpl_greedy_nms_desc_t* desc, void* workspace, size_t workspace_bytes,
+                    float* out_dets, int32_t* out_counts, void* stream);
+
 /* launch-geometry knobs (process-wide; defaults are the tuned values) */
 #define ODPL_TUNE_YOLO_FILL_F4_PER_BLOCK 0
 #define ODPL_TUNE_YOLO_FILL_NT 1
@@ -175,6 +217,10 @@ int odpl_tune_set(int32_t key, int32_t value);
 #define ODPL_PROF_YOLO_FINALIZE 3
 #define ODPL_PROF_RETINA_ASSIGN 4
 #define ODPL_PROF_RETINA_MAIN 5
+#define ODPL_PROF_YOLO_NMS_PREP 6
+#define ODPL_PROF_YOLO_NMS_IMAGE 7
+#define ODPL_PROF_GREEDY_NMS_PREP 8
+#define ODPL_PROF_GREEDY_NMS_IMAGE 9
 #define ODPL_PROF_NUM_KERNELS 16
 int odpl_profile_enable(int32_t kernel_id, int32_t on);
 /* Synchronises the recorded events, writes up to max_n durations (ms) and returns how many launches

@@ -35,6 +35,18 @@ class RetinaLossDesc(ctypes.Structure):
                 ("coord_mode", c_int32), ("flags", c_int32), ("img_size", c_float)]
 
 
+class YoloNmsDesc(ctypes.Structure):
+    _fields_ = [("head", c_void_p * MAX_SCALES), ("G", c_int32 * MAX_SCALES),
+                ("nscales", c_int32), ("B", c_int32), ("A", c_int32), ("no", c_int32),
+                ("conf_thres", c_float), ("nms_thres", c_float), ("flags", c_int32)]
+
+
+class GreedyNmsDesc(ctypes.Structure):
+    _fields_ = [("loc", c_void_p), ("cls", c_void_p), ("anchors", c_void_p),
+                ("B", c_int32), ("An", c_int32), ("C", c_int32), ("topk", c_int32),
+                ("nms_thresh", c_float), ("class_thresh", c_float), ("flags", c_int32)]
+
+
 _lib = None
 
 # name -> (restype, argtypes); every symbol include/odpl_hip.h declares must be listed here
@@ -52,6 +64,10 @@ SIGNATURES = {
     "odpl_box_iou_matrix": (c_int32, [c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_int32, c_int32, c_void_p]),
     "odpl_xywh2xyxy": (c_int32, [c_void_p, c_void_p, ctypes.c_int64, c_void_p]),
     "odpl_ssd_priors": (c_int32, [POINTER(c_int32), POINTER(c_int32), POINTER(c_float), c_void_p, ctypes.c_int64, c_void_p]),
+    "odpl_yolo_nms_workspace_bytes": (c_size_t, [POINTER(YoloNmsDesc)]),
+    "odpl_yolo_nms": (c_int32, [POINTER(YoloNmsDesc), c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "odpl_greedy_nms_workspace_bytes": (c_size_t, [POINTER(GreedyNmsDesc)]),
+    "odpl_greedy_nms": (c_int32, [POINTER(GreedyNmsDesc), c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "odpl_tune_set": (c_int32, [c_int32, c_int32]),
     "odpl_profile_enable": (c_int32, [c_int32, c_int32]),
     "odpl_profile_collect": (c_int32, [c_int32, POINTER(c_float), POINTER(c_float), c_int32]),
@@ -114,7 +130,8 @@ def tune_set(name, value):
     check(lib().odpl_tune_set(TUNE_KEYS[name], int(value)), "odpl_tune_set")
 
 
-PROF_IDS = {"yolo_dense": 0, "yolo_assign": 1, "yolo_obj": 2, "yolo_finalize": 3, "retina_assign": 4, "retina_main": 5}
+PROF_IDS = {"yolo_dense": 0, "yolo_assign": 1, "yolo_obj": 2, "yolo_finalize": 3, "retina_assign": 4, "retina_main": 5,
+            "yolo_nms_prep": 6, "yolo_nms_image": 7, "greedy_nms_prep": 8, "greedy_nms_image": 9}
 
 
 def profile_enable(name, on=True):

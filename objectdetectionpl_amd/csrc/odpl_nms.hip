@@ -1,0 +1,473 @@
+// Batched NMS for MI355X (gfx950).
+//
+// (1) YOLO confidence-weighted MERGE NMS -- model/YOLOV4.py:221-283 (== YOLOV3.py:273-335,
+//     YOLOV2.py:159-222, and YOLOV5.py:157-218 on its reinterpreted memory).  The reference flattens the
+//     RAW heads (no sigmoid, no grid decode), thresholds conf at -0.0151, sorts by conf*max(cls) and loops
+//     {IoU(+1) > thr & same label -> conf-weighted merge into the pivot, drop}.
+//       prep   (N/256 x B WGs)  reads the NCHW heads once (coalesced along the G*G plane; class max/argmax
+//                               per candidate), writes box/conf/cls_conf/label/score as SoA        [HBM read bound]
+//       image  (1 WG / image)   bitonic sort of (score desc, index asc) pairs, gather into sorted SoA, then
+//                               the sequential pivot loop with a block-parallel sweep and wave reductions
+//                               (weighted sums + next pivot = min alive index) per pivot.
+//     The pivot is always retired (the reference never terminates when a box's self-IoU <= thr).
+// (2) RetinaNet / SSD greedy top-k NMS -- model/RetinaNet.py:117-178 == SSD.py:249-310.
+//       prep   (An/256 x B WGs)  class rows staged through LDS (coalesced 16-B loads, padded rows), sigmoid-max
+//                               + first argmax per anchor, pass flag (score > class_thresh)
+//       image  (1 WG / image)   stable compaction of the candidates, k-th largest by bisection on the float
+//                               bits (top-k without sorting the candidates), LDS bitonic sort of the <= topk
+//                               survivors, greedy suppression, the reference's output quirks (keep indexes the
+//                               FILTERED list, boxes/labels come from the UNFILTERED arrays; the last single
+//                               box is dropped).
+#include <limits.h>
+#include "odpl_common.hpp"
+#include "odpl_boxes_dev.hpp"
+#include "odpl_profile.hpp"
+#include "../../include/odpl_hip.h"
+
+namespace {
+using namespace odpl;
+
+constexpr int kPrepT = 256;
+constexpr int kImgT = 1024;
+
+struct YParams {
+    const float* head[ODPL_MAX_SCALES];
+    int G[ODPL_MAX_SCALES], first[ODPL_MAX_SCALES + 1];
+    int nscales, B, A, no, N, Npad;
+    float conf_thres, nms_thres;
+    // per image SoA, unsorted then sorted
+    float4* box; float* conf; float* cconf; int* label; float* score;
+    float4* sbox; float* sconf; float* scconf; int* slabel;
+    float* key; unsigned* idx;           // [B*Npad] sort buffers
+    int* nvalid;                          // [B] (kept 0 between calls)
+    float* out; int* out_counts;
+};
+
+__global__ __launch_bounds__(kPrepT) void yolo_nms_prep_kernel(const YParams P) {
+    const int b = blockIdx.y, n = blockIdx.x * kPrepT + threadIdx.x;
+    int valid = 0;
+    if (n < P.N) {
+        int s = 0;
+        while (s + 1 < P.nscales && n >= P.first[s + 1]) ++s;
+        const int G2 = P.G[s] * P.G[s], r = n - P.first[s], a = r / G2, sp = r - a * G2;
+        const float* base = P.head[s] + ((size_t)(b * P.A + a) * P.no) * G2 + sp;
+        const float x = base[0], y = base[(size_t)G2], w = base[(size_t)2 * G2], h = base[(size_t)3 * G2];
+        const float cf = base[(size_t)4 * G2];
+        float best = base[(size_t)5 * G2]; int bi = 0;                       // max(1): first index on ties
+        for (int k = 1; k < P.no - 5; ++k) {
+            const float v = base[(size_t)(5 + k) * G2];
+            if (best == best && (v > best || v != v)) { best = v; bi = k; }
+        }
+        const Box4 bx = corners_of(x, y, w, h);                              // xywh2xyxy, YOLOV4.py:253
+        const size_t o = (size_t)b * P.N + n;
+        P.box[o] = make_float4(bx.x1, bx.y1, bx.x2, bx.y2);
+        P.conf[o] = cf; P.cconf[o] = best; P.label[o] = bi;
+        valid = cf >= P.conf_thres;                                          // YOLOV4.py:258
+        const float sc = cf * best;                                          // YOLOV4.py:263
+        P.key[(size_t)b * P.Npad + n] = valid ? sc : -INFINITY;
+        P.idx[(size_t)b * P.Npad + n] = valid ? (unsigned)n : 0xffffffffu;
+    } else if (n < P.Npad) {
+        P.key[(size_t)b * P.Npad + n] = -INFINITY;
+        P.idx[(size_t)b * P.Npad + n] = 0xffffffffu;
+    }
+    const unsigned long long m = __ballot(valid);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&P.nvalid[b], __popcll(m));
+}
+
+// (key desc, idx asc): a strict total order, so the unstable network gives a unique result
+__device__ __forceinline__ bool before(float ka, unsigned ia, float kb, unsigned ib) {
+    return ka > kb || (ka == kb && ia < ib);
+}
+
+__device__ void bitonic_sort_global(float* key, unsigned* idx, int npad) {
+    for (int k = 2; k <= npad; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < npad / 2; t += blockDim.x) {
+                const int i = ((t / j) * 2 * j) + (t % j), l = i + j;
+                const bool up = ((i & k) == 0);
+                const float ki = key[i], kl = key[l];
+                const unsigned ii = idx[i], il = idx[l];
+                const bool sw = up ? before(kl, il, ki, ii) : before(ki, ii, kl, il);
+                if (sw) { key[i] = kl; key[l] = ki; idx[i] = il; idx[l] = ii; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(kImgT) void yolo_nms_image_kernel(const YParams P) {
+    __shared__ float s_red[6 * (kImgT / 64)];
+    __shared__ int s_min[kImgT / 64];
+    __shared__ int s_p;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nv = P.nvalid[b];
+    float* key = P.key + (size_t)b * P.Npad;
+    unsigned* idx = P.idx + (size_t)b * P.Npad;
+    float* out = P.out + (size_t)b * P.N * 7;
+    if (nv == 0) {                                             // "continue": output[image_i] stays None
+        if (tid == 0) { P.out_counts[b] = -1; P.nvalid[b] = 0; }
+        return;
+    }
+    bitonic_sort_global(key, idx, P.Npad);
+    const size_t o0 = (size_t)b * P.N;
+    for (int r = tid; r < nv; r += kImgT) {                    // gather into sorted order
+        const unsigned n = idx[r];
+        P.sbox[o0 + r] = P.box[o0 + n]; P.sconf[o0 + r] = P.conf[o0 + n];
+        P.scconf[o0 + r] = P.cconf[o0 + n]; P.slabel[o0 + r] = P.label[o0 + n];
+    }
+    __syncthreads();
+    const float4* sbox = P.sbox + o0; const float* sconf = P.sconf + o0; int* slabel = P.slabel + o0;
+    int p = 0, K = 0;
+    while (p < nv) {
+        const float4 tb = sbox[p];
+        const int lt = slabel[p];
+        Box4 top; top.x1 = tb.x; top.y1 = tb.y; top.x2 = tb.z; top.y2 = tb.w;
+        float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        int nxt = INT_MAX;
+        for (int j = p + tid; j < nv; j += kImgT) {
+            const int l = slabel[j];
+            if (l < 0) continue;
+            const float4 q = sbox[j];
+            Box4 bj; bj.x1 = q.x; bj.y1 = q.y; bj.x2 = q.z; bj.y2 = q.w;
+            const bool inv = (l == lt) && (iou_plus1(top, bj) > P.nms_thres);     // YOLOV4.py:271-274
+            if (inv) {
+                const float w = sconf[j];                                           // YOLOV4.py:275-277
+                acc[0] += w; acc[1] += w * q.x; acc[2] += w * q.y; acc[3] += w * q.z; acc[4] += w * q.w;
+                slabel[j] = -1;
+            } else if (j != p) {
+                nxt = min(nxt, j);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 5; ++i) acc[i] = wave_sum(acc[i]);
+        for (int o = 32; o > 0; o >>= 1) nxt = min(nxt, __shfl_down(nxt, o, 64));
+        if (lane == 0) { for (int i = 0; i < 5; ++i) s_red[wv * 6 + i] = acc[i]; s_min[wv] = nxt; }
+        __syncthreads();
+        if (tid == 0) {
+            float a[5] = {0.f, 0.f, 0.f, 0.f, 0.f}; int mn = INT_MAX;
+            for (int w = 0; w < kImgT / 64; ++w) { for (int i = 0; i < 5; ++i) a[i] += s_red[w * 6 + i]; mn = min(mn, s_min[w]); }
+            float* row = out + (size_t)K * 7;
+            row[0] = a[1] / a[0]; row[1] = a[2] / a[0]; row[2] = a[3] / a[0]; row[3] = a[4] / a[0];
+            row[4] = sconf[p]; row[5] = P.scconf[o0 + p]; row[6] = (float)lt;
+            slabel[p] = -1;                                     // the pivot is always retired
+            s_p = mn;
+        }
+        __syncthreads();
+        p = s_p; ++K;
+        __syncthreads();
+    }
+    if (tid == 0) { P.out_counts[b] = K; P.nvalid[b] = 0; }
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+inline int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+struct YPlan { size_t nvalid, box, conf, cconf, label, sbox, sconf, scconf, slabel, key, idx, total; int N, Npad; };
+
+bool make_yplan(const odpl_yolo_nms_desc_t* d, YPlan* p) {
+    if (!d || d->nscales < 1 || d->nscales > ODPL_MAX_SCALES || d->B < 1 || d->A < 1 || d->no < 6) return false;
+    long long N = 0;
+    for (int i = 0; i < d->nscales; ++i) { if (d->G[i] < 1 || !d->head[i]) return false; N += (long long)d->A * d->G[i] * d->G[i]; }
+    if (N > (1 << 24)) return false;
+    p->N = (int)N; p->Npad = next_pow2((int)N); if (p->Npad < 2) p->Npad = 2;
+    const size_t BN = (size_t)d->B * N, BP = (size_t)d->B * p->Npad;
+    size_t off = 0;
+    p->nvalid = off; off += align_up((size_t)d->B * sizeof(int), 256);
+    p->box = off;    off += align_up(BN * 16, 256);
+    p->conf = off;   off += align_up(BN * 4, 256);
+    p->cconf = off;  off += align_up(BN * 4, 256);
+    p->label = off;  off += align_up(BN * 4, 256);
+    p->sbox = off;   off += align_up(BN * 16, 256);
+    p->sconf = off;  off += align_up(BN * 4, 256);
+    p->scconf = off; off += align_up(BN * 4, 256);
+    p->slabel = off; off += align_up(BN * 4, 256);
+    p->key = off;    off += align_up(BP * 4, 256);
+    p->idx = off;    off += align_up(BP * 4, 256);
+    p->total = off;
+    return true;
+}
+}  // namespace
+
+extern "C" size_t odpl_yolo_nms_workspace_bytes(const odpl_yolo_nms_desc_t* d) {
+    YPlan p;
+    return make_yplan(d, &p) ? p.total : 0;
+}
+
+extern "C" int odpl_yolo_nms(const odpl_yolo_nms_desc_t* d, void* workspace, size_t workspace_bytes,
+                             float* out_dets, int32_t* out_counts, void* stream_) {
+    YPlan pl;
+    if (!make_yplan(d, &pl) || !workspace || workspace_bytes < pl.total || !out_dets || !out_counts) return ODPL_EINVAL;
+    if ((uintptr_t)workspace & 15) return ODPL_EINVAL;
+    hipStream_t stream = (hipStream_t)stream_;
+    char* ws = (char*)workspace;
+    YParams P;
+    int first = 0;
+    for (int i = 0; i < ODPL_MAX_SCALES; ++i) {
+        P.head[i] = i < d->nscales ? d->head[i] : nullptr; P.G[i] = i < d->nscales ? d->G[i] : 1;
+        P.first[i] = first; if (i < d->nscales) first += d->A * d->G[i] * d->G[i];
+    }
+    P.first[ODPL_MAX_SCALES] = first;
+    for (int i = d->nscales; i < ODPL_MAX_SCALES; ++i) P.first[i] = first;
+    P.nscales = d->nscales; P.B = d->B; P.A = d->A; P.no = d->no; P.N = pl.N; P.Npad = pl.Npad;
+    P.conf_thres = d->conf_thres; P.nms_thres = d->nms_thres;
+    P.box = (float4*)(ws + pl.box); P.conf = (float*)(ws + pl.conf); P.cconf = (float*)(ws + pl.cconf);
+    P.label = (int*)(ws + pl.label); P.score = nullptr;
+    P.sbox = (float4*)(ws + pl.sbox); P.sconf = (float*)(ws + pl.sconf); P.scconf = (float*)(ws + pl.scconf);
+    P.slabel = (int*)(ws + pl.slabel); P.key = (float*)(ws + pl.key); P.idx = (unsigned*)(ws + pl.idx);
+    P.nvalid = (int*)(ws + pl.nvalid); P.out = out_dets; P.out_counts = out_counts;
+    if (!(d->flags & ODPL_NMS_STATE_CLEAN)) ODPL_HIP_TRY(hipMemsetAsync(P.nvalid, 0, (size_t)d->B * sizeof(int), stream));
+    prof_begin(ODPL_PROF_YOLO_NMS_PREP, stream);
+    hipLaunchKernelGGL(yolo_nms_prep_kernel, dim3((pl.Npad + kPrepT - 1) / kPrepT, d->B), dim3(kPrepT), 0, stream, P);
+    prof_end(ODPL_PROF_YOLO_NMS_PREP, stream);
+    ODPL_HIP_TRY(hipGetLastError());
+    prof_begin(ODPL_PROF_YOLO_NMS_IMAGE, stream);
+    hipLaunchKernelGGL(yolo_nms_image_kernel, dim3(d->B), dim3(kImgT), 0, stream, P);
+    prof_end(ODPL_PROF_YOLO_NMS_IMAGE, stream);
+    ODPL_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// =================================================================================================
+// (2) RetinaNet / SSD greedy top-k NMS
+namespace {
+constexpr int kRows = 64;             // anchors per LDS sub-tile in the prep kernel (4 lanes scan one row)
+constexpr int kMaxTopk = 1024;
+
+struct GParams {
+    const float* loc; const float* cls; const float* anchors;
+    int B, An, C, topk;
+    float nms_thresh, class_thresh;
+    float* score; int* label;          // [B*An] all anchors
+    float* ckey; int* cidx;            // [B*An] candidates (compacted, index order)
+    float* out; int* out_counts;
+};
+
+__device__ __forceinline__ Box4 decode_anchor(const float* loc4, const float* an4) {
+    // RetinaNet.py:121-126: xy = loc_xy * a_wh + a_xy ; wh = exp(loc_wh) * a_wh ; box = (xy - wh/2, xy + wh/2)
+    const float x = loc4[0] * an4[2] + an4[0], y = loc4[1] * an4[3] + an4[1];
+    const float w = expf(loc4[2]) * an4[2], h = expf(loc4[3]) * an4[3];
+    return corners_of(x, y, w, h);
+}
+
+__global__ __launch_bounds__(256) void greedy_nms_prep_kernel(const GParams P) {
+    extern __shared__ float s_tile[];                       // kRows * (C + 1)
+    const int b = blockIdx.y, tid = threadIdx.x, C = P.C, ld = C + 1;
+    const int a_blk = blockIdx.x * 256;
+    for (int sub = 0; sub < 256; sub += kRows) {
+        const int a0 = a_blk + sub;
+        if (a0 >= P.An) break;
+        const int nr = (P.An - a0) < kRows ? (P.An - a0) : kRows;
+        const float* src = P.cls + ((size_t)b * P.An + a0) * C;
+        __syncthreads();
+        for (int e = tid; e < nr * C; e += 256) {           // coalesced: consecutive lanes, consecutive floats
+            const int r = e / C, k = e - r * C;
+            s_tile[r * ld + k] = src[e];
+        }
+        __syncthreads();
+        const int r = tid >> 2, q = tid & 3;
+        float best = -1.f; int bi = 0x7fffffff;             // sigmoid > 0 > -1
+        if (r < nr) {
+            for (int k = q; k < C; k += 4) {
+                const float s = sigmoidf_(s_tile[r * ld + k]);
+                if (s > best || (s != s && best == best)) { best = s; bi = k; }
+            }
+        }
+        // combine the 4 lanes of a row: larger value, then smaller index (torch.max(1): first index on ties)
+        for (int o = 1; o < 4; o <<= 1) {
+            const float ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (r < nr && q == 0) {
+            const size_t o = (size_t)b * P.An + a0 + r;
+            P.score[o] = best; P.label[o] = bi;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kImgT) void greedy_nms_image_kernel(const GParams P) {
+    __shared__ int s_wcnt[kImgT / 64];
+    __shared__ int s_off, s_cnt, s_p;
+    __shared__ float s_key[kMaxTopk]; __shared__ int s_pos[kMaxTopk];
+    __shared__ float4 s_box[kMaxTopk]; __shared__ float s_area[kMaxTopk]; __shared__ int s_alive[kMaxTopk];
+    __shared__ int s_keep[kMaxTopk];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const size_t o0 = (size_t)b * P.An;
+    const float* score = P.score + o0;
+    float* ckey = P.ckey + o0; int* cidx = P.cidx + o0;
+    if (tid == 0) s_off = 0;
+    __syncthreads();
+    // ---- stable compaction of score > class_thresh (RetinaNet.py:129-130)
+    for (int base = 0; base < P.An; base += kImgT) {
+        const int a = base + tid;
+        const float s = a < P.An ? score[a] : 0.f;
+        const bool f = a < P.An && s > P.class_thresh;
+        const unsigned long long m = __ballot(f);
+        if (lane == 0) s_wcnt[wv] = __popcll(m);
+        __syncthreads();
+        int off = s_off, tot = 0;
+        for (int w = 0; w < kImgT / 64; ++w) { if (w < wv) off += s_wcnt[w]; tot += s_wcnt[w]; }
+        if (f) { const int pos = off + __popcll(m & ((1ull << lane) - 1ull)); ckey[pos] = s; cidx[pos] = a; }
+        __syncthreads();
+        if (tid == 0) s_off += tot;
+        __syncthreads();
+    }
+    const int n = s_off;
+    float* out = P.out + (size_t)b * P.topk * 7;
+    if (n <= 1) {            // 0: nothing; 1: the reference raises IndexError (0-dim squeeze) -- reported via counts
+        if (tid == 0) { P.out_counts[b * 2] = 0; P.out_counts[b * 2 + 1] = n; }
+        return;
+    }
+    // ---- top-k by score (RetinaNet.py:140-141): k-th largest by bisection on the float bits
+    int m = n < P.topk ? n : P.topk;
+    unsigned T = 0;
+    if (n > P.topk) {
+        unsigned lo = 0u, hi = 0x7f800000u;                 // scores are positive finite floats
+        while (lo < hi) {                                   // largest T with count(bits >= T) >= topk
+            const unsigned mid = lo + (hi - lo + 1) / 2;
+            int c = 0;
+            for (int i = tid; i < n; i += kImgT) c += (__float_as_uint(ckey[i]) >= mid);
+            c = wave_sum_i(c);
+            __syncthreads();
+            if (lane == 0) s_wcnt[wv] = c;
+            __syncthreads();
+            int tot = 0;
+            for (int w = 0; w < kImgT / 64; ++w) tot += s_wcnt[w];
+            if (tot >= P.topk) lo = mid; else hi = mid - 1;
+        }
+        T = lo;
+    }
+    // gather the selected candidates: bits > T first (all of them), then bits == T in index order until m
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int base = 0; base < n; base += kImgT) {
+            const int i = base + tid;
+            const unsigned u = i < n ? __float_as_uint(ckey[i]) : 0u;
+            const bool f = i < n && (pass == 0 ? u > T : (u == T));
+            const unsigned long long mk = __ballot(f);
+            if (lane == 0) s_wcnt[wv] = __popcll(mk);
+            __syncthreads();
+            int off = s_cnt, tot = 0;
+            for (int w = 0; w < kImgT / 64; ++w) { if (w < wv) off += s_wcnt[w]; tot += s_wcnt[w]; }
+            if (f) { const int pos = off + __popcll(mk & ((1ull << lane) - 1ull)); if (pos < m) { s_key[pos] = ckey[i]; s_pos[pos] = i; } }
+            __syncthreads();
+            if (tid == 0) s_cnt = min(s_cnt + tot, m);
+            __syncthreads();
+        }
+        if (n <= P.topk) break;                             // T == 0: pass 0 took everything
+    }
+    // ---- sort the m survivors by (score desc, filtered position asc) in LDS
+    int mp = 1; while (mp < m) mp <<= 1;
+    for (int i = m + tid; i < mp; i += kImgT) { s_key[i] = -INFINITY; s_pos[i] = 0x7fffffff; }
+    __syncthreads();
+    for (int k = 2; k <= mp; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < mp / 2; t += kImgT) {
+                const int i = ((t / j) * 2 * j) + (t % j), l = i + j;
+                const bool up = ((i & k) == 0);
+                const float ki = s_key[i], kl = s_key[l]; const int pi = s_pos[i], pl = s_pos[l];
+                const bool sw = up ? before(kl, (unsigned)pl, ki, (unsigned)pi) : before(ki, (unsigned)pi, kl, (unsigned)pl);
+                if (sw) { s_key[i] = kl; s_key[l] = ki; s_pos[i] = pl; s_pos[l] = pi; }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- candidate boxes (decode of the candidate's anchor) and areas (RetinaNet.py:133-139)
+    if (tid < m) {
+        const int a = cidx[s_pos[tid]];
+        const Box4 bx = decode_anchor(P.loc + (o0 + a) * 4, P.anchors + (size_t)a * 4);
+        s_box[tid] = make_float4(bx.x1, bx.y1, bx.x2, bx.y2);
+        s_area[tid] = (bx.x2 - bx.x1 + 1.0f) * (bx.y2 - bx.y1 + 1.0f);
+        s_alive[tid] = 1;
+    }
+    if (tid == 0) s_p = 0;
+    __syncthreads();
+    // ---- greedy loop (RetinaNet.py:143-169): stop WITHOUT keeping when one box is left
+    int K = 0;
+    while (true) {
+        int c = (tid < m && s_alive[tid]) ? 1 : 0;
+        c = wave_sum_i(c);
+        __syncthreads();
+        if (lane == 0) s_wcnt[wv] = c;
+        __syncthreads();
+        int alive = 0;
+        for (int w = 0; w < kImgT / 64; ++w) alive += s_wcnt[w];
+        if (alive <= 1) break;
+        const int p = s_p;
+        const float4 tb = s_box[p]; const float ta = s_area[p];
+        int nxt = INT_MAX;
+        if (tid < m && tid != p && s_alive[tid]) {
+            const float4 q = s_box[tid];
+            const float w = fmaxf(fminf(q.z, tb.z) - fmaxf(q.x, tb.x) + 1.0f, 0.0f);     // clamp(min=x1[i]) etc.
+            const float h = fmaxf(fminf(q.w, tb.w) - fmaxf(q.y, tb.y) + 1.0f, 0.0f);
+            const float inter = w * h;
+            const float ovr = inter / (ta + s_area[tid] - inter);
+            if (ovr <= P.nms_thresh) nxt = tid; else s_alive[tid] = 0;
+        }
+        for (int o = 32; o > 0; o >>= 1) nxt = min(nxt, __shfl_down(nxt, o, 64));
+        __syncthreads();
+        if (lane == 0) s_wcnt[wv] = nxt;
+        __syncthreads();
+        if (tid == 0) {
+            int mn = INT_MAX;
+            for (int w = 0; w < kImgT / 64; ++w) mn = min(mn, s_wcnt[w]);
+            s_keep[K] = s_pos[p];
+            s_alive[p] = 0;
+            s_p = mn == INT_MAX ? 0 : mn;
+        }
+        ++K;
+        __syncthreads();
+    }
+    // ---- output rows (RetinaNet.py:170-176): boxes / labels indexed by the FILTERED position in the UNFILTERED arrays
+    if (tid < K) {
+        const int k = s_keep[tid];
+        const Box4 bx = decode_anchor(P.loc + (o0 + k) * 4, P.anchors + (size_t)k * 4);
+        float* row = out + (size_t)tid * 7;
+        row[0] = bx.x1; row[1] = bx.y1; row[2] = bx.x2; row[3] = bx.y2; row[4] = 0.0f;
+        row[5] = ckey[k]; row[6] = (float)P.label[o0 + k];
+    }
+    if (tid == 0) { P.out_counts[b * 2] = K; P.out_counts[b * 2 + 1] = n; }
+}
+
+struct GPlan { size_t score, label, ckey, cidx, total; };
+bool make_gplan(const odpl_greedy_nms_desc_t* d, GPlan* p) {
+    if (!d || d->B < 1 || d->An < 1 || d->C < 1 || d->topk < 1 || d->topk > kMaxTopk) return false;
+    if (!d->loc || !d->cls || !d->anchors) return false;
+    if ((size_t)kRows * (d->C + 1) * 4 > 60 * 1024) return false;
+    const size_t BN = (size_t)d->B * d->An;
+    size_t off = 0;
+    p->score = off; off += align_up(BN * 4, 256);
+    p->label = off; off += align_up(BN * 4, 256);
+    p->ckey = off;  off += align_up(BN * 4, 256);
+    p->cidx = off;  off += align_up(BN * 4, 256);
+    p->total = off;
+    return true;
+}
+}  // namespace
+
+extern "C" size_t odpl_greedy_nms_workspace_bytes(const odpl_greedy_nms_desc_t* d) {
+    GPlan p;
+    return make_gplan(d, &p) ? p.total : 0;
+}
+
+extern "C" int odpl_greedy_nms(const odpl_greedy_nms_desc_t* d, void* workspace, size_t workspace_bytes,
+                               float* out_dets, int32_t* out_counts, void* stream_) {
+    GPlan pl;
+    if (!make_gplan(d, &pl) || !workspace || workspace_bytes < pl.total || !out_dets || !out_counts) return ODPL_EINVAL;
+    hipStream_t stream = (hipStream_t)stream_;
+    char* ws = (char*)workspace;
+    GParams P;
+    P.loc = d->loc; P.cls = d->cls; P.anchors = d->anchors; P.B = d->B; P.An = d->An; P.C = d->C; P.topk = d->topk;
+    P.nms_thresh = d->nms_thresh; P.class_thresh = d->class_thresh;
+    P.score = (float*)(ws + pl.score); P.label = (int*)(ws + pl.label); P.ckey = (float*)(ws + pl.ckey); P.cidx = (int*)(ws + pl.cidx);
+    P.out = out_dets; P.out_counts = out_counts;
+    prof_begin(ODPL_PROF_GREEDY_NMS_PREP, stream);
+    hipLaunchKernelGGL(greedy_nms_prep_kernel, dim3((d->An + 255) / 256, d->B), dim3(256), (size_t)kRows * (d->C + 1) * 4, stream, P);
+    prof_end(ODPL_PROF_GREEDY_NMS_PREP, stream);
+    ODPL_HIP_TRY(hipGetLastError());
+    prof_begin(ODPL_PROF_GREEDY_NMS_IMAGE, stream);
+    hipLaunchKernelGGL(greedy_nms_image_kernel, dim3(d->B), dim3(kImgT), 0, stream, P);
+    prof_end(ODPL_PROF_GREEDY_NMS_IMAGE, stream);
+    ODPL_HIP_TRY(hipGetLastError());
+    return 0;
+}

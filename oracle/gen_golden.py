@@ -347,6 +347,71 @@ def group_retina(losses, accuracy):
     save("retina", **arrays)
 
 
+def nms_heads(seed, B, C, grids, spread):
+    """Heads whose first five channels are valid geometry: centres in clusters, positive sizes, raw conf
+    around the -0.0151 threshold; no exact score ties."""
+    g = torch.Generator().manual_seed(seed)
+    heads = []
+    for G in grids:
+        h = torch.randn(B, 3, 5 + C, G, G, generator=g)
+        centres = torch.rand(B, 3, 2, 1, 1, generator=g) * 300 + 50
+        h[:, :, 0:2] = centres + torch.randn(B, 3, 2, G, G, generator=g) * spread
+        h[:, :, 2:4] = torch.rand(B, 3, 2, G, G, generator=g) * 80 + 20
+        h[:, :, 4] = torch.randn(B, 3, G, G, generator=g) * 0.8 + 0.4
+        h[:, :, 5:] = torch.rand(B, 3, C, G, G, generator=g)
+        heads.append(h.view(B, 3 * (5 + C), G, G).contiguous())
+    return heads
+
+
+def group_nms(losses, accuracy):
+    """G7: YOLO weighted-merge NMS (v4 / v2-style 5 anchors is the same code / v5 reinterpretation) and the
+    Retina/SSD greedy top-k NMS incl. the 'one box left' and 'nothing above threshold' cases."""
+    from model.YOLOV4 import YOLOv4
+    from model.YOLOV5 import YOLOv5
+    from model.RetinaNet import RetinaNet
+    RetinaUtils, _ = load_retina_utils()
+    arrays = {}
+    for name, seed, grids, spread in (("a", 51, (8, 4, 2), 25.0), ("b", 52, (13, 7), 60.0), ("c", 53, (6,), 5.0)):
+        heads = nms_heads(seed, 2, 4, grids, spread)
+        if name == "c":
+            heads[0][1, :, :, :] = heads[0][1]          # image 1: everything below the conf threshold
+            hv = heads[0].view(2, 3, 9, 6, 6); hv[1, :, 4] = -1.0
+        out = YOLOv4.non_max_suppression(None, [h.clone() for h in heads])
+        for i, h in enumerate(heads):
+            arrays[f"yolo_{name}_head{i}"] = h
+        for b, o in enumerate(out):
+            arrays[f"yolo_{name}_out{b}"] = o if o is not None else torch.zeros(0, 7)
+            arrays[f"yolo_{name}_none{b}"] = torch.tensor(o is None)
+    # v5: [B,3,G,G,no] memory reinterpreted as [B,3,no,G,G] (YOLOV5.py:176-182)
+    heads = nms_heads(54, 2, 4, (8, 4), 25.0)
+    v5 = [h.view(2, 3, 8, 8, 9) if h.shape[2] == 8 else h.view(2, 3, 4, 4, 9) for h in heads]
+    out = YOLOv5.non_max_suppression(None, [h.clone() for h in v5])
+    for i, h in enumerate(v5):
+        arrays[f"v5_head{i}"] = h
+    for b, o in enumerate(out):
+        arrays[f"v5_out{b}"] = o
+    # Retina / SSD greedy
+    class _M:                       # the method only reads self.iou_boxes
+        pass
+    m = _M()
+    m.iou_boxes = RetinaUtils.get_anchor_boxes(torch.Tensor([128, 128]))
+    An = m.iou_boxes.shape[0]
+    g = torch.Generator().manual_seed(55)
+    for name, shift in (("typ", -1.6), ("few", -3.2), ("none", -9.0), ("many", 0.5)):
+        loc = torch.randn(2, An, 4, generator=g) * 0.2
+        cls = torch.randn(2, An, 4, generator=g) + shift
+        if name == "few":
+            cls[:] = -9.0
+            cls[0, 100, 1] = 2.0; cls[0, 101, 2] = 1.5; cls[0, 2000, 0] = 1.0      # 3 candidates in image 0
+            cls[1, 7, 3] = 3.0; cls[1, 1500, 3] = 2.5                                 # 2 candidates in image 1
+        out = RetinaNet.non_max_suppression(m, (loc, cls))
+        arrays[f"ret_{name}_loc"] = loc; arrays[f"ret_{name}_cls"] = cls
+        for b, o in enumerate(out):
+            arrays[f"ret_{name}_out{b}"] = o
+    arrays["ret_anchors"] = m.iou_boxes
+    save("nms", **arrays)
+
+
 GROUPS = {
     "yolo_assign": group_yolo_assign,
     "yolo_loss": group_yolo_loss,
@@ -354,6 +419,7 @@ GROUPS = {
     "iou": group_iou,
     "anchors": group_anchors,
     "retina": group_retina,
+    "nms": group_nms,
 }
 
 

@@ -1,0 +1,87 @@
+"""GPU parity: batched NMS (C ABI) vs the reference's own NMS outputs (golden) and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nms as oracle_nms
+from oracle import retina as oracle_retina
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a)).cuda()
+
+
+def _check_yolo(out, g, prefix, nimg):
+    for b in range(nimg):
+        ref = g[f"{prefix}_out{b}"]
+        if f"{prefix}_none{b}" in g.files and bool(g[f"{prefix}_none{b}"]):
+            assert out[b] is None
+            continue
+        got = out[b].cpu().numpy()
+        assert got.shape == ref.shape, (prefix, b, got.shape, ref.shape)
+        # kept set / order / labels / confidences are index work: exact; merged boxes are fp32 sums
+        assert np.array_equal(got[:, 4:], ref[:, 4:]), (prefix, b)
+        assert np.allclose(got[:, :4], ref[:, :4], rtol=1e-5, atol=1e-4), np.abs(got[:, :4] - ref[:, :4]).max()
+
+
+@pytest.mark.parametrize("name,nh", [("a", 3), ("b", 2), ("c", 1)])
+def test_yolo_nms_vs_golden(golden, name, nh):
+    from objectdetectionpl_amd.LightningFunc.nms import yolo_non_max_suppression
+    g = golden("nms")
+    out = yolo_non_max_suppression([T(g[f"yolo_{name}_head{i}"]) for i in range(nh)])
+    _check_yolo(out, g, f"yolo_{name}", 2)
+
+
+def test_yolo_nms_v5_layout(golden):
+    from objectdetectionpl_amd.LightningFunc.nms import yolo_non_max_suppression
+    g = golden("nms")
+    out = yolo_non_max_suppression([T(g["v5_head0"]), T(g["v5_head1"])])
+    _check_yolo(out, g, "v5", 2)
+
+
+@pytest.mark.parametrize("name", ["typ", "few", "none", "many"])
+def test_greedy_nms_vs_golden(golden, name):
+    from objectdetectionpl_amd.LightningFunc.nms import greedy_non_max_suppression
+    g = golden("nms")
+    out = greedy_non_max_suppression((T(g[f"ret_{name}_loc"]), T(g[f"ret_{name}_cls"])), T(g["ret_anchors"]))
+    for b, o in enumerate(out):
+        ref = g[f"ret_{name}_out{b}"]
+        got = o.cpu().numpy()
+        assert got.shape == ref.shape, (name, b, got.shape, ref.shape)
+        assert np.array_equal(got[:, 6], ref[:, 6]) and np.array_equal(got[:, 4], ref[:, 4])
+        assert np.allclose(got[:, :4], ref[:, :4], rtol=1e-5, atol=1e-4)
+        assert np.allclose(got[:, 5], ref[:, 5], rtol=1e-6, atol=1e-7)
+
+
+def test_greedy_nms_single_candidate_raises_like_the_reference():
+    from objectdetectionpl_amd.LightningFunc.nms import greedy_non_max_suppression
+    an = torch.tensor([[10., 10., 8., 8.], [30., 30., 8., 8.], [50., 50., 8., 8.]]).cuda()
+    loc = torch.zeros(1, 3, 4).cuda()
+    cls = torch.full((1, 3, 2), -9.0).cuda(); cls[0, 1, 0] = 3.0
+    with pytest.raises(IndexError):
+        greedy_non_max_suppression((loc, cls), an)
+
+
+def test_yolo_nms_config2_size_vs_oracle():
+    """BASELINE config-2 candidate count (10 647 / image) with clustered valid boxes: kept set identical to the oracle."""
+    from objectdetectionpl_amd.LightningFunc.nms import yolo_non_max_suppression
+    g = torch.Generator().manual_seed(61)
+    B, C = 2, 80
+    heads = []
+    for G in (52, 26, 13):
+        h = torch.randn(B, 3, 5 + C, G, G, generator=g)
+        centres = torch.rand(B, 3, 2, 1, 1, generator=g) * 300 + 50
+        h[:, :, 0:2] = centres + torch.randn(B, 3, 2, G, G, generator=g) * 40
+        h[:, :, 2:4] = torch.rand(B, 3, 2, G, G, generator=g) * 80 + 20
+        h[:, :, 4] = torch.randn(B, 3, G, G, generator=g) * 0.8 - 0.6
+        h[:, :, 5:] = torch.rand(B, 3, C, G, G, generator=g)
+        heads.append(h.view(B, 3 * (5 + C), G, G).contiguous())
+    ref = oracle_nms.yolo_weighted_nms(heads)
+    out = yolo_non_max_suppression([h.cuda() for h in heads])
+    for r, o in zip(ref, out):
+        o = o.cpu()
+        assert o.shape == r.shape
+        assert torch.equal(o[:, 4:], r[:, 4:])
+        assert torch.allclose(o[:, :4], r[:, :4], rtol=1e-5, atol=1e-3)
