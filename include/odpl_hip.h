@@ -202,6 +202,26 @@ size_t odpl_greedy_nms_workspace_bytes(const odpl_greedy_nms_desc_t* desc);
 int odpl_greedy_nms(const odpl_greedy_nms_desc_t* desc, void* workspace, size_t workspace_bytes,
                     float* out_dets, int32_t* out_counts, void* stream);
 
+/* ---- YOLOv4 inference decode: utils/YoloV4Utils.py:18-176, model/YOLOV4.py:41-49 ------------ */
+
+typedef struct {
+    const float* head;                    /* [B, A*(5+C), H, W] */
+    int32_t H, W, A;
+    float anchor_w[ODPL_MAX_ANCHORS];     /* masked anchors / stride (python double division, rounded once) */
+    float anchor_h[ODPL_MAX_ANCHORS];
+} odpl_yolo_decode_scale_t;
+
+typedef struct {
+    int32_t nscales, B, C;
+    float scale_x_y;                      /* 1 in the reference's YoloLayer */
+    float scale_x_y_offset;               /* f32(0.5 * (scale_x_y - 1)) computed by the host in double */
+    odpl_yolo_decode_scale_t scale[ODPL_MAX_SCALES];
+} odpl_yolo_decode_desc_t;
+
+/* boxes [B, N, 1, 4] (x1,y1,x2,y2 normalised), confs [B, N, C] = sigmoid(cls)*sigmoid(det), N = sum A*H*W,
+ * scales concatenated in order (get_region_boxes). */
+int odpl_yolo_decode(const odpl_yolo_decode_desc_t* desc, float* boxes, float* confs, void* stream);
+
 /* launch-geometry knobs (process-wide; defaults are the tuned values) */
 #define ODPL_TUNE_YOLO_FILL_F4_PER_BLOCK 0
 #define ODPL_TUNE_YOLO_FILL_NT 1
@@ -221,6 +241,7 @@ int odpl_tune_set(int32_t key, int32_t value);
 #define ODPL_PROF_YOLO_NMS_IMAGE 7
 #define ODPL_PROF_GREEDY_NMS_PREP 8
 #define ODPL_PROF_GREEDY_NMS_IMAGE 9
+#define ODPL_PROF_YOLO_DECODE 10
 #define ODPL_PROF_NUM_KERNELS 16
 int odpl_profile_enable(int32_t kernel_id, int32_t on);
 /* Synchronises the recorded events, writes up to max_n durations (ms) and returns how many launches

@@ -47,6 +47,16 @@ class GreedyNmsDesc(ctypes.Structure):
                 ("nms_thresh", c_float), ("class_thresh", c_float), ("flags", c_int32)]
 
 
+class YoloDecodeScale(ctypes.Structure):
+    _fields_ = [("head", c_void_p), ("H", c_int32), ("W", c_int32), ("A", c_int32),
+                ("anchor_w", c_float * MAX_ANCHORS), ("anchor_h", c_float * MAX_ANCHORS)]
+
+
+class YoloDecodeDesc(ctypes.Structure):
+    _fields_ = [("nscales", c_int32), ("B", c_int32), ("C", c_int32), ("scale_x_y", c_float),
+                ("scale_x_y_offset", c_float), ("scale", YoloDecodeScale * MAX_SCALES)]
+
+
 _lib = None
 
 # name -> (restype, argtypes); every symbol include/odpl_hip.h declares must be listed here
@@ -68,6 +78,7 @@ SIGNATURES = {
     "odpl_yolo_nms": (c_int32, [POINTER(YoloNmsDesc), c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "odpl_greedy_nms_workspace_bytes": (c_size_t, [POINTER(GreedyNmsDesc)]),
     "odpl_greedy_nms": (c_int32, [POINTER(GreedyNmsDesc), c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "odpl_yolo_decode": (c_int32, [POINTER(YoloDecodeDesc), c_void_p, c_void_p, c_void_p]),
     "odpl_tune_set": (c_int32, [c_int32, c_int32]),
     "odpl_profile_enable": (c_int32, [c_int32, c_int32]),
     "odpl_profile_collect": (c_int32, [c_int32, POINTER(c_float), POINTER(c_float), c_int32]),
@@ -131,7 +142,7 @@ def tune_set(name, value):
 
 
 PROF_IDS = {"yolo_dense": 0, "yolo_assign": 1, "yolo_obj": 2, "yolo_finalize": 3, "retina_assign": 4, "retina_main": 5,
-            "yolo_nms_prep": 6, "yolo_nms_image": 7, "greedy_nms_prep": 8, "greedy_nms_image": 9}
+            "yolo_nms_prep": 6, "yolo_nms_image": 7, "greedy_nms_prep": 8, "greedy_nms_image": 9, "yolo_decode": 10}
 
 
 def profile_enable(name, on=True):

@@ -412,6 +412,32 @@ def group_nms(losses, accuracy):
     save("nms", **arrays)
 
 
+def group_decode(losses, accuracy):
+    """G9: yolo_forward_dynamic / YoloLayer / get_region_boxes."""
+    from LightningFunc.utils.YoloV4Utils import get_region_boxes, yolo_forward_dynamic
+    from model.YOLOV4 import YoloLayer
+    arrays = {}
+    A18 = [12, 16, 19, 36, 40, 28, 36, 75, 76, 55, 72, 146, 142, 110, 192, 243, 459, 401]
+    g = torch.Generator().manual_seed(71)
+    C, B = 5, 2
+    heads = [torch.randn(B, 3 * (5 + C), G, G, generator=g) * 1.5 for G in (13, 7, 4)]
+    layers = [YoloLayer(anchor_mask=m, num_classes=C, anchors=A18, num_anchors=9, stride=s)
+              for m, s in (([0, 1, 2], 8), ([3, 4, 5], 16), ([6, 7, 8], 32))]
+    outs = []
+    for l, h in zip(layers, heads):
+        l.eval()
+        outs.append(l(h))
+    boxes, confs = get_region_boxes(outs)
+    for i, h in enumerate(heads):
+        arrays[f"head{i}"] = h
+    arrays["boxes"] = boxes; arrays["confs"] = confs
+    # non-square, scale_x_y != 1
+    h = torch.randn(1, 2 * (5 + 3), 5, 9, generator=g)
+    b, c = yolo_forward_dynamic(h, 0.6, 3, [1.5, 2.0, 3.0, 1.0], 2, scale_x_y=1.2)
+    arrays["ns_head"] = h; arrays["ns_boxes"] = b; arrays["ns_confs"] = c
+    save("decode", **arrays)
+
+
 GROUPS = {
     "yolo_assign": group_yolo_assign,
     "yolo_loss": group_yolo_loss,
@@ -420,6 +446,7 @@ GROUPS = {
     "anchors": group_anchors,
     "retina": group_retina,
     "nms": group_nms,
+    "decode": group_decode,
 }
 
 
