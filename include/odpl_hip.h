@@ -160,6 +160,33 @@ int odpl_xywh2xyxy(const float* in, float* out, int64_t n, void* stream);
  * (w,h) table [6][6][2] (double maths rounded once); out [sum fk*fk*per, 4], clamped to <= 1. */
 int odpl_ssd_priors(const int32_t* host_fk, const int32_t* host_per_cell, const float* host_wh, float* out, int64_t n_out, void* stream);
 
+/* ---- YOLOv5 loss: accuracy.py:472-521, losses.py:37-156, accuracy.py:71-114 ------------------- */
+
+typedef struct {
+    const float* p;                       /* [B, na, G, G, 5+nc] channel-LAST (Yolo_Layers.forward, YOLOV5.py:93-97) */
+    float* grad;                          /* same shape, or NULL on every layer: forward only */
+    int32_t G;
+    float anchor_w[ODPL_MAX_ANCHORS];     /* anchors / stride in f32 (losses.py:95-96) */
+    float anchor_h[ODPL_MAX_ANCHORS];
+} odpl_yolov5_layer_t;
+
+typedef struct {
+    int32_t nl, B, na, nc, nT;
+    int32_t iou_mode;                     /* 0 IoU, 1 GIoU (what the reference calls, losses.py:118), 2 DIoU, 3 CIoU */
+    int32_t flags;                        /* ODPL_YOLOV5_STATE_CLEAN */
+    const float* target;                  /* [nT, 6] */
+    odpl_yolov5_layer_t layer[ODPL_MAX_SCALES];
+} odpl_yolov5_loss_desc_t;
+
+#define ODPL_YOLOV5_STATE_CLEAN 1
+
+size_t odpl_yolov5_loss_workspace_bytes(const odpl_yolov5_loss_desc_t* desc);
+/* out4: loss, Localization (lbox*0.05), Classification (lcls*0.58), Conf_obj (lobj*1.0).
+ * out_counts int32[ODPL_MAX_SCALES+1]: matched rows per layer, then status (bit0: a target indexes outside
+ * the grid/batch -- the reference raises IndexError; the row is dropped here). */
+int odpl_yolov5_loss(const odpl_yolov5_loss_desc_t* desc, void* workspace, size_t workspace_bytes,
+                     float* out4, int32_t* out_counts, void* stream);
+
 /* ---- batched NMS ------------------------------------------------------------------------------ */
 
 #define ODPL_NMS_STATE_CLEAN 1      /* last use of the workspace was a successful call of the same entry */
@@ -242,6 +269,7 @@ int odpl_tune_set(int32_t key, int32_t value);
 #define ODPL_PROF_GREEDY_NMS_PREP 8
 #define ODPL_PROF_GREEDY_NMS_IMAGE 9
 #define ODPL_PROF_YOLO_DECODE 10
+#define ODPL_PROF_YOLOV5_DENSE 11
 #define ODPL_PROF_NUM_KERNELS 16
 int odpl_profile_enable(int32_t kernel_id, int32_t on);
 /* Synchronises the recorded events, writes up to max_n durations (ms) and returns how many launches

@@ -128,10 +128,103 @@ class RetinaNetLoss(nn.Module):
         return {"loss": loss, "Localization": metrics[0], "Classification": metrics[1]}
 
 
+class _V5LossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, owner, target, *heads):
+        need = any(ctx.needs_input_grad[2:])
+        hs = [h.contiguous() for h in heads]
+        grads = [torch.empty_like(h) for h in hs] if need else [None] * len(hs)
+        out4, counts = owner._launch(hs, grads, target)
+        ctx.grads = grads
+        ctx.used = False
+        metrics = out4[1:]
+        ctx.mark_non_differentiable(metrics, counts)
+        return out4[0], metrics, counts
+
+    @staticmethod
+    def backward(ctx, g_loss, _gm, _gc):
+        if ctx.used:
+            raise RuntimeError("the fused YOLOv5 loss frees its gradient buffers after the first backward")
+        ctx.used = True
+        grads = ctx.grads
+        ctx.grads = None
+        g = g_loss.contiguous().float()
+        L = _lib.lib()
+        for gr in grads:
+            if gr is not None:
+                _lib.check(L.odpl_scale_inplace_if_not_one(_lib.ptr(gr), gr.numel(), _lib.ptr(g),
+                                                           _lib.current_stream(gr.device)), "odpl_scale_inplace_if_not_one")
+        return (None, None) + tuple(grads)
+
+
+class MultiScaleRegionLoss_v5(nn.Module):
+    """losses.py:70-156.  ctor keeps the reference's signature (the three criterion arguments are unused there
+    as well: BCE-with-logits + focal gamma 1.5 are hard-wired, losses.py:78-89).  `iou_mode` selects the
+    bbox_iou_v5 branch; the reference always calls GIoU (losses.py:118), CIoU/DIoU exist in accuracy.py:101-112.
+    forward(output, target) with output = list of [B, na, G, G, 5+nc] tensors -> dict(loss, Localization,
+    Classification, Conf_obj)."""
+
+    def __init__(self, anchors, anch_masks, cls_criterion, coord_criterion, conf_criterion, num_classes, img_dim=416,
+                 iou_mode="giou", **kwargs):
+        super().__init__()
+        self.nc = num_classes
+        self.nl = len(anchors)
+        self.na = len(anchors[0]) // 2
+        self.stride = torch.tensor([8., 16., 32.])                                  # losses.py:73
+        self.anchor_grid = torch.tensor(anchors).float().view(self.nl, 1, -1, 1, 1, 2)
+        self.anchors = self.anchor_grid.view(self.nl, -1, 2) / self.stride[:self.nl].view(-1, 1, 1)   # :95-96 (f32)
+        self.red = "mean"
+        self.iou_mode = iou_mode
+        self._ws = None
+        self._clean_key = None
+        self.last_counts = None
+
+    def _launch(self, heads, grads, target):
+        _lib.require_cuda(target, *heads)
+        L = _lib.lib()
+        dev = heads[0].device
+        d = _lib.YoloV5LossDesc()
+        tgt = target.float().contiguous()
+        d.nl, d.B, d.na, d.nc, d.nT = len(heads), heads[0].shape[0], self.na, self.nc, tgt.shape[0]
+        d.iou_mode = _lib.IOU_MODES[self.iou_mode]
+        d.target = tgt.data_ptr() if d.nT else None
+        for i, (h, g) in enumerate(zip(heads, grads)):
+            if h.dtype != torch.float32:
+                raise TypeError("YOLOv5 heads must be fp32 here (bf16 heads: cast first; losses accumulate in fp32)")
+            if h.dim() != 5 or h.shape[1] != self.na or h.shape[4] != 5 + self.nc or h.shape[2] != h.shape[3]:
+                raise ValueError(f"layer {i}: expected [B,{self.na},G,G,{5 + self.nc}], got {tuple(h.shape)}")
+            l = d.layer[i]
+            l.p, l.grad, l.G = h.data_ptr(), (g.data_ptr() if g is not None else None), h.shape[2]
+            for a in range(self.na):
+                l.anchor_w[a], l.anchor_h[a] = float(self.anchors[i, a, 0]), float(self.anchors[i, a, 1])
+        need = L.odpl_yolov5_loss_workspace_bytes(ctypes.byref(d))
+        if need == 0:
+            raise OdplError("odpl_yolov5_loss_workspace_bytes rejected the descriptor")
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = torch.empty(int(need * 1.25) + 4096, dtype=torch.uint8, device=dev)
+            self._clean_key = None
+        key = (dev, torch.cuda.current_stream(dev).cuda_stream, d.B, tuple(h.shape[2] for h in heads))
+        d.flags = _lib.YOLOV5_STATE_CLEAN if self._clean_key == key else 0
+        self._clean_key = None
+        out4 = torch.empty(4, dtype=torch.float32, device=dev)
+        counts = torch.empty(_lib.MAX_SCALES + 1, dtype=torch.int32, device=dev)
+        _lib.check(L.odpl_yolov5_loss(ctypes.byref(d), _lib.ptr(self._ws), self._ws.numel(), _lib.ptr(out4),
+                                      _lib.ptr(counts), _lib.current_stream(dev)), "odpl_yolov5_loss")
+        self._clean_key = key
+        self.last_counts = counts
+        return out4, counts
+
+    def forward(self, output, target, seen=None):
+        loss, m, _ = _V5LossFn.apply(self, target, *output)
+        return {"loss": loss, "Localization": m[0], "Classification": m[1], "Conf_obj": m[2]}
+
+
 def configure(args, iou_boxes, anchors, anch_masks, num_classes, img_size):
     """The RetinaNet / SSD / YOLOv5 arms of configure_loss (losses.py:23-28)."""
     cls = {"focal_loss": focal_loss, "ce_loss": nn.CrossEntropyLoss, "bce_loss": nn.BCELoss}[args.cls_criterion]
     coord = {"mse_loss": nn.MSELoss, "smooth_l1_loss": nn.SmoothL1Loss}[args.coord_criterion]
     if args.model_name == "RetinaNet":
         return RetinaNetLoss(iou_boxes, cls, coord, num_classes, img_size)
+    if args.model_name == "YOLOv5":
+        return MultiScaleRegionLoss_v5(anchors, anch_masks, cls, coord, nn.BCELoss, num_classes, img_size)
     raise NotImplementedError(f"{args.model_name}: criterion not built yet (DESIGN.md section 7)")

@@ -57,6 +57,16 @@ class YoloDecodeDesc(ctypes.Structure):
                 ("scale_x_y_offset", c_float), ("scale", YoloDecodeScale * MAX_SCALES)]
 
 
+class YoloV5Layer(ctypes.Structure):
+    _fields_ = [("p", c_void_p), ("grad", c_void_p), ("G", c_int32),
+                ("anchor_w", c_float * MAX_ANCHORS), ("anchor_h", c_float * MAX_ANCHORS)]
+
+
+class YoloV5LossDesc(ctypes.Structure):
+    _fields_ = [("nl", c_int32), ("B", c_int32), ("na", c_int32), ("nc", c_int32), ("nT", c_int32),
+                ("iou_mode", c_int32), ("flags", c_int32), ("target", c_void_p), ("layer", YoloV5Layer * MAX_SCALES)]
+
+
 _lib = None
 
 # name -> (restype, argtypes); every symbol include/odpl_hip.h declares must be listed here
@@ -79,6 +89,8 @@ SIGNATURES = {
     "odpl_greedy_nms_workspace_bytes": (c_size_t, [POINTER(GreedyNmsDesc)]),
     "odpl_greedy_nms": (c_int32, [POINTER(GreedyNmsDesc), c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "odpl_yolo_decode": (c_int32, [POINTER(YoloDecodeDesc), c_void_p, c_void_p, c_void_p]),
+    "odpl_yolov5_loss_workspace_bytes": (c_size_t, [POINTER(YoloV5LossDesc)]),
+    "odpl_yolov5_loss": (c_int32, [POINTER(YoloV5LossDesc), c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "odpl_tune_set": (c_int32, [c_int32, c_int32]),
     "odpl_profile_enable": (c_int32, [c_int32, c_int32]),
     "odpl_profile_collect": (c_int32, [c_int32, POINTER(c_float), POINTER(c_float), c_int32]),
@@ -134,6 +146,8 @@ def require_cuda(*tensors):
 
 YOLO_STATE_CLEAN = 1
 RETINA_STATE_CLEAN = 1
+YOLOV5_STATE_CLEAN = 1
+IOU_MODES = {"iou": 0, "giou": 1, "diou": 2, "ciou": 3}
 TUNE_KEYS = {"yolo_fill_f4_per_block": 0, "yolo_fill_nt": 1, "retina_fill_nt": 2}
 
 
@@ -142,7 +156,7 @@ def tune_set(name, value):
 
 
 PROF_IDS = {"yolo_dense": 0, "yolo_assign": 1, "yolo_obj": 2, "yolo_finalize": 3, "retina_assign": 4, "retina_main": 5,
-            "yolo_nms_prep": 6, "yolo_nms_image": 7, "greedy_nms_prep": 8, "greedy_nms_image": 9, "yolo_decode": 10}
+            "yolo_nms_prep": 6, "yolo_nms_image": 7, "greedy_nms_prep": 8, "greedy_nms_image": 9, "yolo_decode": 10, "yolov5_dense": 11}
 
 
 def profile_enable(name, on=True):

@@ -1,0 +1,454 @@
+// YOLOv5 loss for MI355X (gfx950): build_targets_v5 (accuracy.py:472-521) + MultiScaleRegionLoss_v5.forward
+// (losses.py:98-156) with FocalLoss (losses.py:37-64) and bbox_iou_v5 in IoU/GIoU/DIoU/CIoU mode
+// (accuracy.py:71-114), forward AND d loss/d p for a unit upstream gradient.
+//
+// Layout: p[i] is [B, na, G, G, no] (channel-LAST, what Yolo_Layers.forward hands the criterion,
+// YOLOV5.py:93-97): a cell's no = 5+nc logits are 4*no contiguous bytes.
+//
+//   assign (1 WG / layer)  ratio test < 4, 'rect4' neighbour expansion, rows in the reference's order
+//                          [base | x-1 | y-1 | x+1 | y+1] by ballot/popcount compaction; owner map
+//                          atomicMax(row) => "last row wins" for tobj (and marks each cell's leader row)
+//   rows   (1 wave / row)  coalesced 4*no-byte gather of the cell, box decode, IoU-family value AND its
+//                          gradient by forward-mode differentiation (4 tangents), focal-BCE over the classes
+//   dense  (chunks)        zero stream over the gradient tensors; every float4 that holds a cell's
+//                          objectness logit also evaluates focal-BCE(x, tobj) and its gradient; owner map reset
+//                          [HBM-write bound: the roofline kernel of config 5]
+//   cells  (1 wave / row)  leader rows add the row gradients of all rows that share their cell, ascending row
+//                          order (index_put accumulate semantics, deterministic), over the zeros
+//   finalize (1 WG)        fixed-order sums -> lbox*0.05 + lobj*1.0 + lcls*0.58
+#include "odpl_common.hpp"
+#include "odpl_yolo_dev.hpp"
+#include "odpl_profile.hpp"
+#include "../../include/odpl_hip.h"
+
+namespace {
+using namespace odpl;
+constexpr int kAT = 256;              // assign threads
+constexpr int kDT = 256;              // dense threads
+constexpr int kChunkF4 = 4096;        // float4 per dense workgroup
+
+struct Layer {
+    const float* p; float* grad;
+    int G, cells;                     // cells = B*na*G*G
+    float aw[ODPL_MAX_ANCHORS], ah[ODPL_MAX_ANCHORS];
+    int* owner;                       // [cells]  -1 clean; max row index that maps here
+    int* row_t; int* row_ag;          // [cap] target row ; (a << 4) | group
+    int* row_cell;                    // [cap] linear cell or -1 (dropped)
+    int* row_lead;                    // [cap] 1 if the row is the last row of its cell
+    float* row_iou;                   // [cap]
+    float* row_part;                  // [cap*2] (1 - iou), sum_k focal(cls)
+    float* row_grad;                  // [cap*no]
+    int* nrows;                       // [1]
+    float* dense_part;                // [dense_nblk]
+    int dense_blk0, dense_nblk;
+    unsigned long long inv_no;        // ceil(2^40 / no)
+};
+
+struct VParams {
+    Layer L[ODPL_MAX_SCALES];
+    const float* target;
+    int nl, B, na, nc, no, nT, cap, iou_mode, want_grad;
+    int* status;
+    float* out4; int* out_counts;
+};
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kAT) void v5_assign_kernel(const VParams P) {
+    const Layer& S = P.L[blockIdx.x];
+    __shared__ int s_wcnt[kAT / 64];
+    __shared__ int s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, G = S.G, na = P.na, nT = P.nT;
+    const float fG = (float)G;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    const int ncand = na * nT;
+    for (int pass = 0; pass < 5; ++pass) {
+        for (int c0 = 0; c0 < ncand; c0 += kAT) {
+            const int i = c0 + tid;
+            bool f = false; int a = 0, t = 0;
+            if (i < ncand) {
+                a = i / nT; t = i - a * nT;
+                const float* y = P.target + (size_t)t * 6;
+                const float gx = y[2] * fG, gy = y[3] * fG, gw = y[4] * fG, gh = y[5] * fG;     // accuracy.py:486
+                const float rw = gw / S.aw[a], rh = gh / S.ah[a];                               // :488
+                const float m = fmaxf(fmaxf(rw, 1.0f / rw), fmaxf(rh, 1.0f / rh));              // :489
+                f = m < 4.0f;
+                if (f && pass > 0) {                                                            // :503-504
+                    const float v = (pass & 1) ? gx : gy;           // passes 1,3: x ; 2,4: y
+                    const float fr = v - floorf(v);                 // torch.remainder(v, 1.)
+                    f = pass <= 2 ? (fr < 0.5f && v > 1.0f) : (fr > 0.5f && v < fG - 1.0f);
+                }
+            }
+            const unsigned long long mk = __ballot(f);
+            if (lane == 0) s_wcnt[wv] = __popcll(mk);
+            __syncthreads();
+            int off = s_base, tot = 0;
+            for (int w = 0; w < kAT / 64; ++w) { if (w < wv) off += s_wcnt[w]; tot += s_wcnt[w]; }
+            if (f) {
+                const int r = off + __popcll(mk & ((1ull << lane) - 1ull));
+                S.row_t[r] = t; S.row_ag[r] = (a << 4) | pass;
+            }
+            __syncthreads();
+            if (tid == 0) s_base += tot;
+            __syncthreads();
+        }
+    }
+    const int n = s_base;
+    // cells + last-row-wins owner (losses.py:123 scatter; CPU index_put: sequential, last wins)
+    int bad = 0;
+    for (int r = tid; r < n; r += kAT) {
+        const int t = S.row_t[r], ag = S.row_ag[r], a = ag >> 4, grp = ag & 15;
+        const float* y = P.target + (size_t)t * 6;
+        const float gx = y[2] * fG, gy = y[3] * fG;
+        const float ox = grp == 1 ? 0.5f : (grp == 3 ? -0.5f : 0.0f), oy = grp == 2 ? 0.5f : (grp == 4 ? -0.5f : 0.0f);
+        long long b = trunc_ll(y[0]), gi = trunc_ll(gx - ox), gj = trunc_ll(gy - oy);          // :509-513
+        int cell = -1;
+        if (wrap_idx(b, P.B) & wrap_idx(gj, G) & wrap_idx(gi, G)) cell = ((((int)b * na + a) * G) + (int)gj) * G + (int)gi;
+        else bad = 1;                                               // the reference raises IndexError here
+        S.row_cell[r] = cell;
+        if (cell >= 0) atomicMax(&S.owner[cell], r);
+    }
+    bad = __syncthreads_or(bad);
+    for (int r = tid; r < n; r += kAT) {
+        const int cell = S.row_cell[r];
+        S.row_lead[r] = (cell >= 0 && __hip_atomic_load(&S.owner[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == r) ? 1 : 0;
+    }
+    if (tid == 0) { S.nrows[0] = n; if (bad) atomicOr(&P.status[0], 1); }
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward-mode value + 4 tangents (d/d px, py, pw, ph); tie / clamp conventions follow torch autograd
+struct D4 { float v; float d[4]; };
+__device__ __forceinline__ D4 dconst(float c) { D4 r; r.v = c; r.d[0] = r.d[1] = r.d[2] = r.d[3] = 0.f; return r; }
+__device__ __forceinline__ D4 dvar(float c, int i) { D4 r = dconst(c); r.d[i] = 1.f; return r; }
+__device__ __forceinline__ D4 operator+(const D4& a, const D4& b) { D4 r; r.v = a.v + b.v; for (int i = 0; i < 4; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
+__device__ __forceinline__ D4 operator-(const D4& a, const D4& b) { D4 r; r.v = a.v - b.v; for (int i = 0; i < 4; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
+__device__ __forceinline__ D4 operator*(const D4& a, const D4& b) { D4 r; r.v = a.v * b.v; for (int i = 0; i < 4; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+__device__ __forceinline__ D4 operator/(const D4& a, const D4& b) { D4 r; r.v = a.v / b.v; for (int i = 0; i < 4; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) / b.v; return r; }
+__device__ __forceinline__ D4 operator+(const D4& a, float c) { D4 r = a; r.v = a.v + c; return r; }
+__device__ __forceinline__ D4 operator-(const D4& a, float c) { D4 r = a; r.v = a.v - c; return r; }
+__device__ __forceinline__ D4 operator/(const D4& a, float c) { D4 r; r.v = a.v / c; for (int i = 0; i < 4; ++i) r.d[i] = a.d[i] / c; return r; }
+__device__ __forceinline__ D4 rsub(float c, const D4& a) { D4 r; r.v = c - a.v; for (int i = 0; i < 4; ++i) r.d[i] = -a.d[i]; return r; }
+__device__ __forceinline__ D4 dscale(const D4& a, float s) { D4 r; r.v = a.v; for (int i = 0; i < 4; ++i) r.d[i] = a.d[i] * s; return r; }
+__device__ __forceinline__ D4 dmin(const D4& a, float c) { const float s = a.v < c ? 1.f : (a.v == c ? 0.5f : 0.f); D4 r = dscale(a, s); r.v = fminf(a.v, c); return r; }
+__device__ __forceinline__ D4 dmax(const D4& a, float c) { const float s = a.v > c ? 1.f : (a.v == c ? 0.5f : 0.f); D4 r = dscale(a, s); r.v = fmaxf(a.v, c); return r; }
+__device__ __forceinline__ D4 dclamp0(const D4& a) { D4 r = dscale(a, a.v >= 0.f ? 1.f : 0.f); r.v = fmaxf(a.v, 0.f); return r; }
+__device__ __forceinline__ D4 dsq(const D4& a) { D4 r; r.v = a.v * a.v; for (int i = 0; i < 4; ++i) r.d[i] = 2.f * a.v * a.d[i]; return r; }
+
+// accuracy.py:71-114 with x1y1x2y2=False; box1 = prediction (differentiated), box2 = target
+__device__ D4 iou_family(float px, float py, float pw, float ph, float tx, float ty, float tw, float th, int mode) {
+    const D4 X = dvar(px, 0), Y = dvar(py, 1), Wd = dvar(pw, 2), H = dvar(ph, 3);
+    const D4 b1x1 = X - Wd / 2.0f, b1x2 = X + Wd / 2.0f, b1y1 = Y - H / 2.0f, b1y2 = Y + H / 2.0f;
+    const float b2x1 = tx - tw / 2.0f, b2x2 = tx + tw / 2.0f, b2y1 = ty - th / 2.0f, b2y2 = ty + th / 2.0f;
+    const D4 inter = dclamp0(dmin(b1x2, b2x2) - dmax(b1x1, b2x1)) * dclamp0(dmin(b1y2, b2y2) - dmax(b1y1, b2y1));
+    const D4 w1 = b1x2 - b1x1, h1 = b1y2 - b1y1;
+    const float w2 = b2x2 - b2x1, h2 = b2y2 - b2y1;
+    const D4 uni = ((w1 * h1 + 1e-16f) + w2 * h2) - inter;
+    const D4 iou = inter / uni;
+    if (mode == 0) return iou;
+    const D4 cw = dmax(b1x2, b2x2) - dmin(b1x1, b2x1), ch = dmax(b1y2, b2y2) - dmin(b1y1, b2y1);
+    if (mode == 1) {
+        const D4 c_area = cw * ch + 1e-16f;
+        return iou - (c_area - uni) / c_area;
+    }
+    const D4 c2 = (dsq(cw) + dsq(ch)) + 1e-16f;
+    const D4 rho2 = dsq(rsub(b2x1 + b2x2, b1x1 + b1x2)) / 4.0f + dsq(rsub(b2y1 + b2y2, b1y1 + b1y2)) / 4.0f;
+    if (mode == 2) return iou - rho2 / c2;
+    // CIoU: v = 4/pi^2 (atan(w2/h2) - atan(w1/h1))^2 ; alpha = v / (1 - iou + v) under no_grad
+    const D4 q = w1 / h1;
+    D4 at; at.v = atanf(q.v); { const float k = 1.0f / (1.0f + q.v * q.v); for (int i = 0; i < 4; ++i) at.d[i] = k * q.d[i]; }
+    const D4 v = dscale(dsq(rsub(atanf(w2 / h2), at)), 1.0f);
+    D4 vs; vs.v = 0.40528473456935109f * v.v; for (int i = 0; i < 4; ++i) vs.d[i] = 0.40528473456935109f * v.d[i];
+    const float alpha = vs.v / (1.0f - iou.v + vs.v);
+    D4 va; va.v = vs.v * alpha; for (int i = 0; i < 4; ++i) va.d[i] = vs.d[i] * alpha;
+    return iou - (rho2 / c2 + va);
+}
+
+// FocalLoss(BCEWithLogitsLoss) element and its x-derivative (losses.py:47-57; gamma 1.5, alpha 0.25)
+__device__ __forceinline__ void focal_bce(float x, float t, float& loss, float& dx) {
+    const float bce = (1.0f - t) * x + (log1pf(expf(-fabsf(x))) + fmaxf(-x, 0.0f));
+    const float p = sigmoidf_(x);
+    const float pt = t * p + (1.0f - t) * (1.0f - p);
+    const float af = t * 0.25f + (1.0f - t) * 0.75f;
+    const float om = 1.0f - pt;
+    const float mf = powf(om, 1.5f);
+    loss = bce * (af * mf);
+    const float dpt = (2.0f * t - 1.0f) * p * (1.0f - p);
+    dx = af * ((p - t) * mf - bce * 1.5f * sqrtf(fmaxf(om, 0.0f)) * dpt);
+}
+
+__global__ __launch_bounds__(64) void v5_rows_kernel(const VParams P) {
+    const Layer& S = P.L[blockIdx.y];
+    const int r = blockIdx.x, lane = threadIdx.x, no = P.no, nc = P.nc;
+    const int n = S.nrows[0];
+    if (r >= n) return;
+    const int cell = S.row_cell[r];
+    float* rg = S.row_grad + (size_t)r * no;
+    if (cell < 0) {
+        for (int k = lane; k < no; k += 64) rg[k] = 0.f;
+        if (lane == 0) { S.row_iou[r] = 0.f; S.row_part[r * 2] = 0.f; S.row_part[r * 2 + 1] = 0.f; }
+        return;
+    }
+    const int t = S.row_t[r], ag = S.row_ag[r], a = ag >> 4, grp = ag & 15;
+    const float* ps = S.p + (size_t)cell * no;
+    const float* y = P.target + (size_t)t * 6;
+    const float fG = (float)S.G, fn = (float)n;
+    // ---- box (lane 0): losses.py:115-119, accuracy.py:512-517
+    if (lane == 0) {
+        const float gx = y[2] * fG, gy = y[3] * fG, gw = y[4] * fG, gh = y[5] * fG;
+        const float ox = grp == 1 ? 0.5f : (grp == 3 ? -0.5f : 0.0f), oy = grp == 2 ? 0.5f : (grp == 4 ? -0.5f : 0.0f);
+        const float gi = (float)trunc_ll(gx - ox), gj = (float)trunc_ll(gy - oy);
+        const float tx = gx - gi, ty = gy - gj;                     // tbox = (gxy - gij, gwh)
+        const float s0 = sigmoidf_(ps[0]), s1 = sigmoidf_(ps[1]), s2 = sigmoidf_(ps[2]), s3 = sigmoidf_(ps[3]);
+        const float px = s0 * 2.0f - 0.5f, py = s1 * 2.0f - 0.5f;
+        const float u2 = s2 * 2.0f, u3 = s3 * 2.0f;
+        const float pw = (u2 * u2) * S.aw[a], ph = (u3 * u3) * S.ah[a];
+        const D4 io = iou_family(px, py, pw, ph, tx, ty, gw, gh, P.iou_mode);
+        S.row_iou[r] = io.v;
+        S.row_part[r * 2] = 1.0f - io.v;
+        // d (0.05 * mean(1 - iou)) / d logits
+        const float sc = -0.05f / fn;
+        rg[0] = sc * io.d[0] * 2.0f * s0 * (1.0f - s0);
+        rg[1] = sc * io.d[1] * 2.0f * s1 * (1.0f - s1);
+        rg[2] = sc * io.d[2] * (2.0f * u2 * S.aw[a]) * 2.0f * s2 * (1.0f - s2);
+        rg[3] = sc * io.d[3] * (2.0f * u3 * S.ah[a]) * 2.0f * s3 * (1.0f - s3);
+        rg[4] = 0.f;
+    }
+    // ---- classes: losses.py:126-129
+    float acc = 0.f;
+    if (nc > 1) {
+        const int tc = (int)trunc_ll(y[1]);
+        const float sc = 0.58f / (fn * (float)nc);
+        for (int k = lane; k < nc; k += 64) {
+            float l, dx;
+            focal_bce(ps[5 + k], k == tc ? 1.0f : 0.0f, l, dx);
+            acc += l;
+            rg[5 + k] = dx * sc;
+        }
+    } else {
+        for (int k = lane; k < nc; k += 64) rg[5 + k] = 0.f;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) S.row_part[r * 2 + 1] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+template <bool GRAD>
+__global__ __launch_bounds__(kDT) void v5_dense_kernel(const VParams P) {
+    __shared__ float sh[kDT / 64];
+    const int tid = threadIdx.x;
+    int li = 0;
+    for (int i = 0; i < P.nl; ++i) if ((int)blockIdx.x >= P.L[i].dense_blk0) li = i;
+    const Layer& S = P.L[li];
+    const int no = P.no;
+    const size_t total = (size_t)S.cells * no, total4 = total / 4;
+    const size_t q0 = (size_t)(blockIdx.x - S.dense_blk0) * kChunkF4;
+    const size_t q1 = (q0 + kChunkF4) < total4 ? (q0 + kChunkF4) : total4;
+    const float inv_cells = 1.0f / (float)S.cells;            // mean over all cells, gain 1.0 (losses.py:135,138)
+    float acc = 0.f;
+    v4f* g4 = reinterpret_cast<v4f*>(S.grad);
+    for (size_t q = q0 + tid; q < q1; q += kDT) {
+        v4f o = {0.f, 0.f, 0.f, 0.f};
+        const unsigned e = (unsigned)(q * 4);
+        const unsigned c = (unsigned)(((unsigned long long)e * S.inv_no) >> 40);
+        const unsigned r = e - c * (unsigned)no;
+        if (r >= 1u && r <= 4u) {                             // this quad holds cell c's objectness logit
+            const int ow = S.owner[c];
+            const float tobj = ow >= 0 ? fmaxf(S.row_iou[ow], 0.0f) : 0.0f;     // losses.py:123 (gr = 1)
+            float l, dx;
+            focal_bce(S.p[(size_t)c * no + 4], tobj, l, dx);
+            acc += l;
+            o[4 - r] = dx * inv_cells;
+            S.owner[c] = -1;                                  // leave the map clean
+        }
+        if (GRAD) __builtin_nontemporal_store(o, g4 + q);
+    }
+    // tail (< 4 elements) by the last workgroup of the layer
+    if (q1 == total4 && (size_t)tid < total - total4 * 4) {
+        const size_t e = total4 * 4 + tid;
+        const unsigned c = (unsigned)(e / no), r = (unsigned)(e - (size_t)c * no);
+        float o = 0.f;
+        if (r == 4u) {
+            const int ow = S.owner[c];
+            const float tobj = ow >= 0 ? fmaxf(S.row_iou[ow], 0.0f) : 0.0f;
+            float l, dx;
+            focal_bce(S.p[e], tobj, l, dx);
+            acc += l; o = dx * inv_cells;
+            S.owner[c] = -1;
+        }
+        if (GRAD) S.grad[e] = o;
+    }
+    acc = wave_sum(acc);
+    if ((tid & 63) == 0) sh[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        float a = 0.f;
+        for (int w = 0; w < kDT / 64; ++w) a += sh[w];
+        S.dense_part[blockIdx.x - S.dense_blk0] = a;
+    }
+}
+
+__global__ __launch_bounds__(64) void v5_cells_kernel(const VParams P) {
+    // leader rows gather every row that landed in their cell (ascending row order) and write the sum over the zeros
+    const Layer& S = P.L[blockIdx.y];
+    const int r = blockIdx.x, lane = threadIdx.x, no = P.no;
+    const int n = S.nrows[0];
+    if (r >= n || !S.row_lead[r]) return;
+    const int cell = S.row_cell[r];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;             // lane handles channels lane, lane+64, +128, +192
+    for (int base = 0; base < n; base += 64) {
+        const int rr = base + lane;
+        const bool m = rr < n && S.row_cell[rr] == cell;
+        unsigned long long mk = __ballot(m);
+        while (mk) {
+            const int j = __ffsll((long long)mk) - 1; mk &= mk - 1;
+            const float* g = S.row_grad + (size_t)(base + j) * no;
+            if (lane < no) a0 += g[lane];
+            if (lane + 64 < no) a1 += g[lane + 64];
+            if (lane + 128 < no) a2 += g[lane + 128];
+            if (lane + 192 < no) a3 += g[lane + 192];
+        }
+    }
+    float* dst = S.grad + (size_t)cell * no;
+    if (lane < no && lane != 4) dst[lane] = a0;
+    if (lane + 64 < no) dst[lane + 64] = a1;
+    if (lane + 128 < no) dst[lane + 128] = a2;
+    if (lane + 192 < no) dst[lane + 192] = a3;
+}
+
+__global__ __launch_bounds__(256) void v5_finalize_kernel(const VParams P) {
+    __shared__ double sh[3 * 4];
+    __shared__ float tot[3];
+    const int tid = threadIdx.x;
+    if (tid < 3) tot[tid] = 0.f;
+    __syncthreads();
+    for (int li = 0; li < P.nl; ++li) {
+        const Layer& S = P.L[li];
+        const int n = S.nrows[0];
+        double a = 0, b = 0, c = 0;
+        for (int r = tid; r < n; r += 256) { a += (double)S.row_part[r * 2]; b += (double)S.row_part[r * 2 + 1]; }
+        for (int i = tid; i < S.dense_nblk; i += 256) c += (double)S.dense_part[i];
+        for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); b += __shfl_down(b, o, 64); c += __shfl_down(c, o, 64); }
+        if ((tid & 63) == 0) { sh[(tid >> 6) * 3] = a; sh[(tid >> 6) * 3 + 1] = b; sh[(tid >> 6) * 3 + 2] = c; }
+        __syncthreads();
+        if (tid == 0) {
+            const float sa = (float)(sh[0] + sh[3] + sh[6] + sh[9]), sb = (float)(sh[1] + sh[4] + sh[7] + sh[10]);
+            const float sc = (float)(sh[2] + sh[5] + sh[8] + sh[11]);
+            if (n > 0) {                                                     // losses.py:110: `if nb:`
+                tot[0] += sa / (float)n;                                     // :119 mean(1 - iou)
+                if (P.nc > 1) tot[1] += sb / ((float)n * (float)P.nc);       // :129
+            }
+            tot[2] += sc / (float)S.cells;                                   // :135
+            if (P.out_counts) P.out_counts[li] = n;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const float lbox = tot[0] * 0.05f, lobj = tot[2] * 1.0f, lcls = tot[1] * 0.58f;     // :137-139
+        P.out4[0] = lbox + lobj + lcls; P.out4[1] = lbox; P.out4[2] = lcls; P.out4[3] = lobj;
+        if (P.out_counts) P.out_counts[ODPL_MAX_SCALES] = P.status[0];
+        P.status[0] = 0;
+    }
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct VPlan {
+    size_t status, owner[ODPL_MAX_SCALES], row_t[ODPL_MAX_SCALES], row_ag[ODPL_MAX_SCALES], row_cell[ODPL_MAX_SCALES],
+        row_lead[ODPL_MAX_SCALES], row_iou[ODPL_MAX_SCALES], row_part[ODPL_MAX_SCALES], row_grad[ODPL_MAX_SCALES],
+        nrows[ODPL_MAX_SCALES], dense_part[ODPL_MAX_SCALES];
+    size_t owner_bytes_total, total;
+    int dense_nblk[ODPL_MAX_SCALES], cap, no;
+};
+
+bool make_vplan(const odpl_yolov5_loss_desc_t* d, VPlan* p) {
+    if (!d || d->nl < 1 || d->nl > ODPL_MAX_SCALES || d->B < 1 || d->na < 1 || d->na > ODPL_MAX_ANCHORS || d->nc < 1 || d->nT < 0) return false;
+    if (d->iou_mode < 0 || d->iou_mode > 3 || (d->nT > 0 && !d->target)) return false;
+    p->no = 5 + d->nc;
+    if (p->no > 256) return false;
+    p->cap = 5 * d->na * (d->nT > 0 ? d->nT : 1);
+    size_t off = 0;
+    p->status = off; off += 256;
+    for (int i = 0; i < d->nl; ++i) {            // owner maps first, contiguous: one memset(0xFF) when not clean
+        const odpl_yolov5_layer_t& l = d->layer[i];
+        if (!l.p || l.G < 1) return false;
+        const long long cells = (long long)d->B * d->na * l.G * l.G;
+        if (cells * p->no > 0xfffffff0LL) return false;
+        p->owner[i] = off; off += align_up((size_t)cells * 4, 256);
+    }
+    p->owner_bytes_total = off - 256;
+    for (int i = 0; i < d->nl; ++i) {
+        const size_t cap = (size_t)p->cap;
+        const long long cells = (long long)d->B * d->na * d->layer[i].G * d->layer[i].G;
+        p->dense_nblk[i] = (int)(((size_t)cells * p->no / 4 + kChunkF4 - 1) / kChunkF4); if (p->dense_nblk[i] < 1) p->dense_nblk[i] = 1;
+        p->row_t[i] = off;    off += align_up(cap * 4, 256);
+        p->row_ag[i] = off;   off += align_up(cap * 4, 256);
+        p->row_cell[i] = off; off += align_up(cap * 4, 256);
+        p->row_lead[i] = off; off += align_up(cap * 4, 256);
+        p->row_iou[i] = off;  off += align_up(cap * 4, 256);
+        p->row_part[i] = off; off += align_up(cap * 8, 256);
+        p->row_grad[i] = off; off += align_up(cap * p->no * 4, 256);
+        p->nrows[i] = off;    off += 256;
+        p->dense_part[i] = off; off += align_up((size_t)p->dense_nblk[i] * 4, 256);
+    }
+    p->total = off;
+    return true;
+}
+}  // namespace
+
+extern "C" size_t odpl_yolov5_loss_workspace_bytes(const odpl_yolov5_loss_desc_t* d) {
+    VPlan p;
+    return make_vplan(d, &p) ? p.total : 0;
+}
+
+extern "C" int odpl_yolov5_loss(const odpl_yolov5_loss_desc_t* d, void* workspace, size_t workspace_bytes,
+                                float* out4, int32_t* out_counts, void* stream_) {
+    VPlan pl;
+    if (!make_vplan(d, &pl) || !workspace || workspace_bytes < pl.total || !out4) return ODPL_EINVAL;
+    if ((uintptr_t)workspace & 15) return ODPL_EINVAL;
+    hipStream_t stream = (hipStream_t)stream_;
+    char* ws = (char*)workspace;
+    VParams P;
+    P.target = d->target; P.nl = d->nl; P.B = d->B; P.na = d->na; P.nc = d->nc; P.no = pl.no; P.nT = d->nT; P.cap = pl.cap;
+    P.iou_mode = d->iou_mode; P.status = (int*)(ws + pl.status); P.out4 = out4; P.out_counts = out_counts;
+    int blk = 0, want = 0;
+    for (int i = 0; i < d->nl; ++i) {
+        const odpl_yolov5_layer_t& l = d->layer[i];
+        Layer& S = P.L[i];
+        if (((uintptr_t)l.p | (uintptr_t)l.grad) & 15) return ODPL_EINVAL;
+        S.p = l.p; S.grad = l.grad; S.G = l.G; S.cells = d->B * d->na * l.G * l.G;
+        for (int a = 0; a < ODPL_MAX_ANCHORS; ++a) { S.aw[a] = l.anchor_w[a]; S.ah[a] = l.anchor_h[a]; }
+        S.owner = (int*)(ws + pl.owner[i]); S.row_t = (int*)(ws + pl.row_t[i]); S.row_ag = (int*)(ws + pl.row_ag[i]);
+        S.row_cell = (int*)(ws + pl.row_cell[i]); S.row_lead = (int*)(ws + pl.row_lead[i]);
+        S.row_iou = (float*)(ws + pl.row_iou[i]); S.row_part = (float*)(ws + pl.row_part[i]);
+        S.row_grad = (float*)(ws + pl.row_grad[i]); S.nrows = (int*)(ws + pl.nrows[i]);
+        S.dense_part = (float*)(ws + pl.dense_part[i]);
+        S.dense_blk0 = blk; S.dense_nblk = pl.dense_nblk[i]; blk += S.dense_nblk;
+        S.inv_no = ((1ull << 40) + (unsigned long long)pl.no - 1ull) / (unsigned long long)pl.no;
+        if (l.grad) want++;
+    }
+    if (want != 0 && want != d->nl) return ODPL_EINVAL;
+    P.want_grad = want ? 1 : 0;
+    if (!(d->flags & ODPL_YOLOV5_STATE_CLEAN)) {
+        ODPL_HIP_TRY(hipMemsetAsync(ws + pl.status, 0, 256, stream));
+        ODPL_HIP_TRY(hipMemsetAsync(ws + 256, 0xFF, pl.owner_bytes_total, stream));
+    }
+    hipLaunchKernelGGL(v5_assign_kernel, dim3(d->nl), dim3(kAT), 0, stream, P);
+    ODPL_HIP_TRY(hipGetLastError());
+    if (d->nT > 0) {
+        hipLaunchKernelGGL(v5_rows_kernel, dim3(pl.cap, d->nl), dim3(64), 0, stream, P);
+        ODPL_HIP_TRY(hipGetLastError());
+    }
+    prof_begin(ODPL_PROF_YOLOV5_DENSE, stream);
+    if (P.want_grad) hipLaunchKernelGGL(v5_dense_kernel<true>, dim3(blk), dim3(kDT), 0, stream, P);
+    else hipLaunchKernelGGL(v5_dense_kernel<false>, dim3(blk), dim3(kDT), 0, stream, P);
+    prof_end(ODPL_PROF_YOLOV5_DENSE, stream);
+    ODPL_HIP_TRY(hipGetLastError());
+    if (d->nT > 0 && P.want_grad) {
+        hipLaunchKernelGGL(v5_cells_kernel, dim3(pl.cap, d->nl), dim3(64), 0, stream, P);
+        ODPL_HIP_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(v5_finalize_kernel, dim3(1), dim3(256), 0, stream, P);
+    ODPL_HIP_TRY(hipGetLastError());
+    return 0;
+}

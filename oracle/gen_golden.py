@@ -438,6 +438,40 @@ def group_decode(losses, accuracy):
     save("decode", **arrays)
 
 
+V5_ANCHORS = [[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]]
+
+
+def group_yolov5(losses, accuracy):
+    """G6b: build_targets_v5 rows and MultiScaleRegionLoss_v5 forward + gradients (GIoU, as the reference calls it)."""
+    arrays = {}
+    C, B = 4, 2
+    args = _Args(model_name="YOLOv5", cls_criterion="bce_loss", coord_criterion="smooth_l1_loss", type="Yolov5s")
+    crit = losses.configure_loss(args, None, V5_ANCHORS, None, C, 640)
+    g = torch.Generator().manual_seed(81)
+    for case in ("plain", "dup", "empty"):
+        heads = [torch.randn(B, 3, G, G, 5 + C, generator=g).requires_grad_() for G in (16, 8, 4)]
+        n = 0 if case == "empty" else 6
+        wh = torch.rand(n, 2, generator=g) * 0.5 + 0.03
+        tgt = torch.cat([torch.randint(0, B, (n, 1), generator=g).float(), torch.randint(0, C, (n, 1), generator=g).float(),
+                         torch.rand(n, 2, generator=g) * 0.9 + 0.05, wh], 1)
+        if case == "dup":
+            tgt[3] = tgt[1]; tgt[3, 1] = (tgt[1, 1] + 1) % C; tgt[3, 4:6] = tgt[1, 4:6] * 1.1     # same cells, other box/label
+        out = crit(heads, tgt)
+        out["loss"].backward()
+        for k, v in out.items():
+            arrays[f"{case}_{k}"] = v
+        arrays[f"{case}_target"] = tgt
+        for i, h in enumerate(heads):
+            arrays[f"{case}_head{i}"] = h
+            arrays[f"{case}_grad{i}"] = h.grad if h.grad is not None else torch.zeros_like(h)
+        tcls, tbox, indices, anch = accuracy.build_targets_v5(heads, tgt, crit.anchors, 3, 3)
+        for i in range(3):
+            arrays[f"{case}_L{i}_b"], arrays[f"{case}_L{i}_a"], arrays[f"{case}_L{i}_gj"], arrays[f"{case}_L{i}_gi"] = indices[i]
+            arrays[f"{case}_L{i}_tbox"] = tbox[i]; arrays[f"{case}_L{i}_anch"] = anch[i]; arrays[f"{case}_L{i}_tcls"] = tcls[i]
+    arrays["grid_anchors"] = crit.anchors
+    save("yolov5", **arrays)
+
+
 GROUPS = {
     "yolo_assign": group_yolo_assign,
     "yolo_loss": group_yolo_loss,
@@ -447,6 +481,7 @@ GROUPS = {
     "retina": group_retina,
     "nms": group_nms,
     "decode": group_decode,
+    "yolov5": group_yolov5,
 }
 
 
