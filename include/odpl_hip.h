@@ -187,6 +187,28 @@ size_t odpl_yolov5_loss_workspace_bytes(const odpl_yolov5_loss_desc_t* desc);
 int odpl_yolov5_loss(const odpl_yolov5_loss_desc_t* desc, void* workspace, size_t workspace_bytes,
                      float* out4, int32_t* out_counts, void* stream);
 
+/* ---- SSD loss: losses.py:159-315 ---------------------------------------------------------------- */
+
+typedef struct {
+    const float* off;                     /* [B, P, 4] predicted offsets */
+    const float* cls;                     /* [B, P, C] class logits */
+    float* grad_off;                      /* or NULL together with grad_cls: forward only */
+    float* grad_cls;
+    const float* priors;                  /* [P, 4] (cx,cy,w,h) in [0,1]: SSDUtils.get_dboxes */
+    const float* target;                  /* [nT, 6], nT >= 1 */
+    int32_t B, P, C, nT;
+    int32_t cls_mode;                     /* ODPL_CLS_CE (nn.CrossEntropyLoss) or ODPL_CLS_SOFTMAX_FOCAL (focal_loss) */
+    int32_t coord_mode;                   /* ODPL_COORD_* with reduction='none' then .sum() */
+} odpl_ssd_loss_desc_t;
+
+#define ODPL_CLS_SOFTMAX_FOCAL 2
+
+size_t odpl_ssd_loss_workspace_bytes(const odpl_ssd_loss_desc_t* desc);
+/* out3: loss, Localization, Classification.  out_counts int32[2]: new_batch_size, status (bit0: class id
+ * outside the criterion's range -- the reference raises). */
+int odpl_ssd_loss(const odpl_ssd_loss_desc_t* desc, void* workspace, size_t workspace_bytes,
+                  float* out3, int32_t* out_counts, void* stream);
+
 /* ---- batched NMS ------------------------------------------------------------------------------ */
 
 #define ODPL_NMS_STATE_CLEAN 1      /* last use of the workspace was a successful call of the same entry */

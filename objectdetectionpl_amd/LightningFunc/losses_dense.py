@@ -128,6 +128,98 @@ class RetinaNetLoss(nn.Module):
         return {"loss": loss, "Localization": metrics[0], "Classification": metrics[1]}
 
 
+class _SSDLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, owner, target, off, cls):
+        need = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
+        off_c, cls_c = off.contiguous(), cls.contiguous()
+        g_off = torch.empty_like(off_c) if need else None
+        g_cls = torch.empty_like(cls_c) if need else None
+        out3, counts = owner._launch(off_c, cls_c, g_off, g_cls, target)
+        ctx.grads = (g_off, g_cls)
+        ctx.used = False
+        metrics = out3[1:]
+        ctx.mark_non_differentiable(metrics, counts)
+        return out3[0], metrics, counts
+
+    @staticmethod
+    def backward(ctx, g_loss, _gm, _gc):
+        if ctx.used:
+            raise RuntimeError("the fused SSD loss frees its gradient buffers after the first backward")
+        ctx.used = True
+        g_off, g_cls = ctx.grads
+        ctx.grads = None
+        g = g_loss.contiguous().float()
+        L = _lib.lib()
+        for gr in (g_off, g_cls):
+            if gr is not None:
+                _lib.check(L.odpl_scale_inplace_if_not_one(_lib.ptr(gr), gr.numel(), _lib.ptr(g),
+                                                           _lib.current_stream(gr.device)), "odpl_scale_inplace_if_not_one")
+        return None, None, g_off, g_cls
+
+
+class SSDLoss(nn.Module):
+    """losses.py:159-315.  ctor `(iou_boxes, cls_criterion, coord_criterion, num_classes, img_size)`;
+    forward((predicted_offsets [B,P,4], predicted_classes [B,P,C]), targets) -> {"loss","Localization","Classification"}.
+    The reference's quirk is kept: image j is matched against the first lens[j] rows of `targets`."""
+
+    def __init__(self, iou_boxes, cls_criterion, coord_criterion, num_classes, img_size):
+        super().__init__()
+        self.num_classes = num_classes
+        self.img_size = img_size
+        self.default_boxes = iou_boxes
+        name = getattr(cls_criterion, "__name__", cls_criterion)
+        if cls_criterion is focal_loss or name == "focal_loss":
+            self._cls_mode = _lib.CLS_SOFTMAX_FOCAL
+        elif cls_criterion is nn.CrossEntropyLoss or name in ("ce_loss", "CrossEntropyLoss"):
+            self._cls_mode = _lib.CLS_MODES["ce_loss"]
+        else:
+            self._cls_mode = None        # nn.BCELoss(reduction='none') fails at the first forward in the reference
+        self._coord_name = _coord_name(coord_criterion)
+        self._ws = None
+        self._priors_dev = None
+        self.last_counts = None
+
+    def _launch(self, off, cls, g_off, g_cls, target):
+        if self._cls_mode is None:
+            raise ValueError("Using a target size (torch.Size([P])) that is different to the input size "
+                             "(torch.Size([P, C])) is deprecated. Please ensure they have the same size.")
+        _lib.require_cuda(off, cls, target)
+        L = _lib.lib()
+        dev = off.device
+        if self._priors_dev is None or self._priors_dev.device != dev:
+            self._priors_dev = torch.as_tensor(self.default_boxes, dtype=torch.float32).to(dev).contiguous()
+        pri = self._priors_dev
+        B, Pn, C = cls.shape
+        if off.shape != (B, Pn, 4) or pri.shape != (Pn, 4):
+            raise ValueError(f"shape mismatch: offsets {tuple(off.shape)}, classes {tuple(cls.shape)}, priors {tuple(pri.shape)}")
+        tgt = target.float().contiguous()
+        d = _lib.SsdLossDesc()
+        d.off, d.cls = off.data_ptr(), cls.data_ptr()
+        d.grad_off = g_off.data_ptr() if g_off is not None else None
+        d.grad_cls = g_cls.data_ptr() if g_cls is not None else None
+        d.priors, d.target = pri.data_ptr(), tgt.data_ptr()
+        d.B, d.P, d.C, d.nT = B, Pn, C, tgt.shape[0]
+        d.cls_mode, d.coord_mode = self._cls_mode, _lib.COORD_MODES[self._coord_name]
+        need = L.odpl_ssd_loss_workspace_bytes(ctypes.byref(d))
+        if need == 0:
+            raise OdplError("odpl_ssd_loss_workspace_bytes rejected the descriptor (empty targets raise in the reference too)")
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = torch.empty(int(need * 1.25) + 4096, dtype=torch.uint8, device=dev)
+        out3 = torch.empty(3, dtype=torch.float32, device=dev)
+        counts = torch.empty(2, dtype=torch.int32, device=dev)
+        _lib.check(L.odpl_ssd_loss(ctypes.byref(d), _lib.ptr(self._ws), self._ws.numel(), _lib.ptr(out3), _lib.ptr(counts),
+                                   _lib.current_stream(dev)), "odpl_ssd_loss")
+        self.last_counts = counts
+        return out3, counts
+
+    def forward(self, outputs, targets):
+        predicted_offsets, predicted_classes = outputs
+        assert predicted_classes.size(0) == predicted_offsets.size(0)
+        loss, m, _ = _SSDLossFn.apply(self, targets, predicted_offsets, predicted_classes)
+        return {"loss": loss, "Localization": m[0], "Classification": m[1]}
+
+
 class _V5LossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, owner, target, *heads):
@@ -225,6 +317,8 @@ def configure(args, iou_boxes, anchors, anch_masks, num_classes, img_size):
     coord = {"mse_loss": nn.MSELoss, "smooth_l1_loss": nn.SmoothL1Loss}[args.coord_criterion]
     if args.model_name == "RetinaNet":
         return RetinaNetLoss(iou_boxes, cls, coord, num_classes, img_size)
+    if args.model_name == "SSD":
+        return SSDLoss(iou_boxes, cls, coord, num_classes, img_size)
     if args.model_name == "YOLOv5":
         return MultiScaleRegionLoss_v5(anchors, anch_masks, cls, coord, nn.BCELoss, num_classes, img_size)
     raise NotImplementedError(f"{args.model_name}: criterion not built yet (DESIGN.md section 7)")

@@ -10,6 +10,7 @@ MAX_SCALES = 4
 MAX_ANCHORS = 8
 COORD_MODES = {"mse_loss": 0, "smooth_l1_loss": 1}
 CLS_MODES = {"bce_loss": 0, "ce_loss": 1}
+CLS_SOFTMAX_FOCAL = 2
 
 
 class OdplError(RuntimeError):
@@ -67,6 +68,12 @@ class YoloV5LossDesc(ctypes.Structure):
                 ("iou_mode", c_int32), ("flags", c_int32), ("target", c_void_p), ("layer", YoloV5Layer * MAX_SCALES)]
 
 
+class SsdLossDesc(ctypes.Structure):
+    _fields_ = [("off", c_void_p), ("cls", c_void_p), ("grad_off", c_void_p), ("grad_cls", c_void_p),
+                ("priors", c_void_p), ("target", c_void_p),
+                ("B", c_int32), ("P", c_int32), ("C", c_int32), ("nT", c_int32), ("cls_mode", c_int32), ("coord_mode", c_int32)]
+
+
 _lib = None
 
 # name -> (restype, argtypes); every symbol include/odpl_hip.h declares must be listed here
@@ -91,6 +98,8 @@ SIGNATURES = {
     "odpl_yolo_decode": (c_int32, [POINTER(YoloDecodeDesc), c_void_p, c_void_p, c_void_p]),
     "odpl_yolov5_loss_workspace_bytes": (c_size_t, [POINTER(YoloV5LossDesc)]),
     "odpl_yolov5_loss": (c_int32, [POINTER(YoloV5LossDesc), c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "odpl_ssd_loss_workspace_bytes": (c_size_t, [POINTER(SsdLossDesc)]),
+    "odpl_ssd_loss": (c_int32, [POINTER(SsdLossDesc), c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "odpl_tune_set": (c_int32, [c_int32, c_int32]),
     "odpl_profile_enable": (c_int32, [c_int32, c_int32]),
     "odpl_profile_collect": (c_int32, [c_int32, POINTER(c_float), POINTER(c_float), c_int32]),

@@ -1,0 +1,335 @@
+// SSD loss for MI355X (gfx950): prior<->annotation matching (corner IoU, forced best-prior matches),
+// offset encoding with variances 0.1/0.2, cross-entropy (or the reference's softmax-focal) per prior,
+// 3:1 hard-negative mining and d loss/d (offsets, classes) -- SSDLoss, losses.py:159-315, accuracy.py:6-37.
+//
+// One workgroup (1024 threads) per image; everything about an image stays on one CU:
+//   * lens[j]: number of rows of the j-th distinct image id (losses.py:286-288).  QUIRK kept: image j is
+//     scored against the FIRST lens[j] rows of the whole target tensor (losses.py:299-300);
+//   * per-prior best annotation (first max) + per-annotation best prior by block-wide (value desc, index asc)
+//     reductions; forced matches applied in annotation order (last wins a shared prior, losses.py:215-216);
+//   * hard negatives without a sort: the k-th largest loss among the negatives by bisection on the float
+//     bits (losses are >= 0), ties taken in index order;
+//   * fixed-order reductions, no float atomics.
+// The tensors are small (8 732 x C per image): latency/occupancy bound, not HBM bound.
+#include "odpl_common.hpp"
+#include "odpl_boxes_dev.hpp"
+#include "../../include/odpl_hip.h"
+
+namespace {
+using namespace odpl;
+constexpr int kT = 1024;
+constexpr int kMaxT = 8192;          // target rows staged in LDS as flags
+
+struct SParams {
+    const float* off; const float* cls; float* g_off; float* g_cls;
+    const float* priors; const float* target;
+    int B, P, C, nT, cls_mode, coord_sl1, neg_ratio;
+    float thresh;
+    float* loss; int* ann; int* flag;         // [B*P] per prior: CE loss, annotation index, bit0 matched bit1 selected-negative
+    int* best_prior;                          // [B*nT]
+    float* part;                              // [B*2]
+    int* meta;                                // [0] new_batch_size, [1] status
+    float* out3; int* out_counts;
+};
+
+__device__ __forceinline__ Box4 clamp_points(float cx, float cy, float w, float h) {
+    Box4 b;                                   // losses.py:180-181
+    b.x1 = fmaxf(cx - w / 2.0f, 0.0f); b.y1 = fmaxf(cy - h / 2.0f, 0.0f);
+    b.x2 = fminf(cx + w / 2.0f, 1.0f); b.y2 = fminf(cy + h / 2.0f, 1.0f);
+    return b;
+}
+
+// (value desc, index asc) with NaN treated as the largest value: torch.max's first-index rule
+__device__ __forceinline__ bool better(float ov, int oi, float bv, int bi) {
+    const bool onan = ov != ov, bnan = bv != bv;
+    if (onan != bnan) return onan;
+    if (!onan && ov != bv) return ov > bv;
+    return oi < bi;
+}
+
+// block-wide integer sum (result broadcast)
+__device__ __forceinline__ int block_sum_i(int v, int* sh) {
+    v = wave_sum_i(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    int t = 0;
+    for (int w = 0; w < kT / 64; ++w) t += sh[w];
+    return t;
+}
+__device__ __forceinline__ float block_sum_f(float v, float* sh) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int w = 0; w < kT / 64; ++w) t += sh[w];
+    return t;
+}
+
+__global__ __launch_bounds__(kT) void ssd_image_kernel(const SParams P) {
+    __shared__ unsigned char s_first[kMaxT];
+    __shared__ int s_i[kT / 64];
+    __shared__ float s_f[kT / 64];
+    __shared__ float s_bv[kT / 64]; __shared__ int s_bi[kT / 64];
+    __shared__ int s_run;
+    const int j = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int np = P.P, C = P.C, nT = P.nT;
+    const size_t p0 = (size_t)j * np;
+    float* loss = P.loss + p0; int* ann = P.ann + p0; int* flag = P.flag + p0;
+    // ---- lens[j] (losses.py:286-288): distinct image ids in ascending order
+    for (int t = tid; t < nT; t += kT) {
+        const float x = P.target[(size_t)t * 6];
+        bool first = true;
+        for (int u = 0; u < t; ++u) if (P.target[(size_t)u * 6] == x) { first = false; break; }
+        s_first[t] = first;
+    }
+    __syncthreads();
+    int cD = 0, cM = 0;
+    for (int t = tid; t < nT; t += kT) {
+        const float x = P.target[(size_t)t * 6];
+        cD += s_first[t];
+        int rank = 0;
+        for (int u = 0; u < nT; ++u) rank += (s_first[u] && P.target[(size_t)u * 6] < x);
+        cM += (rank == j);
+    }
+    const int D = block_sum_i(cD, s_i);
+    const int M = block_sum_i(cM, s_i);
+    const int new_bs = D < P.B ? D : P.B;                   // losses.py:296-298
+    if (j == 0 && tid == 0) P.meta[0] = new_bs;
+    const bool want = P.g_cls != nullptr;
+    if (j >= D) {                                           // "continue": the image contributes nothing
+        if (want) {
+            for (size_t e = tid; e < (size_t)np * C; e += kT) P.g_cls[p0 * C + e] = 0.f;
+            for (size_t e = tid; e < (size_t)np * 4; e += kT) P.g_off[p0 * 4 + e] = 0.f;
+        }
+        if (tid == 0) { P.part[j * 2] = 0.f; P.part[j * 2 + 1] = 0.f; }
+        return;
+    }
+    // ---- per prior: best annotation (max over dim 0, first index), losses.py:213
+    for (int p = tid; p < np; p += kT) {
+        const float4 d = reinterpret_cast<const float4*>(P.priors)[p];
+        const Box4 pb = clamp_points(d.x, d.y, d.z, d.w);
+        float best = 0.f; int bi = 0;
+        for (int m = 0; m < M; ++m) {
+            const float* y = P.target + (size_t)m * 6;
+            const float v = iou_corner(pb, clamp_points(y[2], y[3], y[4], y[5]));
+            if (m == 0 || (best == best && (v > best || v != v))) { best = v; bi = m; }
+        }
+        ann[p] = bi;
+        flag[p] = best >= P.thresh ? 1 : 0;                 // losses.py:214
+    }
+    // ---- per annotation: best prior (max over dim 1, first index), losses.py:210
+    int* bestp = P.best_prior + (size_t)j * (nT > 0 ? nT : 1);
+    for (int m = 0; m < M; ++m) {
+        const float* y = P.target + (size_t)m * 6;
+        const Box4 ab = clamp_points(y[2], y[3], y[4], y[5]);
+        float bv = -INFINITY; int bp = 0x7fffffff; bool have = false;
+        for (int p = tid; p < np; p += kT) {
+            const float4 d = reinterpret_cast<const float4*>(P.priors)[p];
+            const float v = iou_corner(clamp_points(d.x, d.y, d.z, d.w), ab);
+            if (!have || (bv == bv && (v > bv || v != v))) { bv = v; bp = p; have = true; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {                  // (value desc, index asc); NaN treated as largest
+            const float ov = __shfl_down(bv, o, 64); const int oi = __shfl_down(bp, o, 64);
+            if (better(ov, oi, bv, bp)) { bv = ov; bp = oi; }
+        }
+        __syncthreads();
+        if (lane == 0) { s_bv[wv] = bv; s_bi[wv] = bp; }
+        __syncthreads();
+        if (tid == 0) {
+            float v = s_bv[0]; int i = s_bi[0];
+            for (int w = 1; w < kT / 64; ++w) {
+                const float ov = s_bv[w]; const int oi = s_bi[w];
+                if (better(ov, oi, v, i)) { v = ov; i = oi; }
+            }
+            bestp[m] = i;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {                                         // losses.py:215-216, sequential: last annotation wins
+        for (int m = 0; m < M; ++m) { const int p = bestp[m]; flag[p] |= 1; ann[p] = m; }
+    }
+    __syncthreads();
+    // ---- per prior classification loss (reduction='none'), N
+    int cN = 0, bad = 0;
+    for (int p = tid; p < np; p += kT) {
+        const int matched = flag[p] & 1;
+        cN += matched;
+        long long yv = matched ? trunc_ll(P.target[(size_t)ann[p] * 6 + 1]) : 0;      // losses.py:252-253
+        const float* x = P.cls + (p0 + p) * C;
+        float mx = -INFINITY;
+        for (int k = 0; k < C; ++k) mx = fmaxf(mx, x[k]);
+        float se = 0.f;
+        for (int k = 0; k < C; ++k) se += expf(x[k] - mx);
+        float l = 0.f;
+        if (P.cls_mode == ODPL_CLS_CE) {
+            if (yv < 0 || yv >= C) { bad = 1; yv = 0; }
+            l = (mx + logf(se)) - x[yv];                   // -log_softmax(x)[y]
+        } else {                                            // softmax focal, one-hot without the background column
+            if (yv < 0 || yv > C) { bad = 1; yv = 0; }
+            if (yv >= 1) {
+                const float pc = fminf(fmaxf(expf(x[yv - 1] - mx) / se, 1e-7f), 1.0f - 1e-7f);
+                const float om = 1.0f - pc;
+                l = 0.25f * (-1.0f * logf(pc)) * (om * om);
+            }
+        }
+        loss[p] = l;
+    }
+    const int N = block_sum_i(cN, s_i);
+    bad = __syncthreads_or(bad);
+    // ---- hard negatives (CE only; in focal mode background rows are exactly 0)
+    int k = 0; unsigned T = 0; int cgt = 0;
+    if (P.cls_mode == ODPL_CLS_CE) {
+        const int nneg = np - N;
+        k = P.neg_ratio * N < nneg ? P.neg_ratio * N : nneg;
+        if (k > 0) {
+            unsigned lo = 0u, hi = 0x7f800000u;             // largest T with count(neg bits >= T) >= k
+            while (lo < hi) {
+                const unsigned mid = lo + (hi - lo + 1) / 2;
+                int c = 0;
+                for (int p = tid; p < np; p += kT) c += (!(flag[p] & 1) && __float_as_uint(loss[p]) >= mid);
+                c = block_sum_i(c, s_i);
+                if (c >= k) lo = mid; else hi = mid - 1;
+            }
+            T = lo;
+            int c = 0;
+            for (int p = tid; p < np; p += kT) c += (!(flag[p] & 1) && __float_as_uint(loss[p]) > T);
+            cgt = block_sum_i(c, s_i);
+            // select: all > T, then ties == T in index order until k
+            if (tid == 0) s_run = cgt;
+            __syncthreads();
+            for (int base = 0; base < np; base += kT) {
+                const int p = base + tid;
+                const bool neg = p < np && !(flag[p] & 1);
+                const unsigned u = neg ? __float_as_uint(loss[p]) : 0u;
+                const bool tie = neg && u == T;
+                const unsigned long long mk = __ballot(tie);
+                if (lane == 0) s_i[wv] = __popcll(mk);
+                __syncthreads();
+                int offc = s_run, tot = 0;
+                for (int w = 0; w < kT / 64; ++w) { if (w < wv) offc += s_i[w]; tot += s_i[w]; }
+                if (neg && u > T) flag[p] |= 2;
+                if (tie && offc + __popcll(mk & ((1ull << lane) - 1ull)) < k) flag[p] |= 2;
+                __syncthreads();
+                if (tid == 0) s_run += tot;
+                __syncthreads();
+            }
+        }
+    }
+    // ---- sums (fixed thread-strided order) and gradients
+    const float w = 1.0f / ((float)N * (float)new_bs);
+    float a_cls = 0.f, a_reg = 0.f;
+    for (int p = tid; p < np; p += kT) {
+        const int f = flag[p];
+        const float* x = P.cls + (p0 + p) * C;
+        float* gx = want ? P.g_cls + (p0 + p) * C : nullptr;
+        float* go = want ? P.g_off + (p0 + p) * 4 : nullptr;
+        if (f & 3) {
+            a_cls += loss[p];
+            if (want) {
+                long long yv = (f & 1) ? trunc_ll(P.target[(size_t)ann[p] * 6 + 1]) : 0;
+                float mx = -INFINITY;
+                for (int q = 0; q < C; ++q) mx = fmaxf(mx, x[q]);
+                float se = 0.f;
+                for (int q = 0; q < C; ++q) se += expf(x[q] - mx);
+                if (P.cls_mode == ODPL_CLS_CE) {
+                    if (yv < 0 || yv >= C) yv = 0;
+                    for (int q = 0; q < C; ++q) gx[q] = (expf(x[q] - mx) / se - (q == yv ? 1.0f : 0.0f)) * w;
+                } else {
+                    if (yv < 0 || yv > C) yv = 0;
+                    if (yv >= 1) {
+                        const int lab = (int)yv - 1;
+                        const float pc_raw = expf(x[lab] - mx) / se;
+                        const float pc = fminf(fmaxf(pc_raw, 1e-7f), 1.0f - 1e-7f), om = 1.0f - pc, lg = logf(pc);
+                        const bool pass = pc_raw >= 1e-7f && pc_raw <= 1.0f - 1e-7f;
+                        const float g = pass ? 0.25f * (-(om * om) / pc + 2.0f * om * lg) : 0.0f;
+                        for (int q = 0; q < C; ++q) gx[q] = g * pc_raw * ((q == lab ? 1.0f : 0.0f) - expf(x[q] - mx) / se) * w;
+                    } else {
+                        for (int q = 0; q < C; ++q) gx[q] = 0.f;
+                    }
+                }
+            }
+        } else if (want) {
+            for (int q = 0; q < C; ++q) gx[q] = 0.f;
+        }
+        if (f & 1) {                                        // losses.py:220-236, 250
+            const float4 d = reinterpret_cast<const float4*>(P.priors)[p];
+            const float* y = P.target + (size_t)ann[p] * 6;
+            float t[4];
+            t[0] = (y[2] - d.x) / (d.z * 0.1f); t[1] = (y[3] - d.y) / (d.w * 0.1f);
+            t[2] = logf(y[4] / d.z) / 0.2f;     t[3] = logf(y[5] / d.w) / 0.2f;
+            for (int q = 0; q < 4; ++q) {
+                const float dd = P.off[(p0 + p) * 4 + q] - t[q];
+                a_reg += coord_elem(dd, P.coord_sl1);
+                if (want) go[q] = coord_deriv(dd, P.coord_sl1) * w;
+            }
+        } else if (want) {
+            go[0] = go[1] = go[2] = go[3] = 0.f;
+        }
+    }
+    a_cls = block_sum_f(a_cls, s_f);
+    a_reg = block_sum_f(a_reg, s_f);
+    if (tid == 0) {
+        P.part[j * 2] = a_cls / (float)N;                   // losses.py:272
+        P.part[j * 2 + 1] = a_reg / (float)N;               // losses.py:273
+        if (bad) atomicOr(&P.meta[1], 1);
+    }
+}
+
+__global__ void ssd_finalize_kernel(const SParams P) {
+    if (threadIdx.x != 0) return;
+    float cl = 0.f, lo = 0.f;
+    for (int j = 0; j < P.B; ++j) { cl += P.part[j * 2]; lo += P.part[j * 2 + 1]; }     // losses.py:306-307
+    const float nb = (float)P.meta[0];
+    lo = lo / nb; cl = cl / nb;                                                          // :312-313
+    P.out3[0] = lo + cl; P.out3[1] = lo; P.out3[2] = cl;
+    if (P.out_counts) { P.out_counts[0] = P.meta[0]; P.out_counts[1] = P.meta[1]; }
+    P.meta[1] = 0;
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+struct SPlan { size_t meta, loss, ann, flag, best, part, total; };
+bool make_splan(const odpl_ssd_loss_desc_t* d, SPlan* p) {
+    if (!d || d->B < 1 || d->P < 1 || d->C < 1 || d->nT < 1 || d->nT > kMaxT) return false;
+    if (!d->off || !d->cls || !d->priors || !d->target) return false;
+    if ((d->grad_off == nullptr) != (d->grad_cls == nullptr)) return false;
+    const size_t BP = (size_t)d->B * d->P;
+    size_t off = 0;
+    p->meta = off; off += 256;
+    p->loss = off; off += align_up(BP * 4, 256);
+    p->ann = off;  off += align_up(BP * 4, 256);
+    p->flag = off; off += align_up(BP * 4, 256);
+    p->best = off; off += align_up((size_t)d->B * d->nT * 4, 256);
+    p->part = off; off += align_up((size_t)d->B * 8, 256);
+    p->total = off;
+    return true;
+}
+}  // namespace
+
+extern "C" size_t odpl_ssd_loss_workspace_bytes(const odpl_ssd_loss_desc_t* d) {
+    SPlan p;
+    return make_splan(d, &p) ? p.total : 0;
+}
+
+extern "C" int odpl_ssd_loss(const odpl_ssd_loss_desc_t* d, void* workspace, size_t workspace_bytes,
+                             float* out3, int32_t* out_counts, void* stream_) {
+    SPlan pl;
+    if (!make_splan(d, &pl) || !workspace || workspace_bytes < pl.total || !out3) return ODPL_EINVAL;
+    if (((uintptr_t)workspace | (uintptr_t)d->priors) & 15) return ODPL_EINVAL;
+    hipStream_t stream = (hipStream_t)stream_;
+    char* ws = (char*)workspace;
+    SParams P;
+    P.off = d->off; P.cls = d->cls; P.g_off = d->grad_off; P.g_cls = d->grad_cls; P.priors = d->priors; P.target = d->target;
+    P.B = d->B; P.P = d->P; P.C = d->C; P.nT = d->nT; P.cls_mode = d->cls_mode; P.coord_sl1 = d->coord_mode == ODPL_COORD_SMOOTH_L1;
+    P.neg_ratio = 3; P.thresh = 0.5f;
+    P.loss = (float*)(ws + pl.loss); P.ann = (int*)(ws + pl.ann); P.flag = (int*)(ws + pl.flag);
+    P.best_prior = (int*)(ws + pl.best); P.part = (float*)(ws + pl.part); P.meta = (int*)(ws + pl.meta);
+    P.out3 = out3; P.out_counts = out_counts;
+    ODPL_HIP_TRY(hipMemsetAsync(P.meta, 0, 256, stream));
+    hipLaunchKernelGGL(ssd_image_kernel, dim3(d->B), dim3(kT), 0, stream, P);
+    ODPL_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(ssd_finalize_kernel, dim3(1), dim3(64), 0, stream, P);
+    ODPL_HIP_TRY(hipGetLastError());
+    return 0;
+}

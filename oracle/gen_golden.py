@@ -472,6 +472,39 @@ def group_yolov5(losses, accuracy):
     save("yolov5", **arrays)
 
 
+def group_ssd(losses, accuracy):
+    """G6c: SSDLoss with ce_loss and focal_loss (+ both coord criteria) on the real 8 732-prior table."""
+    _, SSDUtils = load_retina_utils()
+    priors = SSDUtils.get_dboxes()
+    arrays = {"priors": priors}
+    C, B = 6, 3
+    g = torch.Generator().manual_seed(95)
+    off = (torch.randn(B, 8732, 4, generator=g) * 0.5)
+    cls = torch.randn(B, 8732, C, generator=g)
+    n = 7
+    wh = torch.rand(n, 2, generator=g) * 0.4 + 0.1
+    tgt = torch.cat([torch.tensor([0., 0, 0, 1, 1, 2, 2])[:, None], torch.randint(1, C, (n, 1), generator=g).float(),
+                     torch.rand(n, 2, generator=g) * 0.6 + 0.2, wh], 1)
+    arrays["off"] = off; arrays["cls"] = cls; arrays["target"] = tgt
+    tgt2 = tgt.clone(); tgt2[:, 0] = torch.tensor([0., 0, 0, 0, 2, 2, 2])        # only 2 distinct image ids for B = 3
+    arrays["target2"] = tgt2
+    for cname, ccls in (("ce_loss", nn.CrossEntropyLoss), ("focal_loss", losses.focal_loss)):
+        for kname, kcls in (("smooth_l1_loss", nn.SmoothL1Loss), ("mse_loss", nn.MSELoss)):
+            for tname, tt in (("t1", tgt), ("t2", tgt2)):
+                crit = losses.SSDLoss(priors, ccls, kcls, C, 300)
+                o = off.clone().requires_grad_(); c = cls.clone().requires_grad_()
+                out = crit((o, c), tt)
+                out["loss"].backward()
+                tag = f"{cname}_{kname}_{tname}"
+                for k, v in out.items():
+                    arrays[f"{tag}_{k}"] = v
+                arrays[f"{tag}_grad_off"] = o.grad; arrays[f"{tag}_grad_cls"] = c.grad
+    crit = losses.SSDLoss(priors, nn.CrossEntropyLoss, nn.SmoothL1Loss, C, 300)
+    bwa, mb = crit.match(priors, tgt[:3, 2:], 0.5)
+    arrays["match_ann"] = bwa; arrays["match_bin"] = mb
+    save("ssd", **arrays)
+
+
 GROUPS = {
     "yolo_assign": group_yolo_assign,
     "yolo_loss": group_yolo_loss,
@@ -482,6 +515,7 @@ GROUPS = {
     "nms": group_nms,
     "decode": group_decode,
     "yolov5": group_yolov5,
+    "ssd": group_ssd,
 }
 
 
