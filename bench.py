@@ -19,6 +19,27 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
+# MIOpen ships no gfx950 find-db / kernel-db in this image, so the exhaustive solver search over the ~300 conv
+# problems of YOLOv4 costs ~220 s on a fresh box.  The search RESULTS (text find-db + compiled-kernel cache,
+# produced by tools/build_miopen_db.sh) live under miopen_db/; each rank works on a private copy so that eight
+# processes never contend for one sqlite file.  A missing or stale db only costs start-up time.
+def _stage_miopen_db():
+    import shutil
+    import tempfile
+    src = os.path.join(REPO, "miopen_db")
+    dst = os.path.join(tempfile.gettempdir(), f"odpl_miopen_db_r{os.environ.get('LOCAL_RANK', '0')}_{os.getpid()}")
+    try:
+        if os.path.isdir(src):
+            shutil.copytree(src, dst, dirs_exist_ok=True)
+        os.makedirs(os.path.join(dst, "cache"), exist_ok=True)
+        os.environ.setdefault("MIOPEN_USER_DB_PATH", dst)
+        os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", os.path.join(dst, "cache"))
+    except OSError:
+        pass
+
+
+_stage_miopen_db()
+
 import torch
 import torch.distributed as dist
 
@@ -99,8 +120,10 @@ def main():
     ap.add_argument("--cpu-sample-steps", type=int, default=4)
     ap.add_argument("--bucket-mb", type=int, default=48)
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="libodpl_hip tunable, e.g. yolo_fill_nt=1")
-    ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark=True (MIOpen find)")
-    ap.add_argument("--channels-last", action="store_true", help="run the network in NHWC memory format")
+    ap.add_argument("--no-miopen-find", dest="miopen_find", action="store_false",
+                    help="torch.backends.cudnn.benchmark=False (MIOpen immediate mode instead of the find-db solvers)")
+    ap.add_argument("--no-fused-adam", dest="fused_adam", action="store_false", help="foreach Adam instead of the fused one")
+    ap.add_argument("--no-channels-last", dest="channels_last", action="store_false", help="NCHW memory format for the network")
     a = ap.parse_args()
 
     t_start = time.perf_counter()
@@ -132,7 +155,7 @@ def main():
         model = model.to(memory_format=torch.channels_last)
     crit = model.criterion
     net = wrap_data_parallel(model, dev, bucket_mb=a.bucket_mb) if world > 1 else model
-    opt = torch.optim.Adam(model.parameters(), lr=Args.lr, weight_decay=Args.weight_decay)
+    opt = torch.optim.Adam(model.parameters(), lr=Args.lr, weight_decay=Args.weight_decay, fused=bool(a.fused_adam))
     x, y = synthetic_batch(1 + rank, a.batch, a.classes, a.img, dev)
     if a.channels_last:
         x = x.contiguous(memory_format=torch.channels_last)
