@@ -119,6 +119,7 @@ def main():
     ap.add_argument("--cpu-sample-batch", type=int, default=8)
     ap.add_argument("--cpu-sample-steps", type=int, default=4)
     ap.add_argument("--bucket-mb", type=int, default=48)
+    ap.add_argument("--stamp", action="store_true", help="diagnostic: in-kernel 100 MHz stamps of yolo_dense_kernel (first start -> last end)")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="libodpl_hip tunable, e.g. yolo_fill_nt=1")
     ap.add_argument("--no-miopen-find", dest="miopen_find", action="store_false",
                     help="torch.backends.cudnn.benchmark=False (MIOpen immediate mode instead of the find-db solvers)")
@@ -183,9 +184,19 @@ def main():
         log(f"warmup step {i + 1}/{a.warmup} done")     # the first step includes MIOpen solver selection / kernel builds
     fence()
     _lib.profile_enable("yolo_dense", True)
+    stamps = []
+    if a.stamp:
+        sbuf = torch.zeros(2 * 8192, dtype=torch.int64, device=dev)
+        _lib.check(_lib.lib().odpl_debug_set_stamp_buffer(_lib.ptr(sbuf)), "odpl_debug_set_stamp_buffer")
     t0 = time.perf_counter()
     for _ in range(a.steps):
+        if a.stamp:
+            sbuf.zero_()
         d = step()
+        if a.stamp:
+            v = sbuf.view(-1, 2)
+            v = v[v[:, 0] != 0]
+            stamps.append(float(v[:, 1].max() - v[:, 0].min()) / 100.0)      # us: first workgroup start -> last end
     fence()
     dt = time.perf_counter() - t0
     _lib.profile_enable("yolo_dense", False)
@@ -229,6 +240,7 @@ def main():
                          "avg_kernel_us": round(avg_ms * 1e3, 2),
                          "avg_event_pair_us_uncorrected": round(1e3 * sum(dense_raw_ms) / max(len(dense_raw_ms), 1), 2),
                          "launches": len(dense_ms),
+                         **({"in_kernel_stamp_us": round(sorted(stamps)[len(stamps) // 2], 2)} if stamps else {}),
                          "algorithmic_bytes": alg_bytes, "survey_8d_bytes": 2 * 4 * cells * CH},
         }
         if world == 1 and not a.no_cpu_baseline:

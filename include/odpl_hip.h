@@ -277,6 +277,10 @@ int odpl_yolo_decode(const odpl_yolo_decode_desc_t* desc, float* boxes, float* c
 #define ODPL_TUNE_RETINA_FILL_NT 2
 int odpl_tune_set(int32_t key, int32_t value);
 
+/* diagnostic: when non-NULL, every workgroup w of yolo_dense_kernel stores its start / end reading of the
+ * constant 100 MHz counter into dev_u64[2w], dev_u64[2w+1] (buffer >= 2 * grid entries); NULL disables it. */
+int odpl_debug_set_stamp_buffer(void* dev_u64);
+
 /* ---- in-library kernel timing (bench.py roofline leg) ------------------------------------------
  * HIP events recorded on the launch stream immediately around the named kernel of every later call.
  * No counterpart in the reference (it has no benchmark); host_ms is a HOST buffer.               */

@@ -100,6 +100,7 @@ SIGNATURES = {
     "odpl_yolov5_loss": (c_int32, [POINTER(YoloV5LossDesc), c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "odpl_ssd_loss_workspace_bytes": (c_size_t, [POINTER(SsdLossDesc)]),
     "odpl_ssd_loss": (c_int32, [POINTER(SsdLossDesc), c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "odpl_debug_set_stamp_buffer": (c_int32, [c_void_p]),
     "odpl_tune_set": (c_int32, [c_int32, c_int32]),
     "odpl_profile_enable": (c_int32, [c_int32, c_int32]),
     "odpl_profile_collect": (c_int32, [c_int32, POINTER(c_float), POINTER(c_float), c_int32]),

@@ -32,6 +32,7 @@ constexpr int kObjThreads = 128;
 
 // tunables (odpl_tune_set): defaults chosen on MI355X, see DESIGN.md "Kernels"
 int g_fill_f4_per_block = 2048;         // float4 stores per fill block (x16 B)
+unsigned long long* g_stamp = nullptr;
 int g_fill_nt = 1;                      // 1: non-temporal stores for the zero fill (in-step: 11.4 vs 12.1 us)
 
 
@@ -62,6 +63,7 @@ struct Params {
     float* out7;
     float* out_scales;
     int* out_counts;
+    unsigned long long* stamp;   // diagnostic only (odpl_debug_set_stamp_buffer): [2*wg] start, [2*wg+1] end, 100 MHz ticks
 };
 
 __global__ __launch_bounds__(kAssignThreads) void yolo_assign_kernel(const Params P) {
@@ -180,9 +182,18 @@ __device__ __forceinline__ void conf_cell(float z, int st, float w_obj, float w_
     }                                               // st == 0: ignored (anchor IoU > thres)
 }
 
+// diagnostic stamps: first-start / last-end of the grid on the constant 100 MHz counter (never read by the kernel)
+__device__ __forceinline__ void stamp_begin(const Params& P) {
+    if (P.stamp && threadIdx.x == 0) P.stamp[2 * blockIdx.x] = (unsigned long long)wall_clock64();
+}
+__device__ __forceinline__ void stamp_end(const Params& P) {
+    if (P.stamp) { __syncthreads(); if (threadIdx.x == 0) { __builtin_amdgcn_s_waitcnt(0); P.stamp[2 * blockIdx.x + 1] = (unsigned long long)wall_clock64(); } }
+}
+
 __global__ __launch_bounds__(kDenseThreads) void yolo_dense_kernel(const Params P) {
     __shared__ float sh[2 * (kDenseThreads / 64)];
     const int bid = blockIdx.x, tid = threadIdx.x;
+    stamp_begin(P);
     int si = 0;
     bool is_conf = false;
     for (int i = 0; i < P.nscales; ++i) {
@@ -240,6 +251,7 @@ __global__ __launch_bounds__(kDenseThreads) void yolo_dense_kernel(const Params 
             cur = seg_end + (next_conf < r1 ? 1 : 0);
         }
     }
+    stamp_end(P);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -465,6 +477,7 @@ extern "C" int odpl_yolo_region_loss(const odpl_yolo_loss_desc_t* d, void* works
     P.ignore_thres = d->ignore_thres; P.obj_scale = d->obj_scale; P.noobj_scale = d->noobj_scale;
     P.inv_S = d->average ? 1.0f / (float)d->nscales : 1.0f;
     P.fill_nt = g_fill_nt;
+    P.stamp = g_stamp;
     P.out7 = out7; P.out_scales = out_scales; P.out_counts = out_counts;
     int nblk = 0;
     bool any_grad = false;
@@ -511,6 +524,8 @@ extern "C" int odpl_yolo_region_loss(const odpl_yolo_loss_desc_t* d, void* works
 }
 
 namespace odpl { extern int g_retina_fill_nt; }
+
+extern "C" int odpl_debug_set_stamp_buffer(void* dev_u64x2) { g_stamp = (unsigned long long*)dev_u64x2; return 0; }
 
 extern "C" int odpl_tune_set(int32_t key, int32_t value) {
     switch (key) {
