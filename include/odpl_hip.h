@@ -271,6 +271,22 @@ typedef struct {
  * scales concatenated in order (get_region_boxes). */
 int odpl_yolo_decode(const odpl_yolo_decode_desc_t* desc, float* boxes, float* confs, void* stream);
 
+/* ---- evaluation statistics: accuracy.py:116-154, 207-287 ---------------------------------------- */
+
+/* get_batch_statistics: dets [B, Kmax, 7] with counts[b] valid rows (<= 0: image skipped, the reference's None),
+ * targets [nT, 6] whose columns 2:6 are compared as corners (accuracy.py:132-148) -> tp [B, Kmax] (1.0 / 0.0).
+ * status int32[1]: bit0 = more than 1024 annotations on one image (truncated). */
+int odpl_batch_statistics(const float* dets, const int32_t* counts, const float* targets, int32_t B, int32_t Kmax,
+                          int32_t nT, float iou_threshold, float* tp, int32_t* status, void* stream);
+
+size_t odpl_ap_per_class_workspace_bytes(int32_t N, int32_t M);
+/* ap_per_class + compute_ap: tp f64[N], conf f32[N], pred_cls f32[N], target_cls f32[M] (all device) ->
+ * p, r, ap, f1 f64[<= M] and classes int32[<= M] for the *out_num_classes unique target classes (ascending). */
+int odpl_ap_per_class(const double* tp, const float* conf, const float* pred_cls, const float* target_cls,
+                      int32_t N, int32_t M, void* workspace, size_t workspace_bytes,
+                      double* out_p, double* out_r, double* out_ap, double* out_f1, int32_t* out_classes,
+                      int32_t* out_num_classes, void* stream);
+
 /* launch-geometry knobs (process-wide; defaults are the tuned values) */
 #define ODPL_TUNE_YOLO_FILL_F4_PER_BLOCK 0
 #define ODPL_TUNE_YOLO_FILL_NT 1

@@ -102,3 +102,64 @@ def xywh2xyxy(x):
     out = torch.empty_like(xi)
     _lib.check(_lib.lib().odpl_xywh2xyxy(_lib.ptr(xi), _lib.ptr(out), xi.shape[0], _lib.current_stream(xi.device)), "odpl_xywh2xyxy")
     return out.view(x.shape)
+
+
+def get_batch_statistics(outputs, targets, iou_threshold):
+    """accuracy.py:116-154.  outputs: List[Optional[Tensor[K,7]]] (NMS output), targets [nT,6] with columns 2:6
+    already in pixels.  Returns the reference's list of [true_positives (np.float64), scores (np), labels (np)]
+    for the images whose output is not None."""
+    import numpy as np
+    live = [(i, o) for i, o in enumerate(outputs) if o is not None]
+    if not live:
+        return []
+    _lib.require_cuda(targets, *[o for _, o in live])
+    dev = targets.device
+    B = len(outputs)
+    Kmax = max(1, max(o.shape[0] for _, o in live))
+    dets = torch.zeros(B, Kmax, 7, dtype=torch.float32, device=dev)
+    counts = torch.full((B,), -1, dtype=torch.int32)
+    for i, o in live:
+        dets[i, :o.shape[0]] = o
+        counts[i] = o.shape[0]
+    counts = counts.to(dev)
+    tg = targets.float().contiguous()
+    tp = torch.empty(B, Kmax, dtype=torch.float32, device=dev)
+    status = torch.empty(1, dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib().odpl_batch_statistics(_lib.ptr(dets), _lib.ptr(counts), _lib.ptr(tg) if tg.shape[0] else None, B, Kmax,
+                                                tg.shape[0], float(iou_threshold), _lib.ptr(tp), _lib.ptr(status),
+                                                _lib.current_stream(dev)), "odpl_batch_statistics")
+    tp_h = tp.cpu().numpy().astype(np.float64)
+    return [[tp_h[i, :o.shape[0]], o[:, 4].cpu().data.numpy(), o[:, -1].cpu().data.numpy()] for i, o in live]
+
+
+def ap_per_class(tp, conf, pred_cls, target_cls, device="cuda"):
+    """accuracy.py:207-260 (+ compute_ap 262-287): numpy in, numpy out (p, r, ap, f1, unique_classes int32), computed
+    on the device in double precision."""
+    import ctypes as _ct
+
+    import numpy as np
+    dev = torch.device(device)
+    N, M = len(tp), len(target_cls)
+    if M == 0:
+        e = np.array([])
+        return e, e, e, e, np.array([], dtype="int32")
+    if N == 0:
+        uc = np.unique(np.asarray(target_cls))
+        z = np.zeros(len(uc))
+        return z, z.copy(), z.copy(), z.copy(), uc.astype("int32")
+    L = _lib.lib()
+    t_tp = torch.as_tensor(np.asarray(tp, dtype=np.float64)).to(dev)
+    t_cf = torch.as_tensor(np.asarray(conf, dtype=np.float32)).to(dev)
+    t_pc = torch.as_tensor(np.asarray(pred_cls, dtype=np.float32)).to(dev)
+    t_tc = torch.as_tensor(np.asarray(target_cls, dtype=np.float32)).to(dev)
+    need = L.odpl_ap_per_class_workspace_bytes(N, M)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    outs = [torch.zeros(M, dtype=torch.float64, device=dev) for _ in range(4)]
+    ocls = torch.zeros(M, dtype=torch.int32, device=dev)
+    ncls = torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.check(L.odpl_ap_per_class(_lib.ptr(t_tp), _lib.ptr(t_cf), _lib.ptr(t_pc), _lib.ptr(t_tc), N, M, _lib.ptr(ws), need,
+                                   *[_lib.ptr(o) for o in outs], _lib.ptr(ocls), _lib.ptr(ncls), _lib.current_stream(dev)),
+               "odpl_ap_per_class")
+    k = int(ncls.item())
+    p, r, ap, f1 = (o[:k].cpu().numpy() for o in outs)
+    return p, r, ap, f1, ocls[:k].cpu().numpy().astype("int32")

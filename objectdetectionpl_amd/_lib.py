@@ -101,6 +101,9 @@ SIGNATURES = {
     "odpl_ssd_loss_workspace_bytes": (c_size_t, [POINTER(SsdLossDesc)]),
     "odpl_ssd_loss": (c_int32, [POINTER(SsdLossDesc), c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "odpl_debug_set_stamp_buffer": (c_int32, [c_void_p]),
+    "odpl_batch_statistics": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p]),
+    "odpl_ap_per_class_workspace_bytes": (c_size_t, [c_int32, c_int32]),
+    "odpl_ap_per_class": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_size_t] + [c_void_p] * 6 + [c_void_p]),
     "odpl_tune_set": (c_int32, [c_int32, c_int32]),
     "odpl_profile_enable": (c_int32, [c_int32, c_int32]),
     "odpl_profile_collect": (c_int32, [c_int32, POINTER(c_float), POINTER(c_float), c_int32]),

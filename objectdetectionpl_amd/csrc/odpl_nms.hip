@@ -22,6 +22,7 @@
 #include "odpl_common.hpp"
 #include "odpl_boxes_dev.hpp"
 #include "odpl_profile.hpp"
+#include "odpl_sort_dev.hpp"
 #include "../../include/odpl_hip.h"
 
 namespace {
@@ -72,27 +73,6 @@ __global__ __launch_bounds__(kPrepT) void yolo_nms_prep_kernel(const YParams P) 
     }
     const unsigned long long m = __ballot(valid);
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(&P.nvalid[b], __popcll(m));
-}
-
-// (key desc, idx asc): a strict total order, so the unstable network gives a unique result
-__device__ __forceinline__ bool before(float ka, unsigned ia, float kb, unsigned ib) {
-    return ka > kb || (ka == kb && ia < ib);
-}
-
-__device__ void bitonic_sort_global(float* key, unsigned* idx, int npad) {
-    for (int k = 2; k <= npad; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = threadIdx.x; t < npad / 2; t += blockDim.x) {
-                const int i = ((t / j) * 2 * j) + (t % j), l = i + j;
-                const bool up = ((i & k) == 0);
-                const float ki = key[i], kl = key[l];
-                const unsigned ii = idx[i], il = idx[l];
-                const bool sw = up ? before(kl, il, ki, ii) : before(ki, ii, kl, il);
-                if (sw) { key[i] = kl; key[l] = ki; idx[i] = il; idx[l] = ii; }
-            }
-            __syncthreads();
-        }
-    }
 }
 
 __global__ __launch_bounds__(kImgT) void yolo_nms_image_kernel(const YParams P) {

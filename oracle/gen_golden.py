@@ -505,6 +505,52 @@ def group_ssd(losses, accuracy):
     save("ssd", **arrays)
 
 
+def group_metrics(losses, accuracy):
+    """G8: get_batch_statistics, ap_per_class, compute_ap."""
+    arrays = {}
+    g = torch.Generator().manual_seed(97)
+    B = 3
+    outs, n_out = [], [40, 0, 25]
+    tg = []
+    for b in range(B):
+        nt = [6, 3, 4][b]
+        xy = torch.rand(nt, 2, generator=g) * 300
+        wh = torch.rand(nt, 2, generator=g) * 80 + 20
+        lab = torch.randint(0, 4, (nt, 1), generator=g).float()
+        tg.append(torch.cat([torch.full((nt, 1), float(b)), lab, xy, xy + wh], 1))     # used as corners (quirk 6)
+        if n_out[b] == 0:
+            outs.append(None)
+            continue
+        k = n_out[b]
+        src = tg[-1][torch.randint(0, nt, (k,), generator=g)]
+        box = src[:, 2:6] + torch.randn(k, 4, generator=g) * 12
+        conf = torch.rand(k, 1, generator=g)
+        lbl = torch.where(torch.rand(k, 1, generator=g) < 0.7, src[:, 1:2], torch.randint(0, 5, (k, 1), generator=g).float())
+        outs.append(torch.cat([box, conf, torch.rand(k, 1, generator=g), lbl], 1))
+    targets = torch.cat(tg, 0)
+    stats = accuracy.get_batch_statistics(outs, targets, 0.5)
+    arrays["targets"] = targets
+    for b, o in enumerate(outs):
+        arrays[f"out{b}"] = o if o is not None else torch.zeros(0, 7)
+    for i, (tp, sc, lb) in enumerate(stats):
+        arrays[f"stat{i}_tp"] = tp; arrays[f"stat{i}_score"] = sc; arrays[f"stat{i}_label"] = lb
+    arrays["nstats"] = np.int64(len(stats))
+    tp = np.concatenate([s[0] for s in stats]); conf = np.concatenate([s[1] for s in stats]); pc = np.concatenate([s[2] for s in stats])
+    tcls = targets[:, 1].numpy()
+    p, r, ap, f1, uc = accuracy.ap_per_class(tp, conf, pc, tcls)
+    arrays.update(ap_tp=tp, ap_conf=conf, ap_pred_cls=pc, ap_target_cls=tcls, ap_p=p, ap_r=r, ap_ap=ap, ap_f1=f1, ap_classes=uc)
+    # a larger random case
+    rng = np.random.RandomState(5)
+    n = 5000
+    conf2 = rng.rand(n).astype(np.float32); pc2 = rng.randint(0, 12, n).astype(np.float32)
+    tp2 = (rng.rand(n) < conf2 * 0.8).astype(np.float64); tc2 = rng.randint(0, 10, 900).astype(np.float32)
+    p, r, ap, f1, uc = accuracy.ap_per_class(tp2, conf2, pc2, tc2)
+    arrays.update(big_tp=tp2, big_conf=conf2, big_pred_cls=pc2, big_target_cls=tc2, big_p=p, big_r=r, big_ap=ap, big_f1=f1, big_classes=uc)
+    rec = np.array([0.1, 0.1, 0.3, 0.5, 0.5, 0.9]); prec = np.array([1.0, 0.5, 0.66, 0.75, 0.6, 0.5])
+    arrays["cap_recall"] = rec; arrays["cap_precision"] = prec; arrays["cap_ap"] = accuracy.compute_ap(rec, prec)
+    save("metrics", **arrays)
+
+
 GROUPS = {
     "yolo_assign": group_yolo_assign,
     "yolo_loss": group_yolo_loss,
@@ -516,6 +562,7 @@ GROUPS = {
     "decode": group_decode,
     "yolov5": group_yolov5,
     "ssd": group_ssd,
+    "metrics": group_metrics,
 }
 
 
