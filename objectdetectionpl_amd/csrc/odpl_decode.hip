@@ -34,9 +34,18 @@ __global__ __launch_bounds__(kThreads) void yolo_decode_kernel(const DParams P) 
     const int lb = blockIdx.x - P.blk0[s], a = lb / tiles, sp0 = (lb - a * tiles) * kCells;
     const int nc = (HW - sp0) < kCells ? (HW - sp0) : kCells;
     const float* src = P.head[s] + ((size_t)(b * P.A[s] + a) * CH) * HW + sp0;
-    for (int e = tid; e < CH * kCells; e += kThreads) {  // channel rows: 64 consecutive floats per row
-        const int c = e >> 6, i = e & 63;
-        if (i < nc) s_t[c * ld + i] = src[(size_t)c * HW + i];
+    for (int e = tid; e < CH * kCells; e += 4 * kThreads) {   // channel rows: 64 consecutive floats per row, 4 loads in flight
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int ee = e + u * kThreads, c = ee >> 6, i = ee & 63;
+            v[u] = (c < CH && i < nc) ? src[(size_t)c * HW + i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int ee = e + u * kThreads, c = ee >> 6, i = ee & 63;
+            if (c < CH && i < nc) s_t[c * ld + i] = v[u];
+        }
     }
     __syncthreads();
     const size_t n0 = (size_t)b * P.Ntot + P.first[s] + (size_t)a * HW + sp0;     // first candidate of the tile

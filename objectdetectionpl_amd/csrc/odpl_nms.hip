@@ -55,7 +55,16 @@ __global__ __launch_bounds__(kPrepT) void yolo_nms_prep_kernel(const YParams P) 
         const float x = base[0], y = base[(size_t)G2], w = base[(size_t)2 * G2], h = base[(size_t)3 * G2];
         const float cf = base[(size_t)4 * G2];
         float best = base[(size_t)5 * G2]; int bi = 0;                       // max(1): first index on ties
-        for (int k = 1; k < P.no - 5; ++k) {
+        const int nc = P.no - 5;
+        int k = 1;
+        for (; k + 8 <= nc; k += 8) {                                        // 8 independent loads in flight per lane
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = base[(size_t)(5 + k + u) * G2];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (best == best && (v[u] > best || v[u] != v[u])) { best = v[u]; bi = k + u; }
+        }
+        for (; k < nc; ++k) {
             const float v = base[(size_t)(5 + k) * G2];
             if (best == best && (v > best || v != v)) { best = v; bi = k; }
         }
@@ -232,35 +241,38 @@ __device__ __forceinline__ Box4 decode_anchor(const float* loc4, const float* an
 __global__ __launch_bounds__(256) void greedy_nms_prep_kernel(const GParams P) {
     extern __shared__ float s_tile[];                       // kRows * (C + 1)
     const int b = blockIdx.y, tid = threadIdx.x, C = P.C, ld = C + 1;
-    const int a_blk = blockIdx.x * 256;
-    for (int sub = 0; sub < 256; sub += kRows) {
-        const int a0 = a_blk + sub;
-        if (a0 >= P.An) break;
-        const int nr = (P.An - a0) < kRows ? (P.An - a0) : kRows;
-        const float* src = P.cls + ((size_t)b * P.An + a0) * C;
-        __syncthreads();
-        for (int e = tid; e < nr * C; e += 256) {           // coalesced: consecutive lanes, consecutive floats
-            const int r = e / C, k = e - r * C;
-            s_tile[r * ld + k] = src[e];
+    const int a0 = blockIdx.x * kRows;
+    const int nr = (P.An - a0) < kRows ? (P.An - a0) : kRows;
+    const float* src = P.cls + ((size_t)b * P.An + a0) * C;
+    const int n = nr * C;
+    // coalesced: consecutive lanes read consecutive floats; 4 loads in flight per lane
+    for (int e = tid; e < n; e += 4 * 256) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = (e + u * 256) < n ? src[e + u * 256] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int ee = e + u * 256;
+            if (ee < n) { const int r = ee / C; s_tile[r * ld + (ee - r * C)] = v[u]; }
         }
-        __syncthreads();
-        const int r = tid >> 2, q = tid & 3;
-        float best = -1.f; int bi = 0x7fffffff;             // sigmoid > 0 > -1
-        if (r < nr) {
-            for (int k = q; k < C; k += 4) {
-                const float s = sigmoidf_(s_tile[r * ld + k]);
-                if (s > best || (s != s && best == best)) { best = s; bi = k; }
-            }
+    }
+    __syncthreads();
+    const int r = tid >> 2, q = tid & 3;
+    float best = -1.f; int bi = 0x7fffffff;                 // sigmoid > 0 > -1
+    if (r < nr) {
+        for (int k = q; k < C; k += 4) {
+            const float s = sigmoidf_(s_tile[r * ld + k]);
+            if (s > best || (s != s && best == best)) { best = s; bi = k; }
         }
-        // combine the 4 lanes of a row: larger value, then smaller index (torch.max(1): first index on ties)
-        for (int o = 1; o < 4; o <<= 1) {
-            const float ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
-            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-        }
-        if (r < nr && q == 0) {
-            const size_t o = (size_t)b * P.An + a0 + r;
-            P.score[o] = best; P.label[o] = bi;
-        }
+    }
+    // combine the 4 lanes of a row: larger value, then smaller index (torch.max(1): first index on ties)
+    for (int o = 1; o < 4; o <<= 1) {
+        const float ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (r < nr && q == 0) {
+        const size_t o = (size_t)b * P.An + a0 + r;
+        P.score[o] = best; P.label[o] = bi;
     }
 }
 
@@ -442,7 +454,7 @@ extern "C" int odpl_greedy_nms(const odpl_greedy_nms_desc_t* d, void* workspace,
     P.score = (float*)(ws + pl.score); P.label = (int*)(ws + pl.label); P.ckey = (float*)(ws + pl.ckey); P.cidx = (int*)(ws + pl.cidx);
     P.out = out_dets; P.out_counts = out_counts;
     prof_begin(ODPL_PROF_GREEDY_NMS_PREP, stream);
-    hipLaunchKernelGGL(greedy_nms_prep_kernel, dim3((d->An + 255) / 256, d->B), dim3(256), (size_t)kRows * (d->C + 1) * 4, stream, P);
+    hipLaunchKernelGGL(greedy_nms_prep_kernel, dim3((d->An + kRows - 1) / kRows, d->B), dim3(256), (size_t)kRows * (d->C + 1) * 4, stream, P);
     prof_end(ODPL_PROF_GREEDY_NMS_PREP, stream);
     ODPL_HIP_TRY(hipGetLastError());
     prof_begin(ODPL_PROF_GREEDY_NMS_IMAGE, stream);

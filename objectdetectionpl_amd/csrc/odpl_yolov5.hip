@@ -10,8 +10,8 @@
 //                          atomicMax(row) => "last row wins" for tobj (and marks each cell's leader row)
 //   rows   (1 wave / row)  coalesced 4*no-byte gather of the cell, box decode, IoU-family value AND its
 //                          gradient by forward-mode differentiation (4 tangents), focal-BCE over the classes
-//   dense  (chunks)        zero stream over the gradient tensors; every float4 that holds a cell's
-//                          objectness logit also evaluates focal-BCE(x, tobj) and its gradient; owner map reset
+//   dense  (chunks)        per chunk: objectness focal-BCE(x, tobj) of its <= 194 cells up front (gathers -> LDS), then
+//                          a pure 16-B store stream over the gradient tensor; owner map reset
 //                          [HBM-write bound: the roofline kernel of config 5]
 //   cells  (1 wave / row)  leader rows add the row gradients of all rows that share their cell, ascending row
 //                          order (index_put accumulate semantics, deterministic), over the zeros
@@ -40,7 +40,8 @@ struct Layer {
     float* row_grad;                  // [cap*no]
     int* nrows;                       // [1]
     float* dense_part;                // [dense_nblk]
-    int dense_blk0, dense_nblk;
+    int dense_blk0, dense_nblk;       // fill workgroups
+    int conf_blk0, conf_nblk;         // objectness workgroups (thread = cell); dense_part has conf_nblk entries
     unsigned long long inv_no;        // ceil(2^40 / no)
 };
 
@@ -233,50 +234,39 @@ __global__ __launch_bounds__(64) void v5_rows_kernel(const VParams P) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// dense pass: a workgroup owns a contiguous chunk of kChunkF4 float4 of the gradient tensor.
+//   phase 1: the <= 194 cells whose objectness element falls in the chunk are handled by one thread each:
+//            gather x (stride 4*no bytes), owner row, its IoU -> focal-BCE(x, tobj) value and gradient into LDS;
+//            owner map reset.  All loads are issued up front, in parallel.
+//   phase 2: pure store stream: every quad is ONE 16-byte non-temporal store; a quad that contains a cell's
+//            objectness element takes that element from LDS.  No load sits in the store stream and no partial
+//            (dword) store is issued, so the fill runs at the HBM write ceiling.
 template <bool GRAD>
 __global__ __launch_bounds__(kDT) void v5_dense_kernel(const VParams P) {
     __shared__ float sh[kDT / 64];
+    __shared__ float s_g[kChunkF4 * 4 / 6 + 2];      // cells per chunk at the smallest row (no = 6)
     const int tid = threadIdx.x;
     int li = 0;
     for (int i = 0; i < P.nl; ++i) if ((int)blockIdx.x >= P.L[i].dense_blk0) li = i;
     const Layer& S = P.L[li];
-    const int no = P.no;
+    const unsigned no = (unsigned)P.no;
     const size_t total = (size_t)S.cells * no, total4 = total / 4;
     const size_t q0 = (size_t)(blockIdx.x - S.dense_blk0) * kChunkF4;
-    const size_t q1 = (q0 + kChunkF4) < total4 ? (q0 + kChunkF4) : total4;
-    const float inv_cells = 1.0f / (float)S.cells;            // mean over all cells, gain 1.0 (losses.py:135,138)
+    const bool last = (q0 + kChunkF4) >= total4;
+    const size_t q1 = last ? total4 : (q0 + kChunkF4);
+    const size_t e0 = q0 * 4, e1 = last ? total : q1 * 4;     // the last chunk also owns the < 4 tail elements
+    const unsigned c_lo = e0 <= 4 ? 0u : (unsigned)((e0 - 4 + no - 1) / no);
+    const int n_loc = e1 >= 5 ? (int)((e1 - 5) / no) - (int)c_lo + 1 : 0;        // cells with e0 <= no*c+4 < e1
     float acc = 0.f;
-    v4f* g4 = reinterpret_cast<v4f*>(S.grad);
-    for (size_t q = q0 + tid; q < q1; q += kDT) {
-        v4f o = {0.f, 0.f, 0.f, 0.f};
-        const unsigned e = (unsigned)(q * 4);
-        const unsigned c = (unsigned)(((unsigned long long)e * S.inv_no) >> 40);
-        const unsigned r = e - c * (unsigned)no;
-        if (r >= 1u && r <= 4u) {                             // this quad holds cell c's objectness logit
-            const int ow = S.owner[c];
-            const float tobj = ow >= 0 ? fmaxf(S.row_iou[ow], 0.0f) : 0.0f;     // losses.py:123 (gr = 1)
-            float l, dx;
-            focal_bce(S.p[(size_t)c * no + 4], tobj, l, dx);
-            acc += l;
-            o[4 - r] = dx * inv_cells;
-            S.owner[c] = -1;                                  // leave the map clean
-        }
-        if (GRAD) __builtin_nontemporal_store(o, g4 + q);
-    }
-    // tail (< 4 elements) by the last workgroup of the layer
-    if (q1 == total4 && (size_t)tid < total - total4 * 4) {
-        const size_t e = total4 * 4 + tid;
-        const unsigned c = (unsigned)(e / no), r = (unsigned)(e - (size_t)c * no);
-        float o = 0.f;
-        if (r == 4u) {
-            const int ow = S.owner[c];
-            const float tobj = ow >= 0 ? fmaxf(S.row_iou[ow], 0.0f) : 0.0f;
-            float l, dx;
-            focal_bce(S.p[e], tobj, l, dx);
-            acc += l; o = dx * inv_cells;
-            S.owner[c] = -1;
-        }
-        if (GRAD) S.grad[e] = o;
+    for (int i = tid; i < n_loc; i += kDT) {                  // one pass at no = 85 (<= 194 cells per chunk)
+        const unsigned c = c_lo + i;
+        const int ow = S.owner[c];
+        const float tobj = ow >= 0 ? fmaxf(S.row_iou[ow], 0.0f) : 0.0f;         // losses.py:123 (gr = 1)
+        float l, dx;
+        focal_bce(S.p[(size_t)c * no + 4], tobj, l, dx);
+        acc += l;
+        s_g[i] = dx * (1.0f / (float)S.cells);                // mean over all cells, gain 1.0 (losses.py:135,138)
+        if (ow >= 0) S.owner[c] = -1;                         // leave the map clean
     }
     acc = wave_sum(acc);
     if ((tid & 63) == 0) sh[tid >> 6] = acc;
@@ -285,6 +275,21 @@ __global__ __launch_bounds__(kDT) void v5_dense_kernel(const VParams P) {
         float a = 0.f;
         for (int w = 0; w < kDT / 64; ++w) a += sh[w];
         S.dense_part[blockIdx.x - S.dense_blk0] = a;
+    }
+    if (!GRAD) return;
+    v4f* g4 = reinterpret_cast<v4f*>(S.grad);
+    for (size_t q = q0 + tid; q < q1; q += kDT) {
+        v4f o = {0.f, 0.f, 0.f, 0.f};
+        const unsigned e = (unsigned)(q * 4);
+        const unsigned c = (unsigned)(((unsigned long long)e * S.inv_no) >> 40);
+        const unsigned r = e - c * no;
+        if (r >= 1u && r <= 4u) o[4 - r] = s_g[c - c_lo];     // this quad holds cell c's objectness element
+        __builtin_nontemporal_store(o, g4 + q);
+    }
+    if (last && (size_t)tid < total - total4 * 4) {           // < 4 tail elements of the layer
+        const size_t e = total4 * 4 + tid;
+        const unsigned c = (unsigned)(e / no);
+        S.grad[e] = (e - (size_t)c * no) == 4 ? s_g[c - c_lo] : 0.f;
     }
 }
 
@@ -358,7 +363,7 @@ struct VPlan {
         row_lead[ODPL_MAX_SCALES], row_iou[ODPL_MAX_SCALES], row_part[ODPL_MAX_SCALES], row_grad[ODPL_MAX_SCALES],
         nrows[ODPL_MAX_SCALES], dense_part[ODPL_MAX_SCALES];
     size_t owner_bytes_total, total;
-    int dense_nblk[ODPL_MAX_SCALES], cap, no;
+    int dense_nblk[ODPL_MAX_SCALES], conf_nblk[ODPL_MAX_SCALES], cap, no;
 };
 
 bool make_vplan(const odpl_yolov5_loss_desc_t* d, VPlan* p) {
@@ -381,6 +386,7 @@ bool make_vplan(const odpl_yolov5_loss_desc_t* d, VPlan* p) {
         const size_t cap = (size_t)p->cap;
         const long long cells = (long long)d->B * d->na * d->layer[i].G * d->layer[i].G;
         p->dense_nblk[i] = (int)(((size_t)cells * p->no / 4 + kChunkF4 - 1) / kChunkF4); if (p->dense_nblk[i] < 1) p->dense_nblk[i] = 1;
+        p->conf_nblk[i] = (int)((cells + kDT - 1) / kDT);
         p->row_t[i] = off;    off += align_up(cap * 4, 256);
         p->row_ag[i] = off;   off += align_up(cap * 4, 256);
         p->row_cell[i] = off; off += align_up(cap * 4, 256);
@@ -423,12 +429,14 @@ extern "C" int odpl_yolov5_loss(const odpl_yolov5_loss_desc_t* d, void* workspac
         S.row_iou = (float*)(ws + pl.row_iou[i]); S.row_part = (float*)(ws + pl.row_part[i]);
         S.row_grad = (float*)(ws + pl.row_grad[i]); S.nrows = (int*)(ws + pl.nrows[i]);
         S.dense_part = (float*)(ws + pl.dense_part[i]);
+        S.conf_blk0 = 0; S.conf_nblk = 0;
         S.dense_blk0 = blk; S.dense_nblk = pl.dense_nblk[i]; blk += S.dense_nblk;
         S.inv_no = ((1ull << 40) + (unsigned long long)pl.no - 1ull) / (unsigned long long)pl.no;
         if (l.grad) want++;
     }
     if (want != 0 && want != d->nl) return ODPL_EINVAL;
     P.want_grad = want ? 1 : 0;
+
     if (!(d->flags & ODPL_YOLOV5_STATE_CLEAN)) {
         ODPL_HIP_TRY(hipMemsetAsync(ws + pl.status, 0, 256, stream));
         ODPL_HIP_TRY(hipMemsetAsync(ws + 256, 0xFF, pl.owner_bytes_total, stream));

@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""Kernel-level roofline table for every hot-path family at the BASELINE shapes (cold caches: 1 GiB fill between
+calls; HIP-event timing by the library, three events per launch).  One JSON line per kernel."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from objectdetectionpl_amd import _lib
+from objectdetectionpl_amd.LightningFunc import nms
+from objectdetectionpl_amd.LightningFunc.losses import MultiScaleRegionLoss_v4
+from objectdetectionpl_amd.LightningFunc.losses_dense import MultiScaleRegionLoss_v5, RetinaNetLoss, focal_loss
+from objectdetectionpl_amd.LightningFunc.utils import YoloV4Utils
+from objectdetectionpl_amd.LightningFunc.utils.RetinaUtils import get_anchor_boxes
+
+dev = torch.device("cuda:0")
+big = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+N = int(os.environ.get("N", 20))
+A9 = [[12, 16], [19, 36], [40, 28], [36, 75], [76, 55], [72, 146], [142, 110], [192, 243], [459, 401]]
+A18 = [v for a in A9 for v in a]
+M3 = [[0, 1, 2], [3, 4, 5], [6, 7, 8]]
+V5A = [[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]]
+
+
+def targets(g, B, per, C, lo=0.02, hi=0.5):
+    n = B * per
+    wh = torch.rand(n, 2, generator=g) * (hi - lo) + lo
+    return torch.cat([torch.arange(B).repeat_interleave(per).float()[:, None], torch.randint(0, C, (n, 1), generator=g).float(),
+                      torch.rand(n, 2, generator=g) * (1 - wh), wh], 1).to(dev)
+
+
+def measure(name, kernels, fn, alg_bytes, note):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    for k in kernels:
+        _lib.profile_enable(k, True)
+    for _ in range(N):
+        big.fill_(1.0)
+        fn()
+    torch.cuda.synchronize()
+    for k in kernels:
+        _lib.profile_enable(k, False)
+        ms, _ = _lib.profile_collect(k)
+        ms.sort()
+        us = 1e3 * ms[len(ms) // 2]
+        b = alg_bytes.get(k)
+        rec = {"workload": name, "kernel": k, "median_us": round(us, 2)}
+        if b:
+            rec.update(algorithmic_bytes=b, GBps=round(b / (us * 1e-6) / 1e9, 1), frac_of_8TBps=round(b / (us * 1e-6) / 8e12, 4))
+        rec["note"] = note.get(k, "")
+        print(json.dumps(rec), flush=True)
+
+
+def main():
+    g = torch.Generator().manual_seed(3)
+    # ---- config 2: YOLOv4 loss, NMS, decode
+    B, C = 16, 80
+    heads = [torch.randn(B, 255, G, G, generator=g).to(dev).requires_grad_() for G in (52, 26, 13)]
+    tgt = targets(g, B, 7, C)
+    crit = MultiScaleRegionLoss_v4(A9, M3, "bce_loss", "smooth_l1_loss", "bce_loss", C, 416)
+    cells = sum(B * 3 * G * G for G in (52, 26, 13))
+    measure("config2 YOLOv4 loss fwd+bwd (B=16, C=80, 416^2)", ["yolo_assign", "yolo_dense", "yolo_obj", "yolo_finalize"],
+            lambda: crit(heads, tgt), {"yolo_dense": 4 * cells * 85 + 12 * cells},
+            {"yolo_dense": "grad write + conf read + state read/reset", "yolo_assign": "latency bound", "yolo_obj": "latency bound",
+             "yolo_finalize": "latency bound"})
+    hn = []
+    for G in (52, 26, 13):       # valid geometry so that the NMS does real work
+        h = torch.randn(B, 3, 85, G, G, generator=g)
+        h[:, :, 0:2] = torch.rand(B, 3, 2, 1, 1, generator=g) * 300 + 50 + torch.randn(B, 3, 2, G, G, generator=g) * 40
+        h[:, :, 2:4] = torch.rand(B, 3, 2, G, G, generator=g) * 80 + 20
+        h[:, :, 4] = torch.randn(B, 3, G, G, generator=g) * 0.8 - 1.0
+        h[:, :, 5:] = torch.rand(B, 3, 80, G, G, generator=g)
+        hn.append(h.view(B, 255, G, G).contiguous().to(dev))
+    kept = sum(o.shape[0] for o in nms.yolo_non_max_suppression(hn) if o is not None)
+    measure(f"config2 YOLO weighted-merge NMS (10647 cand/img, {kept} kept over 16 img)", ["yolo_nms_prep", "yolo_nms_image"],
+            lambda: nms.yolo_non_max_suppression(hn), {"yolo_nms_prep": 4 * cells * 85 + cells * 40},
+            {"yolo_nms_prep": "head read + SoA write", "yolo_nms_image": "1 WG/image: bitonic sort + sequential pivots"})
+    measure("config2 YOLOv4 inference decode", ["yolo_decode"],
+            lambda: YoloV4Utils.decode_heads([h.detach() for h in heads], C, A18, M3, [8, 16, 32]),
+            {"yolo_decode": 4 * cells * 85 + 4 * cells * 84}, {"yolo_decode": "head read + boxes/confs write"})
+    del heads, hn
+    # ---- config 4: RetinaNet loss + greedy NMS
+    B, C = 4, 80
+    anchors = get_anchor_boxes([1333, 800], dev)
+    An = anchors.shape[0]
+    loc = (torch.randn(B, An, 4, generator=g) * 0.3).to(dev).requires_grad_()
+    cls = torch.randn(B, An, C, generator=g).to(dev).requires_grad_()
+    tg = targets(g, B, 8, C, 0.05, 0.5)
+    rc = RetinaNetLoss(anchors, focal_loss, "smooth_l1_loss", C, 800)
+    measure(f"config4 RetinaNet loss fwd+bwd (B=4, {An} anchors, C=80)", ["retina_assign", "retina_main"],
+            lambda: rc((loc, cls), tg), {"retina_main": 4 * B * An * 84 + 4 * B * An, "retina_assign": 16 * An + 4 * B * An},
+            {"retina_main": "grad write + code read", "retina_assign": "anchors read + code write; IoU compute"})
+    cls_n = (cls.detach() - 3.0)
+    measure("config4 Retina greedy top-100 NMS", ["greedy_nms_prep", "greedy_nms_image"],
+            lambda: nms.greedy_non_max_suppression((loc.detach(), cls_n), anchors),
+            {"greedy_nms_prep": 4 * B * An * C + 8 * B * An}, {"greedy_nms_prep": "class rows read (LDS staged) + score/label write",
+                                                                 "greedy_nms_image": "1 WG/image"})
+    del loc, cls, cls_n
+    # ---- config 5: YOLOv5-l loss (fp32 here)
+    B, C = 32, 80
+    h5 = [torch.randn(B, 3, G, G, 85, generator=g).to(dev).requires_grad_() for G in (80, 40, 20)]
+    t5 = targets(g, B, 7, C)
+    c5 = MultiScaleRegionLoss_v5(V5A, None, None, None, None, C, 640)
+    cells5 = sum(B * 3 * G * G for G in (80, 40, 20))
+    measure("config5 YOLOv5 loss fwd+bwd (B=32, C=80, 640^2, fp32)", ["yolov5_dense"], lambda: c5(h5, t5),
+            {"yolov5_dense": 4 * cells5 * 85 + 12 * cells5}, {"yolov5_dense": "grad write + objectness gather + owner map read/reset"})
+
+
+if __name__ == "__main__":
+    main()
