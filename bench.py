@@ -119,6 +119,7 @@ def main():
     ap.add_argument("--cpu-sample-batch", type=int, default=8)
     ap.add_argument("--cpu-sample-steps", type=int, default=4)
     ap.add_argument("--bucket-mb", type=int, default=48)
+    ap.add_argument("--force-ddp", action="store_true", help="wrap in DDP (RCCL) even at world size 1: exercises the N>1 code path on one GPU")
     ap.add_argument("--stamp", action="store_true", help="diagnostic: in-kernel 100 MHz stamps of yolo_dense_kernel (first start -> last end)")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="libodpl_hip tunable, e.g. yolo_fill_nt=1")
     ap.add_argument("--no-miopen-find", dest="miopen_find", action="store_false",
@@ -138,8 +139,13 @@ def main():
         sys.exit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_ddp = world > 1 or a.force_ddp
+    if use_ddp:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     from objectdetectionpl_amd import _lib
@@ -155,7 +161,7 @@ def main():
     if a.channels_last:
         model = model.to(memory_format=torch.channels_last)
     crit = model.criterion
-    net = wrap_data_parallel(model, dev, bucket_mb=a.bucket_mb) if world > 1 else model
+    net = wrap_data_parallel(model, dev, bucket_mb=a.bucket_mb) if use_ddp else model
     opt = torch.optim.Adam(model.parameters(), lr=Args.lr, weight_decay=Args.weight_decay, fused=bool(a.fused_adam))
     x, y = synthetic_batch(1 + rank, a.batch, a.classes, a.img, dev)
     if a.channels_last:
@@ -170,7 +176,7 @@ def main():
         return d
 
     def fence():
-        if world > 1:
+        if use_ddp:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -204,7 +210,7 @@ def main():
     loss_val = float(d["loss"].item())
 
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_ddp:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
 
@@ -246,7 +252,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a.cpu_sample_batch, a.classes, a.img, a.cpu_sample_steps)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_ddp:
         dist.barrier()
         dist.destroy_process_group()
 
