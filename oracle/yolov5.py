@@ -69,7 +69,17 @@ def v5_loss(p, targets, anchors, nc, iou_mode="giou"):
             pwh = (ps[:, 2:4].sigmoid() * 2) ** 2 * an
             iou = iou_v5(torch.cat((pxy, pwh), 1).t(), tbox.t(), x1y1x2y2=False, mode=iou_mode)
             lbox = lbox + (1.0 - iou).mean()
-            tobj[b, a, gj, gi] = iou.detach().clamp(0).type(tobj.dtype)     # gr = 1.0; duplicates: last row wins
+            # gr = 1.0.  Duplicate cells: the reference's `tobj[b,a,gj,gi] = ...` is an index_put with repeated
+            # indices -- sequential (last row wins) for the sizes its own runs produce, but ATen splits the loop
+            # across threads for a few thousand rows and the winner becomes thread-count dependent.  The contract
+            # here (and in the HIP kernel) is the deterministic one: the LAST row in row order wins.
+            na, G2 = pi.shape[1], G * G
+            lin = ((b * na + a) * G + gj) * G + gi
+            owner = torch.full((pi.shape[0] * na * G2,), -1, dtype=torch.long)
+            owner.scatter_reduce_(0, lin, torch.arange(lin.numel()), reduce="amax", include_self=True)
+            hit = owner >= 0
+            flat = tobj.view(-1)
+            flat[hit] = iou.detach().clamp(0).type(tobj.dtype)[owner[hit]]
             if nc > 1:
                 t = torch.zeros_like(ps[:, 5:])
                 t[range(b.shape[0]), tcls] = 1.0

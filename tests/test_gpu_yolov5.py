@@ -30,7 +30,7 @@ def test_v5_loss_vs_golden(golden, case):
     out = crit(heads, T(g[f"{case}_target"]).to(d))
     out["loss"].backward()
     for k in KEYS:
-        a, b = out[k].item(), float(g[f"{case}_{k}"])
+        a, b = out[k].item(), float(np.asarray(g[f"{case}_{k}"]).reshape(-1)[0])
         assert abs(a - b) <= 1e-4 * abs(b) + 1e-6, (k, a, b)
     for i, h in enumerate(heads):
         _cmp_grads(h.grad, g[f"{case}_grad{i}"])
