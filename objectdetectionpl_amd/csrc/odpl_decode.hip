@@ -62,9 +62,21 @@ __global__ __launch_bounds__(kThreads) void yolo_decode_kernel(const DParams P) 
     }
     __syncthreads();
     float* dst = P.confs + n0 * C;                       // 64 candidates x C classes, contiguous
-    for (int e = tid; e < nc * C; e += kThreads) {
-        const int i = e / C, k = e - i * C;
-        dst[e] = sigmoidf_(s_t[(5 + k) * ld + i]) * s_t[4 * ld + i];              // :170
+    if ((C & 3) == 0 && ((n0 * C) & 3) == 0) {           // 16-B stores: 4 consecutive classes of one candidate
+        const int c4 = C >> 2;
+        for (int e = tid; e < nc * c4; e += kThreads) {
+            const int i = e / c4, k = 4 * (e - i * c4);
+            const float dc = s_t[4 * ld + i];
+            float4 o;
+            o.x = sigmoidf_(s_t[(5 + k) * ld + i]) * dc; o.y = sigmoidf_(s_t[(6 + k) * ld + i]) * dc;      // :170
+            o.z = sigmoidf_(s_t[(7 + k) * ld + i]) * dc; o.w = sigmoidf_(s_t[(8 + k) * ld + i]) * dc;
+            reinterpret_cast<float4*>(dst)[e] = o;
+        }
+    } else {
+        for (int e = tid; e < nc * C; e += kThreads) {
+            const int i = e / C, k = e - i * C;
+            dst[e] = sigmoidf_(s_t[(5 + k) * ld + i]) * s_t[4 * ld + i];          // :170
+        }
     }
 }
 }  // namespace

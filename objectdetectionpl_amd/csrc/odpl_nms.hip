@@ -44,44 +44,66 @@ struct YParams {
     float* out; int* out_counts;
 };
 
+// A workgroup = 64 consecutive candidates x 4 waves; wave q scans classes [q*nc/4, (q+1)*nc/4) so that four times
+// as many waves (and loads) are in flight per CU; lanes run along the G*G plane => every load is one coalesced
+// 256-B segment.  Wave 0 merges the four partial (max, first argmax) pairs through LDS and writes the SoA.
 __global__ __launch_bounds__(kPrepT) void yolo_nms_prep_kernel(const YParams P) {
-    const int b = blockIdx.y, n = blockIdx.x * kPrepT + threadIdx.x;
-    int valid = 0;
+    __shared__ float s_best[4][64];
+    __shared__ int s_bi[4][64];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, q = threadIdx.x >> 6, n = blockIdx.x * 64 + lane;
+    const int nc = P.no - 5;
+    const float* base = nullptr;
+    int G2 = 1;
     if (n < P.N) {
         int s = 0;
         while (s + 1 < P.nscales && n >= P.first[s + 1]) ++s;
-        const int G2 = P.G[s] * P.G[s], r = n - P.first[s], a = r / G2, sp = r - a * G2;
-        const float* base = P.head[s] + ((size_t)(b * P.A + a) * P.no) * G2 + sp;
-        const float x = base[0], y = base[(size_t)G2], w = base[(size_t)2 * G2], h = base[(size_t)3 * G2];
-        const float cf = base[(size_t)4 * G2];
-        float best = base[(size_t)5 * G2]; int bi = 0;                       // max(1): first index on ties
-        const int nc = P.no - 5;
-        int k = 1;
-        for (; k + 8 <= nc; k += 8) {                                        // 8 independent loads in flight per lane
+        G2 = P.G[s] * P.G[s];
+        const int r = n - P.first[s], a = r / G2, sp = r - a * G2;
+        base = P.head[s] + ((size_t)(b * P.A + a) * P.no) * G2 + sp;
+    }
+    const int k0 = (int)(((long long)nc * q) / 4), k1 = (int)(((long long)nc * (q + 1)) / 4);
+    float best = -INFINITY; int bi = 0x7fffffff; bool have = false;
+    if (base) {
+        int k = k0;
+        for (; k + 8 <= k1; k += 8) {                                        // 8 independent loads in flight per lane
             float v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) v[u] = base[(size_t)(5 + k + u) * G2];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) if (best == best && (v[u] > best || v[u] != v[u])) { best = v[u]; bi = k + u; }
+            for (int u = 0; u < 8; ++u) if (!have || (best == best && (v[u] > best || v[u] != v[u]))) { best = v[u]; bi = k + u; have = true; }
         }
-        for (; k < nc; ++k) {
+        for (; k < k1; ++k) {
             const float v = base[(size_t)(5 + k) * G2];
-            if (best == best && (v > best || v != v)) { best = v; bi = k; }
+            if (!have || (best == best && (v > best || v != v))) { best = v; bi = k; have = true; }
         }
-        const Box4 bx = corners_of(x, y, w, h);                              // xywh2xyxy, YOLOV4.py:253
-        const size_t o = (size_t)b * P.N + n;
-        P.box[o] = make_float4(bx.x1, bx.y1, bx.x2, bx.y2);
-        P.conf[o] = cf; P.cconf[o] = best; P.label[o] = bi;
-        valid = cf >= P.conf_thres;                                          // YOLOV4.py:258
-        const float sc = cf * best;                                          // YOLOV4.py:263
-        P.key[(size_t)b * P.Npad + n] = valid ? sc : -INFINITY;
-        P.idx[(size_t)b * P.Npad + n] = valid ? (unsigned)n : 0xffffffffu;
-    } else if (n < P.Npad) {
-        P.key[(size_t)b * P.Npad + n] = -INFINITY;
-        P.idx[(size_t)b * P.Npad + n] = 0xffffffffu;
     }
-    const unsigned long long m = __ballot(valid);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&P.nvalid[b], __popcll(m));
+    s_best[q][lane] = best; s_bi[q][lane] = have ? bi : 0x7fffffff;
+    __syncthreads();
+    int valid = 0;
+    if (q == 0) {
+        if (base) {
+            float bv = s_best[0][lane]; int bk = s_bi[0][lane];
+            for (int w = 1; w < 4; ++w) {                                    // class ranges ascend with w: first index wins ties
+                const float ov = s_best[w][lane]; const int ok = s_bi[w][lane];
+                if (ok == 0x7fffffff) continue;
+                if (bk == 0x7fffffff || (bv == bv && (ov > bv || ov != ov))) { bv = ov; bk = ok; }
+            }
+            const float x = base[0], y = base[(size_t)G2], w = base[(size_t)2 * G2], h = base[(size_t)3 * G2];
+            const float cf = base[(size_t)4 * G2];
+            const Box4 bx = corners_of(x, y, w, h);                          // xywh2xyxy, YOLOV4.py:253
+            const size_t o = (size_t)b * P.N + n;
+            P.box[o] = make_float4(bx.x1, bx.y1, bx.x2, bx.y2);
+            P.conf[o] = cf; P.cconf[o] = bv; P.label[o] = bk;
+            valid = cf >= P.conf_thres;                                      // YOLOV4.py:258
+            P.key[(size_t)b * P.Npad + n] = valid ? cf * bv : -INFINITY;    // YOLOV4.py:263
+            P.idx[(size_t)b * P.Npad + n] = valid ? (unsigned)n : 0xffffffffu;
+        } else if (n < P.Npad) {
+            P.key[(size_t)b * P.Npad + n] = -INFINITY;
+            P.idx[(size_t)b * P.Npad + n] = 0xffffffffu;
+        }
+        const unsigned long long m = __ballot(valid);
+        if (lane == 0 && m) atomicAdd(&P.nvalid[b], __popcll(m));
+    }
 }
 
 __global__ __launch_bounds__(kImgT) void yolo_nms_image_kernel(const YParams P) {
@@ -206,7 +228,7 @@ extern "C" int odpl_yolo_nms(const odpl_yolo_nms_desc_t* d, void* workspace, siz
     P.nvalid = (int*)(ws + pl.nvalid); P.out = out_dets; P.out_counts = out_counts;
     if (!(d->flags & ODPL_NMS_STATE_CLEAN)) ODPL_HIP_TRY(hipMemsetAsync(P.nvalid, 0, (size_t)d->B * sizeof(int), stream));
     prof_begin(ODPL_PROF_YOLO_NMS_PREP, stream);
-    hipLaunchKernelGGL(yolo_nms_prep_kernel, dim3((pl.Npad + kPrepT - 1) / kPrepT, d->B), dim3(kPrepT), 0, stream, P);
+    hipLaunchKernelGGL(yolo_nms_prep_kernel, dim3((pl.Npad + 63) / 64, d->B), dim3(kPrepT), 0, stream, P);
     prof_end(ODPL_PROF_YOLO_NMS_PREP, stream);
     ODPL_HIP_TRY(hipGetLastError());
     prof_begin(ODPL_PROF_YOLO_NMS_IMAGE, stream);
@@ -239,22 +261,29 @@ __device__ __forceinline__ Box4 decode_anchor(const float* loc4, const float* an
 }
 
 __global__ __launch_bounds__(256) void greedy_nms_prep_kernel(const GParams P) {
-    extern __shared__ float s_tile[];                       // kRows * (C + 1)
-    const int b = blockIdx.y, tid = threadIdx.x, C = P.C, ld = C + 1;
-    const int a0 = blockIdx.x * kRows;
+    extern __shared__ float s_tile[];                       // kRows * ld
+    const int b = blockIdx.y, tid = threadIdx.x, C = P.C;
+    const bool vec = (C & 3) == 0;
+    const int ld = vec ? C + 4 : C + 1;                     // C+4: rows stay 16-B aligned, and (C+4) mod 32 spreads the 8 rows
+    const int a0 = blockIdx.x * kRows;                      // of a 32-lane group over distinct banks for C = 80
     const int nr = (P.An - a0) < kRows ? (P.An - a0) : kRows;
     const float* src = P.cls + ((size_t)b * P.An + a0) * C;
     const int n = nr * C;
-    // coalesced: consecutive lanes read consecutive floats; 4 loads in flight per lane
-    for (int e = tid; e < n; e += 4 * 256) {
-        float v[4];
+    if (vec) {                                              // the 64 x C tile is contiguous: 16-B loads, 4 in flight per lane
+        const float4* src4 = reinterpret_cast<const float4*>(src);
+        const int n4 = n >> 2, c4 = C >> 2;
+        for (int e = tid; e < n4; e += 4 * 256) {
+            float4 v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = (e + u * 256) < n ? src[e + u * 256] : 0.f;
+            for (int u = 0; u < 4; ++u) v[u] = (e + u * 256) < n4 ? src4[e + u * 256] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int ee = e + u * 256;
-            if (ee < n) { const int r = ee / C; s_tile[r * ld + (ee - r * C)] = v[u]; }
+            for (int u = 0; u < 4; ++u) {
+                const int ee = e + u * 256;
+                if (ee < n4) { const int r = ee / c4; *reinterpret_cast<float4*>(&s_tile[r * ld + 4 * (ee - r * c4)]) = v[u]; }
+            }
         }
+    } else {
+        for (int e = tid; e < n; e += 256) { const int r = e / C; s_tile[r * ld + (e - r * C)] = src[e]; }
     }
     __syncthreads();
     const int r = tid >> 2, q = tid & 3;
@@ -425,7 +454,7 @@ struct GPlan { size_t score, label, ckey, cidx, total; };
 bool make_gplan(const odpl_greedy_nms_desc_t* d, GPlan* p) {
     if (!d || d->B < 1 || d->An < 1 || d->C < 1 || d->topk < 1 || d->topk > kMaxTopk) return false;
     if (!d->loc || !d->cls || !d->anchors) return false;
-    if ((size_t)kRows * (d->C + 1) * 4 > 60 * 1024) return false;
+    if ((size_t)kRows * (d->C + 4) * 4 > 60 * 1024) return false;
     const size_t BN = (size_t)d->B * d->An;
     size_t off = 0;
     p->score = off; off += align_up(BN * 4, 256);
@@ -454,7 +483,7 @@ extern "C" int odpl_greedy_nms(const odpl_greedy_nms_desc_t* d, void* workspace,
     P.score = (float*)(ws + pl.score); P.label = (int*)(ws + pl.label); P.ckey = (float*)(ws + pl.ckey); P.cidx = (int*)(ws + pl.cidx);
     P.out = out_dets; P.out_counts = out_counts;
     prof_begin(ODPL_PROF_GREEDY_NMS_PREP, stream);
-    hipLaunchKernelGGL(greedy_nms_prep_kernel, dim3((d->An + kRows - 1) / kRows, d->B), dim3(256), (size_t)kRows * (d->C + 1) * 4, stream, P);
+    hipLaunchKernelGGL(greedy_nms_prep_kernel, dim3((d->An + kRows - 1) / kRows, d->B), dim3(256), (size_t)kRows * (d->C + 4) * 4, stream, P);
     prof_end(ODPL_PROF_GREEDY_NMS_PREP, stream);
     ODPL_HIP_TRY(hipGetLastError());
     prof_begin(ODPL_PROF_GREEDY_NMS_IMAGE, stream);

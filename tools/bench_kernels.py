@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Kernel-level roofline table for every hot-path family at the BASELINE shapes (cold caches: 1 GiB fill between
-calls; HIP-event timing by the library, three events per launch).  One JSON line per kernel."""
+"""Kernel-level roofline table for every hot-path family at the BASELINE shapes.  Cold caches: a 1 GiB buffer is
+READ between calls (clean eviction of L2 + Infinity Cache; EVICT=write fills it instead, which leaves 256 MB of
+dirty lines draining under the timed kernel and roughly halves read bandwidth).  HIP-event timing by the library,
+three events per launch.  One JSON line per kernel."""
 import json
 import os
 import sys
@@ -38,7 +40,10 @@ def measure(name, kernels, fn, alg_bytes, note):
     for k in kernels:
         _lib.profile_enable(k, True)
     for _ in range(N):
-        big.fill_(1.0)
+        if os.environ.get("EVICT", "read") == "write":
+            big.fill_(1.0)
+        else:
+            big.sum()
         fn()
     torch.cuda.synchronize()
     for k in kernels:
@@ -47,7 +52,7 @@ def measure(name, kernels, fn, alg_bytes, note):
         ms.sort()
         us = 1e3 * ms[len(ms) // 2]
         b = alg_bytes.get(k)
-        rec = {"workload": name, "kernel": k, "median_us": round(us, 2)}
+        rec = {"workload": name, "kernel": k, "median_us": round(us, 2), "evict": os.environ.get("EVICT", "read")}
         if b:
             rec.update(algorithmic_bytes=b, GBps=round(b / (us * 1e-6) / 1e9, 1), frac_of_8TBps=round(b / (us * 1e-6) / 8e12, 4))
         rec["note"] = note.get(k, "")
