@@ -287,6 +287,15 @@ int odpl_ap_per_class(const double* tp, const float* conf, const float* pred_cls
                       double* out_p, double* out_r, double* out_ap, double* out_f1, int32_t* out_classes,
                       int32_t* out_num_classes, void* stream);
 
+/* get_yolo_statistics (accuracy.py:382-470), one scale: (1) training-style decode of the raw head
+ * [B, A*(5+C), G, G] into pred_boxes [B,A,G,G,4] (grid units), pred_conf [B,A,G,G], pred_cls [B,A,G,G,C] and
+ * output [B, A*G*G, 5+C] (boxes*stride, conf, cls); (2) odpl_yolo_build_targets on them; (3) the six metrics
+ * out6 = cls_acc, recall50, recall75, precision, conf_obj, conf_noobj. */
+int odpl_yolo_train_decode(const float* head, int32_t B, int32_t A, int32_t C, int32_t G, const float* host_anchor_wh,
+                           float stride, float* pred_boxes, float* pred_conf, float* pred_cls, float* output, void* stream);
+int odpl_yolo_stats_reduce(const float* pred_conf, const float* class_mask, const float* iou_scores, const uint8_t* obj_mask,
+                           const uint8_t* noobj_mask, int64_t cells, float* out6, void* stream);
+
 /* launch-geometry knobs (process-wide; defaults are the tuned values) */
 #define ODPL_TUNE_YOLO_FILL_F4_PER_BLOCK 0
 #define ODPL_TUNE_YOLO_FILL_NT 1

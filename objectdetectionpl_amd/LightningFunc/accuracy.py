@@ -163,3 +163,41 @@ def ap_per_class(tp, conf, pred_cls, target_cls, device="cuda"):
     k = int(ncls.item())
     p, r, ap, f1 = (o[:k].cpu().numpy() for o in outs)
     return p, r, ap, f1, ocls[:k].cpu().numpy().astype("int32")
+
+
+def get_yolo_statistics(self, output, target):
+    """accuracy.py:382-470 (attached to the YOLO v2/v3/v4 model classes as a method, `self` = the model).
+    Returns {grid_size: [cls_acc, recall50, recall75, precision, conf_obj, conf_noobj, output.cpu()]}."""
+    import ctypes as _ct
+    if type(output) != list:
+        output = [output]
+    L = _lib.lib()
+    res = {}
+    for i, x in enumerate(output):
+        if self.anch_masks is not None:                                  # yolo_v4
+            anchors = [self.anchors[m] for m in self.anch_masks[i]]
+        elif len(self.anchors) == 3:                                     # yolo_v3
+            anchors = self.anchors[i]
+        else:                                                            # yolo_v2
+            anchors = self.anchors
+        _lib.require_cuda(x, target)
+        x = x.float().contiguous()
+        dev = x.device
+        A, B, G, C = len(anchors), x.size(0), x.size(2), self.num_classes
+        stride = self.img_size / G
+        wh = (_ct.c_float * (2 * A))()
+        for a, (aw, ah) in enumerate(anchors):
+            wh[2 * a], wh[2 * a + 1] = aw / stride, ah / stride            # accuracy.py:426: python double, then f32
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        pb, pconf, pcls, out = f(B, A, G, G, 4), f(B, A, G, G), f(B, A, G, G, C), f(B, A * G * G, 5 + C)
+        _lib.check(L.odpl_yolo_train_decode(_lib.ptr(x), B, A, C, G, wh, stride, _lib.ptr(pb), _lib.ptr(pconf), _lib.ptr(pcls),
+                                            _lib.ptr(out), _lib.current_stream(dev)), "odpl_yolo_train_decode")
+        sa = torch.tensor([[wh[2 * a], wh[2 * a + 1]] for a in range(A)], dtype=torch.float32, device=dev)
+        iou_scores, class_mask, obj_mask, noobj_mask, *_rest = build_targets(pb, pcls, target, sa, self.ignore_thres)
+        out6 = f(6)
+        _lib.check(L.odpl_yolo_stats_reduce(_lib.ptr(pconf), _lib.ptr(class_mask), _lib.ptr(iou_scores), _lib.ptr(obj_mask),
+                                            _lib.ptr(noobj_mask), B * A * G * G, _lib.ptr(out6), _lib.current_stream(dev)),
+                   "odpl_yolo_stats_reduce")
+        vals = out6.cpu().numpy()
+        res[G] = [vals[0], vals[1], vals[2], vals[3], vals[4], vals[5], out.cpu()]
+    return res

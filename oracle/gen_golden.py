@@ -551,6 +551,26 @@ def group_metrics(losses, accuracy):
     save("metrics", **arrays)
 
 
+def group_yolo_stats(losses, accuracy):
+    """G8b: get_yolo_statistics (accuracy.py:382-470) on a 2-scale YOLOv4-style model stub."""
+    torch.cuda.FloatTensor = torch.FloatTensor
+    class _M:
+        pass
+    m = _M()
+    m.anchors = V4_ANCHORS; m.anch_masks = [[3, 4, 5], [6, 7, 8]]; m.num_classes = 4; m.img_size = 416; m.ignore_thres = 0.5
+    g = torch.Generator().manual_seed(99)
+    heads = [torch.randn(2, 27, G, G, generator=g) for G in (26, 13)]
+    tgt = assign_cases(26, 4)["dup"]
+    out = accuracy.get_yolo_statistics(m, heads, tgt)
+    arrays = {"target": tgt}
+    for i, h in enumerate(heads):
+        arrays[f"head{i}"] = h
+    for G, vals in out.items():
+        for name, v in zip(("cls_acc", "recall50", "recall75", "precision", "conf_obj", "conf_noobj", "output"), vals):
+            arrays[f"G{G}_{name}"] = v
+    save("yolo_stats", **arrays)
+
+
 GROUPS = {
     "yolo_assign": group_yolo_assign,
     "yolo_loss": group_yolo_loss,
@@ -563,6 +583,7 @@ GROUPS = {
     "yolov5": group_yolov5,
     "ssd": group_ssd,
     "metrics": group_metrics,
+    "yolo_stats": group_yolo_stats,
 }
 
 

@@ -184,3 +184,33 @@ def region_loss_v2(head, target, anchors, num_classes, img_dim=416, **kw):
     """`losses.py:797-905`: single scale, A = len(anchors) (5), dict returned directly (no /n)."""
     r = region_loss(head, target, anchors, num_classes, img_dim, **kw)
     return dict(zip(KEYS, r))
+
+
+def yolo_statistics(heads, target, anchors, anch_masks, num_classes, img_size, ignore_thres=IGNORE_THRES):
+    """`accuracy.py:382-470` (get_yolo_statistics) for the v4 anchor convention (anch_masks given).
+    -> {G: [cls_acc, recall50, recall75, precision, conf_obj, conf_noobj, output[B, A*G*G, 5+C]]}."""
+    res = {}
+    C = num_classes
+    for i, x in enumerate(heads):
+        sub = [anchors[m] for m in anch_masks[i]]
+        A, B, G = len(sub), x.size(0), x.size(2)
+        p = x.view(B, A, C + 5, G, G).permute(0, 1, 3, 4, 2).contiguous()
+        sx, sy, w, h = torch.sigmoid(p[..., 0]), torch.sigmoid(p[..., 1]), p[..., 2], p[..., 3]
+        conf, pcls = torch.sigmoid(p[..., 4]), torch.sigmoid(p[..., 5:])
+        stride = img_size / G
+        sa = scaled_anchors(sub, img_size, G)
+        pb = torch.empty(B, A, G, G, 4)
+        pb[..., 0] = sx + torch.arange(G, dtype=torch.float32).view(1, 1, 1, G)
+        pb[..., 1] = sy + torch.arange(G, dtype=torch.float32).view(1, 1, G, 1)
+        pb[..., 2] = torch.exp(w) * sa[:, 0].view(1, A, 1, 1)
+        pb[..., 3] = torch.exp(h) * sa[:, 1].view(1, A, 1, 1)
+        asg = assign_targets(pb, pcls, target, sa, ignore_thres)
+        om, nm = asg["obj_mask"].bool(), asg["noobj_mask"].bool()
+        conf50 = (conf > 0.5).float()
+        iou50, iou75 = (asg["iou_scores"] > 0.5).float(), (asg["iou_scores"] > 0.75).float()
+        det = conf50 * asg["class_mask"] * asg["tconf"]
+        out = torch.cat((pb.view(B, -1, 4) * stride, conf.view(B, -1, 1), pcls.view(B, -1, C)), -1)
+        res[G] = [(100 * asg["class_mask"][om].mean()).numpy(), (torch.sum(iou50 * det) / (om.sum() + 1e-16)).numpy(),
+                  (torch.sum(iou75 * det) / (om.sum() + 1e-16)).numpy(), (torch.sum(iou50 * det) / (conf50.sum() + 1e-16)).numpy(),
+                  conf[om].mean().numpy(), conf[nm].mean().numpy(), out]
+    return res

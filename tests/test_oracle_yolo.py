@@ -103,3 +103,13 @@ def test_iou_family_bit_exact(golden):
     assert np.array_equal(boxes.iou_corner(T(g["corner_a"]), T(g["corner_b"])).numpy(), g["corner_iou"], equal_nan=True)
     assert np.array_equal(boxes.iou_matrix_plus1(a[:64], b[:16], "xywh").numpy(), g["retina_box_iou_xywh"])
     assert np.array_equal(boxes.iou_matrix_plus1(ax[:64], bx[:16], "xyxy").numpy(), g["retina_box_iou_xyxy"])
+
+
+def test_yolo_statistics(golden):
+    g = golden("yolo_stats")
+    heads = [T(g["head0"]), T(g["head1"])]
+    res = yolo.yolo_statistics(heads, T(g["target"]), V4_ANCHORS, [[3, 4, 5], [6, 7, 8]], 4, 416)
+    for G in (26, 13):
+        for i, name in enumerate(("cls_acc", "recall50", "recall75", "precision", "conf_obj", "conf_noobj")):
+            assert _close(res[G][i], g[f"G{G}_{name}"]), (G, name)
+        assert _close(res[G][6].numpy(), g[f"G{G}_output"], rtol=1e-6, atol=1e-6)
