@@ -1,0 +1,43 @@
+"""Synthetic COCO-shaped data module producing the reference's collate wire format ON THE DEVICE:
+`(x f32 [B,3,H,W] in [0,1] (BGR order, no mean/std: dataset/Pascal.py:98,179), y f32 [nT,6] = (img_idx_in_batch,
+cls, x, y, w, h) normalised)` -- dataset/Pascal.py:176-186.  Datasets themselves are out of scope (absent data,
+Windows paths); this module exists so that training/eval loops can run at full device speed without a CPU loader."""
+import torch
+
+
+class SyntheticCocoModule:
+    name = "synthetic"
+
+    def __init__(self, batch_size, img_size, num_classes=80, targets_per_image=7, steps_per_epoch=8, device="cuda", seed=1):
+        self.batch_size, self.img_size, self.num_classes = batch_size, img_size, num_classes
+        self.targets_per_image, self.steps_per_epoch = targets_per_image, steps_per_epoch
+        self.device, self.seed = torch.device(device), seed
+
+    def setup(self, stage=None):
+        return self
+
+    def get_class(self):
+        return [str(i) for i in range(self.num_classes)]
+
+    def _batch(self, g):
+        B, n = self.batch_size, self.batch_size * self.targets_per_image
+        x = torch.rand(B, 3, self.img_size, self.img_size, generator=g, device=self.device)
+        b = torch.arange(B, device=self.device).repeat_interleave(self.targets_per_image).float()
+        cls = torch.randint(0, self.num_classes, (n,), generator=g, device=self.device).float()
+        wh = torch.rand(n, 2, generator=g, device=self.device) * 0.48 + 0.02
+        xy = torch.rand(n, 2, generator=g, device=self.device) * (1 - wh)
+        return x, torch.cat([b[:, None], cls[:, None], xy, wh], 1)
+
+    def _loader(self, offset):
+        g = torch.Generator(device=self.device).manual_seed(self.seed + offset)
+        for _ in range(self.steps_per_epoch):
+            yield self._batch(g)
+
+    def train_dataloader(self):
+        return self._loader(0)
+
+    def val_dataloader(self):
+        return self._loader(1000)
+
+    def test_dataloader(self):
+        return self._loader(2000)

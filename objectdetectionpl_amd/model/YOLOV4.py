@@ -15,6 +15,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ..LightningFunc import step as _step
+from ..LightningFunc.accuracy import get_yolo_statistics as _get_yolo_statistics
 from ..LightningFunc.losses import configure_loss
 
 try:                                    # PL is optional: the reference derives from pl.LightningModule
@@ -192,15 +194,14 @@ class YOLOv4(_Base):
         x20, x13, x6 = self.neek(d5, d4, d3)
         return self.head(x20, x13, x6)
 
-    # step glue (LightningFunc/step.py:14-25): forward + criterion; logging is the trainer's business
-    def training_step(self, batch, batch_idx=0):
-        x, y = batch
-        return self.criterion(self.forward(x), y)
-
-    def validation_step(self, batch, batch_idx=0):
-        x, y = batch
-        with torch.no_grad():
-            return self.criterion(self.forward(x), y)
+    # step glue: the functions the reference setattr's in __build_func (YOLOV4.py:186-202)
+    training_step = _step.training_step
+    training_epoch_end = _step.training_epoch_end
+    validation_step = _step.validation_step
+    validation_epoch_end = _step.validation_epoch_end
+    test_step = _step.test_step
+    test_epoch_end = _step.test_epoch_end
+    get_yolo_statistics = _get_yolo_statistics
 
     def non_max_suppression(self, predictions, conf_thres=0.5, nms_thres=0.4):
         from ..LightningFunc.nms import yolo_non_max_suppression

@@ -1,0 +1,37 @@
+"""End to end on the device: YOLOv4 (reduced input) trained for a few steps on the synthetic module, validated and
+tested through NMS + get_yolo_statistics -- every hot-path kernel family of the YOLO flow in one run."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+class Args:
+    model_name = "YOLOv4"; cls_criterion = "bce_loss"; coord_criterion = "smooth_l1_loss"; data_module = "synthetic"
+    lr = 1e-3; weight_decay = 1e-5
+
+
+def test_fit_validate_test_yolov4_small():
+    from objectdetectionpl_amd.dataset.Synthetic import SyntheticCocoModule
+    from objectdetectionpl_amd.model.YOLOV4 import YOLOv4
+    from objectdetectionpl_amd.trainer import Trainer
+    torch.manual_seed(0)
+    dm = SyntheticCocoModule(batch_size=2, img_size=128, num_classes=4, targets_per_image=3, steps_per_epoch=4, device="cuda:0")
+    model = YOLOv4(dm.get_class(), Args())
+    model.img_size = 128                       # instance override: the class default is 416 (SURVEY section 7 hard part 5)
+    model.criterion.img_dim = 128
+    tr = Trainer(max_epochs=2, limit_val_batches=2, limit_test_batches=2, device="cuda:0")
+    hist = tr.fit(model, dm)
+    kinds = [h[0] for h in hist]
+    assert kinds == ["train", "val", "train", "val"]
+    for _, _, scalars in hist:
+        tags = {t for t, _, _, _ in scalars}
+        assert {"Epoch/loss", "Epoch/Conf", "Epoch/Classification"} <= tags
+        assert all(math.isfinite(v) for _, _, v, _ in scalars)
+    res = tr.test(model, dm)
+    assert set(res.keys()) == {16, 8, 4}
+    for g, d in res.items():
+        assert set(d) == {"cls_acc", "recall50", "recall75", "precision", "conf_obj", "conf_noobj"}
+        assert 0.0 <= d["conf_noobj"] <= 1.0
