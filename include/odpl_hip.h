@@ -296,6 +296,15 @@ int odpl_yolo_train_decode(const float* head, int32_t B, int32_t A, int32_t C, i
 int odpl_yolo_stats_reduce(const float* pred_conf, const float* class_mask, const float* iou_scores, const uint8_t* obj_mask,
                            const uint8_t* noobj_mask, int64_t cells, float* out6, void* stream);
 
+/* ---- SPP block of the YOLOv4 neck: utils/YoloV4Utils.py:400-420 ----------------- */
+/* y[B, 4C, H, W] = cat(maxpool13(x), maxpool9(x), maxpool5(x), x) (stride 1, same padding); strides are ELEMENT
+ * strides (b, c, h, w) of dense tensors in any memory format (NCHW or channels-last); H*W <= 1024.
+ * grad_x has x's strides, grad_y has y's. */
+int odpl_spp_forward(const float* x, const int64_t* host_x_strides, int32_t B, int32_t C, int32_t H, int32_t W,
+                     float* y, const int64_t* host_y_strides, void* stream);
+int odpl_spp_backward(const float* x, const int64_t* host_x_strides, int32_t B, int32_t C, int32_t H, int32_t W,
+                      const float* grad_y, const int64_t* host_y_strides, float* grad_x, void* stream);
+
 /* launch-geometry knobs (process-wide; defaults are the tuned values) */
 #define ODPL_TUNE_YOLO_FILL_F4_PER_BLOCK 0
 #define ODPL_TUNE_YOLO_FILL_NT 1

@@ -18,6 +18,7 @@ import torch.nn.functional as F
 from ..LightningFunc import step as _step
 from ..LightningFunc.accuracy import get_yolo_statistics as _get_yolo_statistics
 from ..LightningFunc.losses import configure_loss
+from ..LightningFunc.utils.spp import spp_cat
 
 try:                                    # PL is optional: the reference derives from pl.LightningModule
     import pytorch_lightning as pl
@@ -116,7 +117,10 @@ class PANNeck(nn.Module):
 
     def forward(self, d5, d4, d3):
         x3 = self._seq(d5, 1, 3)
-        spp = torch.cat([F.max_pool2d(x3, 13, 1, 6), F.max_pool2d(x3, 9, 1, 4), F.max_pool2d(x3, 5, 1, 2), x3], 1)
+        if x3.is_cuda and x3.dtype == torch.float32 and x3.shape[2] * x3.shape[3] <= 1024:
+            spp = spp_cat(x3)                      # fused HIP SPP (YoloV4Utils.py:412-418)
+        else:
+            spp = torch.cat([F.max_pool2d(x3, 13, 1, 6), F.max_pool2d(x3, 9, 1, 4), F.max_pool2d(x3, 5, 1, 2), x3], 1)
         x6 = self._seq(spp, 4, 6)
         up = F.interpolate(self.conv7(x6), size=d4.shape[2:], mode="nearest")
         x13 = self._seq(torch.cat([self.conv8(d4), up], 1), 9, 13)
