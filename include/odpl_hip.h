@@ -305,6 +305,23 @@ int odpl_spp_forward(const float* x, const int64_t* host_x_strides, int32_t B, i
 int odpl_spp_backward(const float* x, const int64_t* host_x_strides, int32_t B, int32_t C, int32_t H, int32_t W,
                       const float* grad_y, const int64_t* host_y_strides, float* grad_x, void* stream);
 
+/* ---- fused BatchNorm2d + activation on channels-last fp32: utils/YoloV4Utils.py:208-236 ---- */
+#define ODPL_ACT_LINEAR 0
+#define ODPL_ACT_MISH 1
+#define ODPL_ACT_LEAKY 2             /* LeakyReLU(0.1) */
+size_t odpl_bn_act_workspace_bytes(int64_t R, int32_t C);
+/* x, y: row-major [R = N*H*W, C] (a channels-last NCHW tensor), C % 4 == 0.  training != 0: batch statistics are
+ * computed, written to save_mean / save_invstd and folded into running_mean / running_var (momentum, unbiased var);
+ * training == 0: the caller pre-fills save_mean / save_invstd from the running statistics. */
+int odpl_bn_act_forward(const float* x, int64_t R, int32_t C, const float* gamma, const float* beta,
+                        float* running_mean, float* running_var, int32_t training, float momentum, float eps,
+                        int32_t act, float* save_mean, float* save_invstd, float* y, void* workspace,
+                        size_t workspace_bytes, void* stream);
+int odpl_bn_act_backward(const float* x, const float* grad_y, int64_t R, int32_t C, const float* gamma, const float* beta,
+                         const float* save_mean, const float* save_invstd, int32_t training, int32_t act,
+                         float* grad_x, float* grad_gamma, float* grad_beta, void* workspace, size_t workspace_bytes,
+                         void* stream);
+
 /* launch-geometry knobs (process-wide; defaults are the tuned values) */
 #define ODPL_TUNE_YOLO_FILL_F4_PER_BLOCK 0
 #define ODPL_TUNE_YOLO_FILL_NT 1

@@ -1,0 +1,78 @@
+"""Fused BatchNorm2d + activation epilogue of the reference's Conv_Bn_Activation unit
+(`utils/YoloV4Utils.py:208-236`) for channels-last fp32 activations: 2 passes forward, 2 backward."""
+import torch
+
+from ... import _lib
+
+ACT = {"linear": 0, "mish": 1, "leaky": 2}
+_ws = {}
+
+
+def _workspace(dev, need):
+    w = _ws.get(dev)
+    if w is None or w.numel() < need:
+        w = torch.empty(int(need * 1.5) + 4096, dtype=torch.uint8, device=dev)
+        _ws[dev] = w
+    return w
+
+
+def fusable(x, bn):
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] % 4 == 0 and bn.momentum is not None
+            and bn.affine and bn.track_running_stats and x.is_contiguous(memory_format=torch.channels_last))
+
+
+class _BnActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, act):
+        N, C, H, W = x.shape
+        R = N * H * W
+        dev = x.device
+        L = _lib.lib()
+        y = torch.empty_like(x)                                  # keeps the channels-last strides
+        if training:
+            mean = torch.empty(C, dtype=torch.float32, device=dev)
+            invstd = torch.empty(C, dtype=torch.float32, device=dev)
+        else:
+            mean = running_mean.clone()
+            invstd = torch.rsqrt(running_var + eps)
+        need = L.odpl_bn_act_workspace_bytes(R, C)
+        ws = _workspace(dev, need)
+        _lib.check(L.odpl_bn_act_forward(_lib.ptr(x), R, C, _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(running_mean), _lib.ptr(running_var),
+                                         1 if training else 0, float(momentum), float(eps), act, _lib.ptr(mean), _lib.ptr(invstd),
+                                         _lib.ptr(y), _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)), "odpl_bn_act_forward")
+        ctx.save_for_backward(x, weight, bias, mean, invstd)
+        ctx.training, ctx.act = training, act
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, bias, mean, invstd = ctx.saved_tensors
+        N, C, H, W = x.shape
+        R = N * H * W
+        dev = x.device
+        L = _lib.lib()
+        if not gy.is_contiguous(memory_format=torch.channels_last) or gy.dtype != torch.float32:
+            gy = gy.float().contiguous(memory_format=torch.channels_last)
+        gx = torch.empty_like(x)
+        dg = torch.empty(C, dtype=torch.float32, device=dev)
+        db = torch.empty(C, dtype=torch.float32, device=dev)
+        need = L.odpl_bn_act_workspace_bytes(R, C)
+        ws = _workspace(dev, need)
+        _lib.check(L.odpl_bn_act_backward(_lib.ptr(x), _lib.ptr(gy), R, C, _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(mean), _lib.ptr(invstd),
+                                          1 if ctx.training else 0, ctx.act, _lib.ptr(gx), _lib.ptr(dg), _lib.ptr(db), _lib.ptr(ws),
+                                          ws.numel(), _lib.current_stream(dev)), "odpl_bn_act_backward")
+        return gx, dg, db, None, None, None, None, None, None
+
+
+def bn_act(x, bn, act):
+    """act(bn(x)) for a channels-last fp32 tensor and an nn.BatchNorm2d module (its buffers are updated like
+    nn.BatchNorm2d does in training mode).  Uses the C++ binding when built (10x less host time per call)."""
+    ext = _lib.torch_ext()
+    if ext is not None:
+        y = ext.bn_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.training,
+                       bn.momentum, bn.eps, ACT[act])
+        if y is not None:
+            return y
+    if bn.training:
+        bn.num_batches_tracked.add_(1)
+    return _BnActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.momentum, bn.eps, ACT[act])

@@ -108,6 +108,11 @@ SIGNATURES = {
     "odpl_yolo_stats_reduce": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_void_p, c_void_p]),
     "odpl_spp_forward": (c_int32, [c_void_p, POINTER(ctypes.c_int64), c_int32, c_int32, c_int32, c_int32, c_void_p, POINTER(ctypes.c_int64), c_void_p]),
     "odpl_spp_backward": (c_int32, [c_void_p, POINTER(ctypes.c_int64), c_int32, c_int32, c_int32, c_int32, c_void_p, POINTER(ctypes.c_int64), c_void_p, c_void_p]),
+    "odpl_bn_act_workspace_bytes": (c_size_t, [ctypes.c_int64, c_int32]),
+    "odpl_bn_act_forward": (c_int32, [c_void_p, ctypes.c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_float, c_float,
+                                      c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "odpl_bn_act_backward": (c_int32, [c_void_p, c_void_p, ctypes.c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
+                                       c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "odpl_tune_set": (c_int32, [c_int32, c_int32]),
     "odpl_profile_enable": (c_int32, [c_int32, c_int32]),
     "odpl_profile_collect": (c_int32, [c_int32, POINTER(c_float), POINTER(c_float), c_int32]),
@@ -125,7 +130,7 @@ def lib():
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 f"or `make -C objectdetectionpl_amd/csrc` (hipcc --offload-arch=gfx950). "
                 f"objectdetectionpl_amd has no CPU fallback.")
-        l = ctypes.CDLL(LIB_PATH)
+        l = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)      # global: the torch binding resolves its symbols against it
         for name, (res, args) in SIGNATURES.items():
             try:
                 fn = getattr(l, name)
@@ -189,3 +194,25 @@ def profile_collect(name, max_n=4096):
         raise OdplError("odpl_profile_collect failed")
     n = min(n, max_n)
     return [buf[i] for i in range(n)], [raw[i] for i in range(n)]
+
+
+_torch_ext = None
+
+
+def torch_ext():
+    """The C++ torch binding (csrc/torch_ext/odpl_torch_ext.so) for the per-layer epilogue ops, or None if it has
+    not been built (callers then use the slower Python autograd path)."""
+    global _torch_ext
+    if _torch_ext is None:
+        import importlib.util
+        path = os.path.join(_HERE, "csrc", "torch_ext", "odpl_torch_ext.so")
+        if not os.path.exists(path):
+            _torch_ext = False
+        else:
+            lib()                                   # libodpl_hip.so first (RTLD_GLOBAL, soname libodpl_hip.so)
+            import torch  # noqa: F401
+            spec = importlib.util.spec_from_file_location("odpl_torch_ext", path)
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            _torch_ext = mod
+    return _torch_ext or None

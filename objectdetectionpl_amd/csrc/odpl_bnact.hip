@@ -1,0 +1,249 @@
+// Fused BatchNorm2d (training or eval) + activation (Mish / LeakyReLU(0.1) / identity) for channels-last fp32
+// tensors, forward and backward -- the conv epilogues of LightningFunc/utils/YoloV4Utils.py:208-236
+// (Conv_Bn_Activation), SURVEY 8f rank 4.  In the profiled YOLOv4 step MIOpen's BN kernels + ATen's Mish kernels
+// make ~5 passes over every conv output in forward and ~7 in backward; this file makes 2 + 2:
+//   stats     per row-tile per-channel (sum, sum of squares) in DOUBLE -> partials            [1 read]
+//   finalize  per channel: mean, biased var -> invstd, running-stat update (momentum, unbiased var)
+//   apply     y = act(gamma * (x - mean) * invstd + beta)                                    [1 read + 1 write]
+//   bwd_red   recompute z, gz = gy * act'(z); per-channel partials (sum gz, sum gz * xhat)   [2 reads]
+//   bwd_fin   dbeta, dgamma
+//   bwd_dx    gx = gamma * invstd * (gz - dbeta/R - xhat * dgamma/R)                         [2 reads + 1 write]
+// Layout: a channels-last [N,C,H,W] tensor is a row-major [R = N*H*W, C] matrix; lanes run along C with 16-B
+// accesses (C % 4 == 0), so every wave instruction is a coalesced 1-KiB segment.  HBM-bound.
+#include "odpl_common.hpp"
+#include "../../include/odpl_hip.h"
+
+namespace {
+using namespace odpl;
+constexpr int kT = 256;
+
+// Mish through ONE exponential: with n = e^z,  tanh(softplus(z)) = n(n+2) / (n(n+2) + 2)  and  sigmoid(z) = n / (1+n).
+// (ATen evaluates tanh(log1p(exp(z))): three transcendentals, which makes the epilogue VALU-bound instead of
+// HBM-bound.)  No cancellation: every term is positive; for z > 20 the ratio is 1 to fp32 precision.
+__device__ __forceinline__ float mish_t(float z, float& n) {
+    n = __expf(fminf(z, 20.0f));
+    const float p = n * (n + 2.0f);
+    return __fdividef(p, p + 2.0f);
+}
+__device__ __forceinline__ float act_fwd(float z, int act) {
+    if (act == ODPL_ACT_MISH) { float n; return z * mish_t(z, n); }            // x * tanh(softplus(x))
+    if (act == ODPL_ACT_LEAKY) return z > 0.f ? z : 0.1f * z;
+    return z;
+}
+__device__ __forceinline__ float act_grad(float z, int act) {
+    if (act == ODPL_ACT_MISH) {                                                 // ts + z * sigmoid(z) * (1 - ts^2)  (ATen mish_backward)
+        float n;
+        const float ts = mish_t(z, n);
+        const float sg = z > 20.0f ? 1.0f : __fdividef(n, 1.0f + n);
+        return ts + z * sg * (1.0f - ts * ts);
+    }
+    if (act == ODPL_ACT_LEAKY) return z > 0.f ? 1.0f : 0.1f;
+    return 1.0f;
+}
+
+struct BnParams {
+    const float* x; const float* gy; float* y; float* gx;
+    const float* gamma; const float* beta;
+    float* mean; float* invstd;                  // [C] batch statistics (saved for backward)
+    float* running_mean; float* running_var;     // [C] or null
+    double* part;                                // [nblk][C][2]
+    float* dgamma; float* dbeta;                 // [C]
+    long long R; int C, act, nblk, rows_per_blk, training;
+    float eps, momentum;
+};
+
+// one pass over a row tile: per-channel sums of (a, b) where (a, b) = f(row, channel-quad)
+template <bool BWD>
+__global__ __launch_bounds__(kT) void bn_reduce_kernel(const BnParams P) {
+    extern __shared__ double s_red[];                       // [rows_par][C][2] staged for the cross-row combine
+    const int C = P.C, c4n = C >> 2;                        // channel quads
+    const int tpr = c4n < kT ? c4n : kT;                    // threads per row
+    const int rows_par = kT / tpr;                          // rows handled in parallel by the workgroup
+    const int tr = threadIdx.x / tpr, tc = threadIdx.x - tr * tpr;
+    const long long r0 = (long long)blockIdx.x * P.rows_per_blk;
+    long long r1 = r0 + P.rows_per_blk; if (r1 > P.R) r1 = P.R;
+    for (int q0 = 0; q0 < c4n; q0 += tpr) {                 // C > 1024: several channel passes
+        const int q = q0 + tc;
+        double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+        if (q < c4n && tr < rows_par) {
+            float4 mu, is, ga, be;
+            if (BWD) {
+                mu = reinterpret_cast<const float4*>(P.mean)[q]; is = reinterpret_cast<const float4*>(P.invstd)[q];
+                ga = reinterpret_cast<const float4*>(P.gamma)[q]; be = reinterpret_cast<const float4*>(P.beta)[q];
+            }
+            for (long long r = r0 + tr; r < r1; r += rows_par) {
+                const float4 v = reinterpret_cast<const float4*>(P.x)[r * c4n + q];
+                if (!BWD) {
+                    a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w;
+                    b[0] += (double)v.x * v.x; b[1] += (double)v.y * v.y; b[2] += (double)v.z * v.z; b[3] += (double)v.w * v.w;
+                } else {
+                    const float4 g = reinterpret_cast<const float4*>(P.gy)[r * c4n + q];
+                    const float xh0 = (v.x - mu.x) * is.x, xh1 = (v.y - mu.y) * is.y, xh2 = (v.z - mu.z) * is.z, xh3 = (v.w - mu.w) * is.w;
+                    const float g0 = g.x * act_grad(ga.x * xh0 + be.x, P.act), g1 = g.y * act_grad(ga.y * xh1 + be.y, P.act);
+                    const float g2 = g.z * act_grad(ga.z * xh2 + be.z, P.act), g3 = g.w * act_grad(ga.w * xh3 + be.w, P.act);
+                    a[0] += g0; a[1] += g1; a[2] += g2; a[3] += g3;
+                    b[0] += (double)g0 * xh0; b[1] += (double)g1 * xh1; b[2] += (double)g2 * xh2; b[3] += (double)g3 * xh3;
+                }
+            }
+        }
+        // combine the rows_par row-lanes through LDS (fixed order), write the workgroup partial
+        __syncthreads();
+        if (q < c4n && tr < rows_par) {
+            double* d = s_red + ((size_t)tr * tpr + tc) * 8;
+            for (int i = 0; i < 4; ++i) { d[i] = a[i]; d[4 + i] = b[i]; }
+        }
+        __syncthreads();
+        if (tr == 0 && q < c4n) {
+            double sa[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
+            for (int t = 0; t < rows_par; ++t) {
+                const double* d = s_red + ((size_t)t * tpr + tc) * 8;
+                for (int i = 0; i < 4; ++i) { sa[i] += d[i]; sb[i] += d[4 + i]; }
+            }
+            double* o = P.part + ((size_t)blockIdx.x * C + 4 * q) * 2;
+            for (int i = 0; i < 4; ++i) { o[2 * i] = sa[i]; o[2 * i + 1] = sb[i]; }
+        }
+    }
+}
+
+// one workgroup per channel: lanes stride over the row-tile partials, fixed shuffle tree + fixed wave order
+__device__ __forceinline__ void channel_sums(const BnParams& P, int c, double& s, double& ss) {
+    __shared__ double sh[2 * (kT / 64)];
+    s = 0; ss = 0;
+    for (int b = threadIdx.x; b < P.nblk; b += kT) { const double* p = P.part + ((size_t)b * P.C + c) * 2; s += p[0]; ss += p[1]; }
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_down(s, o, 64); ss += __shfl_down(ss, o, 64); }
+    if ((threadIdx.x & 63) == 0) { sh[(threadIdx.x >> 6) * 2] = s; sh[(threadIdx.x >> 6) * 2 + 1] = ss; }
+    __syncthreads();
+    s = 0; ss = 0;
+    for (int w = 0; w < kT / 64; ++w) { s += sh[w * 2]; ss += sh[w * 2 + 1]; }
+}
+
+__global__ __launch_bounds__(kT) void bn_stats_finalize_kernel(const BnParams P) {
+    const int c = blockIdx.x;
+    double s, ss;
+    channel_sums(P, c, s, ss);
+    if (threadIdx.x != 0) return;
+    const double n = (double)P.R, mean = s / n;
+    double var = ss / n - mean * mean; if (var < 0) var = 0;              // biased (normalisation)
+    P.mean[c] = (float)mean;
+    P.invstd[c] = (float)(1.0 / sqrt(var + (double)P.eps));
+    if (P.running_mean) {                                                 // nn.BatchNorm2d: unbiased var into the running buffer
+        const double unb = n > 1 ? var * n / (n - 1) : var;
+        P.running_mean[c] = (float)((1.0 - P.momentum) * P.running_mean[c] + P.momentum * mean);
+        P.running_var[c] = (float)((1.0 - P.momentum) * P.running_var[c] + P.momentum * unb);
+    }
+}
+
+__global__ __launch_bounds__(kT) void bn_bwd_finalize_kernel(const BnParams P) {
+    const int c = blockIdx.x;
+    double s, ss;
+    channel_sums(P, c, s, ss);
+    if (threadIdx.x != 0) return;
+    P.dbeta[c] = (float)s;
+    P.dgamma[c] = (float)ss;
+}
+
+__global__ __launch_bounds__(kT) void bn_apply_kernel(const BnParams P) {
+    const int c4n = P.C >> 2;
+    const long long n4 = P.R * c4n, stride = (long long)gridDim.x * kT;
+    const unsigned sq = (unsigned)(stride % c4n);            // the channel quad advances by a constant per iteration
+    long long i = (long long)blockIdx.x * kT + threadIdx.x;
+    unsigned q = (unsigned)(i % c4n);
+    for (; i < n4; i += stride, q = (q + sq >= (unsigned)c4n) ? q + sq - c4n : q + sq) {
+        const float4 v = reinterpret_cast<const float4*>(P.x)[i];
+        const float4 mu = reinterpret_cast<const float4*>(P.mean)[q], is = reinterpret_cast<const float4*>(P.invstd)[q];
+        const float4 ga = reinterpret_cast<const float4*>(P.gamma)[q], be = reinterpret_cast<const float4*>(P.beta)[q];
+        float4 o;
+        o.x = act_fwd(ga.x * ((v.x - mu.x) * is.x) + be.x, P.act); o.y = act_fwd(ga.y * ((v.y - mu.y) * is.y) + be.y, P.act);
+        o.z = act_fwd(ga.z * ((v.z - mu.z) * is.z) + be.z, P.act); o.w = act_fwd(ga.w * ((v.w - mu.w) * is.w) + be.w, P.act);
+        reinterpret_cast<float4*>(P.y)[i] = o;
+    }
+}
+
+__global__ __launch_bounds__(kT) void bn_bwd_dx_kernel(const BnParams P) {
+    const int c4n = P.C >> 2;
+    const long long n4 = P.R * c4n, stride = (long long)gridDim.x * kT;
+    const float invR = P.training ? (float)(1.0 / (double)P.R) : 0.0f;     // eval mode: statistics are constants
+    const unsigned sq = (unsigned)(stride % c4n);
+    long long i = (long long)blockIdx.x * kT + threadIdx.x;
+    unsigned q = (unsigned)(i % c4n);
+    for (; i < n4; i += stride, q = (q + sq >= (unsigned)c4n) ? q + sq - c4n : q + sq) {
+        const float4 v = reinterpret_cast<const float4*>(P.x)[i], g = reinterpret_cast<const float4*>(P.gy)[i];
+        const float4 mu = reinterpret_cast<const float4*>(P.mean)[q], is = reinterpret_cast<const float4*>(P.invstd)[q];
+        const float4 ga = reinterpret_cast<const float4*>(P.gamma)[q], be = reinterpret_cast<const float4*>(P.beta)[q];
+        const float4 db = reinterpret_cast<const float4*>(P.dbeta)[q], dg = reinterpret_cast<const float4*>(P.dgamma)[q];
+        float4 o;
+#define ODPL_DX(f) { const float xh = (v.f - mu.f) * is.f; const float gz = g.f * act_grad(ga.f * xh + be.f, P.act); \
+                     o.f = ga.f * is.f * (gz - db.f * invR - xh * dg.f * invR); }
+        ODPL_DX(x) ODPL_DX(y) ODPL_DX(z) ODPL_DX(w)
+#undef ODPL_DX
+        reinterpret_cast<float4*>(P.gx)[i] = o;
+    }
+}
+
+bool plan(long long R, int C, int* rows_per_blk, int* nblk, size_t* lds) {
+    if (R < 1 || C < 4 || (C & 3)) return false;
+    long long rpb = R / 1024; if (rpb < 16) rpb = 16; if (rpb > 512) rpb = 512;
+    *rows_per_blk = (int)rpb;
+    *nblk = (int)((R + rpb - 1) / rpb);
+    const int c4n = C >> 2, tpr = c4n < kT ? c4n : kT, rows_par = kT / tpr;
+    *lds = (size_t)rows_par * tpr * 8 * sizeof(double);
+    return true;
+}
+}  // namespace
+
+extern "C" size_t odpl_bn_act_workspace_bytes(int64_t R, int32_t C) {
+    int rpb, nblk; size_t lds;
+    if (!plan(R, C, &rpb, &nblk, &lds)) return 0;
+    return (size_t)nblk * C * 2 * sizeof(double) + 256;
+}
+
+extern "C" int odpl_bn_act_forward(const float* x, int64_t R, int32_t C, const float* gamma, const float* beta,
+                                   float* running_mean, float* running_var, int32_t training, float momentum, float eps,
+                                   int32_t act, float* save_mean, float* save_invstd, float* y, void* workspace,
+                                   size_t workspace_bytes, void* stream_) {
+    int rpb, nblk; size_t lds;
+    if (!x || !y || !gamma || !beta || !save_mean || !save_invstd || !plan(R, C, &rpb, &nblk, &lds)) return ODPL_EINVAL;
+    if (act < 0 || act > 2 || (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)save_mean | (uintptr_t)save_invstd) & 15)) return ODPL_EINVAL;
+    hipStream_t stream = (hipStream_t)stream_;
+    BnParams P = {};
+    P.x = x; P.y = y; P.gamma = gamma; P.beta = beta; P.mean = save_mean; P.invstd = save_invstd;
+    P.running_mean = running_mean; P.running_var = running_var; P.R = R; P.C = C; P.act = act; P.nblk = nblk;
+    P.rows_per_blk = rpb; P.training = training; P.eps = eps; P.momentum = momentum; P.part = (double*)workspace;
+    if (training) {
+        if (!workspace || workspace_bytes < odpl_bn_act_workspace_bytes(R, C) || ((uintptr_t)workspace & 15)) return ODPL_EINVAL;
+        hipLaunchKernelGGL(bn_reduce_kernel<false>, dim3(nblk), dim3(kT), lds, stream, P);
+        ODPL_HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), dim3(kT), 0, stream, P);
+        ODPL_HIP_TRY(hipGetLastError());
+    }   // eval: the caller filled save_mean / save_invstd from the running statistics
+    const long long n4 = R * (C >> 2);
+    long long blocks = (n4 + kT - 1) / kT; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)blocks), dim3(kT), 0, stream, P);
+    ODPL_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int odpl_bn_act_backward(const float* x, const float* grad_y, int64_t R, int32_t C, const float* gamma, const float* beta,
+                                    const float* save_mean, const float* save_invstd, int32_t training, int32_t act,
+                                    float* grad_x, float* grad_gamma, float* grad_beta, void* workspace, size_t workspace_bytes,
+                                    void* stream_) {
+    int rpb, nblk; size_t lds;
+    if (!x || !grad_y || !grad_x || !gamma || !beta || !save_mean || !save_invstd || !grad_gamma || !grad_beta || !plan(R, C, &rpb, &nblk, &lds))
+        return ODPL_EINVAL;
+    if (!workspace || workspace_bytes < odpl_bn_act_workspace_bytes(R, C) || act < 0 || act > 2) return ODPL_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)grad_y | (uintptr_t)grad_x | (uintptr_t)grad_gamma | (uintptr_t)grad_beta | (uintptr_t)workspace) & 15) return ODPL_EINVAL;
+    hipStream_t stream = (hipStream_t)stream_;
+    BnParams P = {};
+    P.x = x; P.gy = grad_y; P.gx = grad_x; P.gamma = gamma; P.beta = beta; P.mean = (float*)save_mean; P.invstd = (float*)save_invstd;
+    P.R = R; P.C = C; P.act = act; P.nblk = nblk; P.rows_per_blk = rpb; P.training = training; P.part = (double*)workspace;
+    P.dgamma = grad_gamma; P.dbeta = grad_beta;
+    hipLaunchKernelGGL(bn_reduce_kernel<true>, dim3(nblk), dim3(kT), lds, stream, P);
+    ODPL_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(kT), 0, stream, P);
+    ODPL_HIP_TRY(hipGetLastError());
+    const long long n4 = R * (C >> 2);
+    long long blocks = (n4 + kT - 1) / kT; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(bn_bwd_dx_kernel, dim3((unsigned)blocks), dim3(kT), 0, stream, P);
+    ODPL_HIP_TRY(hipGetLastError());
+    return 0;
+}

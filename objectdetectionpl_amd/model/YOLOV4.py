@@ -18,6 +18,7 @@ import torch.nn.functional as F
 from ..LightningFunc import step as _step
 from ..LightningFunc.accuracy import get_yolo_statistics as _get_yolo_statistics
 from ..LightningFunc.losses import configure_loss
+from ..LightningFunc.utils import bnact as _bnact
 from ..LightningFunc.utils.spp import spp_cat
 
 try:                                    # PL is optional: the reference derives from pl.LightningModule
@@ -42,11 +43,22 @@ class ConvUnit(nn.Module):
         elif act != "linear":
             raise ValueError(act)
         self.conv = nn.ModuleList(layers)
+        self._act = act if bn else None
 
     def forward(self, x):
-        for l in self.conv:
+        if self._act is not None and ConvUnit.fuse_epilogue:
+            z = self.conv[0](x)
+            if _bnact.fusable(z, self.conv[1]):
+                return _bnact.bn_act(z, self.conv[1], self._act)     # fused BN + activation (HIP, channels-last)
+            x = z
+            rest = list(self.conv)[1:]
+        else:
+            rest = self.conv
+        for l in rest:
             x = l(x)
         return x
+
+    fuse_epilogue = True          # class switch: False = plain nn.BatchNorm2d + nn.Mish / nn.LeakyReLU
 
 
 class ResChain(nn.Module):
