@@ -316,7 +316,7 @@ size_t odpl_bn_act_workspace_bytes(int64_t R, int32_t C);
 int odpl_bn_act_forward(const float* x, int64_t R, int32_t C, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, int32_t training, float momentum, float eps,
                         int32_t act, float* save_mean, float* save_invstd, float* y, void* workspace,
-                        size_t workspace_bytes, void* stream);
+                        size_t workspace_bytes, int64_t* num_batches_tracked /* device int64[1] or NULL: += 1 */, void* stream);
 int odpl_bn_act_backward(const float* x, const float* grad_y, int64_t R, int32_t C, const float* gamma, const float* beta,
                          const float* save_mean, const float* save_invstd, int32_t training, int32_t act,
                          float* grad_x, float* grad_gamma, float* grad_beta, void* workspace, size_t workspace_bytes,

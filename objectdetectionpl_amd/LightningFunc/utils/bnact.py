@@ -23,7 +23,7 @@ def fusable(x, bn):
 
 class _BnActFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, act):
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, act, nbt=None):
         N, C, H, W = x.shape
         R = N * H * W
         dev = x.device
@@ -39,7 +39,8 @@ class _BnActFn(torch.autograd.Function):
         ws = _workspace(dev, need)
         _lib.check(L.odpl_bn_act_forward(_lib.ptr(x), R, C, _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(running_mean), _lib.ptr(running_var),
                                          1 if training else 0, float(momentum), float(eps), act, _lib.ptr(mean), _lib.ptr(invstd),
-                                         _lib.ptr(y), _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)), "odpl_bn_act_forward")
+                                         _lib.ptr(y), _lib.ptr(ws), ws.numel(), _lib.ptr(nbt) if training else None,
+                                         _lib.current_stream(dev)), "odpl_bn_act_forward")
         ctx.save_for_backward(x, weight, bias, mean, invstd)
         ctx.training, ctx.act = training, act
         return y
@@ -61,7 +62,7 @@ class _BnActFn(torch.autograd.Function):
         _lib.check(L.odpl_bn_act_backward(_lib.ptr(x), _lib.ptr(gy), R, C, _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(mean), _lib.ptr(invstd),
                                           1 if ctx.training else 0, ctx.act, _lib.ptr(gx), _lib.ptr(dg), _lib.ptr(db), _lib.ptr(ws),
                                           ws.numel(), _lib.current_stream(dev)), "odpl_bn_act_backward")
-        return gx, dg, db, None, None, None, None, None, None
+        return gx, dg, db, None, None, None, None, None, None, None
 
 
 def bn_act(x, bn, act):
@@ -73,6 +74,5 @@ def bn_act(x, bn, act):
                        bn.momentum, bn.eps, ACT[act])
         if y is not None:
             return y
-    if bn.training:
-        bn.num_batches_tracked.add_(1)
-    return _BnActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.momentum, bn.eps, ACT[act])
+    return _BnActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.momentum, bn.eps, ACT[act],
+                          bn.num_batches_tracked)

@@ -110,7 +110,7 @@ SIGNATURES = {
     "odpl_spp_backward": (c_int32, [c_void_p, POINTER(ctypes.c_int64), c_int32, c_int32, c_int32, c_int32, c_void_p, POINTER(ctypes.c_int64), c_void_p, c_void_p]),
     "odpl_bn_act_workspace_bytes": (c_size_t, [ctypes.c_int64, c_int32]),
     "odpl_bn_act_forward": (c_int32, [c_void_p, ctypes.c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_float, c_float,
-                                      c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                      c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "odpl_bn_act_backward": (c_int32, [c_void_p, c_void_p, ctypes.c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "odpl_tune_set": (c_int32, [c_int32, c_int32]),

@@ -48,6 +48,7 @@ struct BnParams {
     float* running_mean; float* running_var;     // [C] or null
     double* part;                                // [nblk][C][2]
     float* dgamma; float* dbeta;                 // [C]
+    long long* num_batches_tracked;              // nn.BatchNorm2d buffer, +1 per training forward (or null)
     long long R; int C, act, nblk, rows_per_blk, training;
     float eps, momentum;
 };
@@ -126,6 +127,7 @@ __global__ __launch_bounds__(kT) void bn_stats_finalize_kernel(const BnParams P)
     double var = ss / n - mean * mean; if (var < 0) var = 0;              // biased (normalisation)
     P.mean[c] = (float)mean;
     P.invstd[c] = (float)(1.0 / sqrt(var + (double)P.eps));
+    if (c == 0 && P.num_batches_tracked) P.num_batches_tracked[0] += 1;
     if (P.running_mean) {                                                 // nn.BatchNorm2d: unbiased var into the running buffer
         const double unb = n > 1 ? var * n / (n - 1) : var;
         P.running_mean[c] = (float)((1.0 - P.momentum) * P.running_mean[c] + P.momentum * mean);
@@ -200,7 +202,7 @@ extern "C" size_t odpl_bn_act_workspace_bytes(int64_t R, int32_t C) {
 extern "C" int odpl_bn_act_forward(const float* x, int64_t R, int32_t C, const float* gamma, const float* beta,
                                    float* running_mean, float* running_var, int32_t training, float momentum, float eps,
                                    int32_t act, float* save_mean, float* save_invstd, float* y, void* workspace,
-                                   size_t workspace_bytes, void* stream_) {
+                                   size_t workspace_bytes, int64_t* num_batches_tracked, void* stream_) {
     int rpb, nblk; size_t lds;
     if (!x || !y || !gamma || !beta || !save_mean || !save_invstd || !plan(R, C, &rpb, &nblk, &lds)) return ODPL_EINVAL;
     if (act < 0 || act > 2 || (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)save_mean | (uintptr_t)save_invstd) & 15)) return ODPL_EINVAL;
@@ -209,6 +211,7 @@ extern "C" int odpl_bn_act_forward(const float* x, int64_t R, int32_t C, const f
     P.x = x; P.y = y; P.gamma = gamma; P.beta = beta; P.mean = save_mean; P.invstd = save_invstd;
     P.running_mean = running_mean; P.running_var = running_var; P.R = R; P.C = C; P.act = act; P.nblk = nblk;
     P.rows_per_blk = rpb; P.training = training; P.eps = eps; P.momentum = momentum; P.part = (double*)workspace;
+    P.num_batches_tracked = (long long*)num_batches_tracked;
     if (training) {
         if (!workspace || workspace_bytes < odpl_bn_act_workspace_bytes(R, C) || ((uintptr_t)workspace & 15)) return ODPL_EINVAL;
         hipLaunchKernelGGL(bn_reduce_kernel<false>, dim3(nblk), dim3(kT), lds, stream, P);

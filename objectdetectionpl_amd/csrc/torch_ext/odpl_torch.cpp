@@ -20,7 +20,7 @@ bool fusable(const Tensor& x, const Tensor& w) {
 
 struct BnActFn : public torch::autograd::Function<BnActFn> {
     static Tensor forward(AutogradContext* ctx, Tensor x, Tensor weight, Tensor bias, Tensor running_mean, Tensor running_var,
-                          bool training, double momentum, double eps, int64_t act) {
+                          Tensor nbt, bool training, double momentum, double eps, int64_t act) {
         const int64_t C = x.size(1), R = x.numel() / C;
         auto y = at::empty_like(x);
         Tensor mean, invstd;
@@ -37,7 +37,8 @@ struct BnActFn : public torch::autograd::Function<BnActFn> {
         check(odpl_bn_act_forward(x.data_ptr<float>(), R, (int32_t)C, weight.data_ptr<float>(), bias.data_ptr<float>(),
                                   running_mean.data_ptr<float>(), running_var.data_ptr<float>(), training ? 1 : 0, (float)momentum,
                                   (float)eps, (int32_t)act, mean.data_ptr<float>(), invstd.data_ptr<float>(), y.data_ptr<float>(),
-                                  ws.data_ptr(), need, stream), "odpl_bn_act_forward");
+                                  ws.data_ptr(), need, (training && nbt.defined()) ? nbt.data_ptr<int64_t>() : nullptr, stream),
+              "odpl_bn_act_forward");
         ctx->save_for_backward({x, weight, bias, mean, invstd});
         ctx->saved_data["training"] = training;
         ctx->saved_data["act"] = act;
@@ -62,7 +63,7 @@ struct BnActFn : public torch::autograd::Function<BnActFn> {
         check(odpl_bn_act_backward(x.data_ptr<float>(), gy.data_ptr<float>(), R, (int32_t)C, weight.data_ptr<float>(), bias.data_ptr<float>(),
                                    mean.data_ptr<float>(), invstd.data_ptr<float>(), training ? 1 : 0, (int32_t)act, gx.data_ptr<float>(),
                                    dg.data_ptr<float>(), db.data_ptr<float>(), ws.data_ptr(), need, stream), "odpl_bn_act_backward");
-        return {gx, dg, db, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+        return {gx, dg, db, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
     }
 };
 
@@ -70,8 +71,7 @@ struct BnActFn : public torch::autograd::Function<BnActFn> {
 Tensor bn_act(Tensor x, Tensor weight, Tensor bias, Tensor running_mean, Tensor running_var, Tensor num_batches_tracked,
               bool training, double momentum, double eps, int64_t act) {
     if (!fusable(x, weight)) return Tensor();
-    if (training && num_batches_tracked.defined()) num_batches_tracked.add_(1);
-    return BnActFn::apply(x, weight, bias, running_mean, running_var, training, momentum, eps, act);
+    return BnActFn::apply(x, weight, bias, running_mean, running_var, num_batches_tracked, training, momentum, eps, act);
 }
 }  // namespace
 
