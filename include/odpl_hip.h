@@ -309,6 +309,7 @@ int odpl_spp_backward(const float* x, const int64_t* host_x_strides, int32_t B, 
 #define ODPL_ACT_LINEAR 0
 #define ODPL_ACT_MISH 1
 #define ODPL_ACT_LEAKY 2             /* LeakyReLU(0.1) */
+#define ODPL_ACT_RELU 3
 size_t odpl_bn_act_workspace_bytes(int64_t R, int32_t C);
 /* x, y: row-major [R = N*H*W, C] (a channels-last NCHW tensor), C % 4 == 0.  training != 0: batch statistics are
  * computed, written to save_mean / save_invstd and folded into running_mean / running_var (momentum, unbiased var);

@@ -54,7 +54,8 @@ def _scalars(self):
 def training_step(self, batch, batch_idx):
     """step.py:14-25."""
     x, y = batch
-    result_dict = self.criterion(self.forward(x), y)
+    out = self.forward(x)
+    result_dict = self.criterion(out, y)
     step = getattr(self, "global_step", batch_idx)
     for key, val in result_dict.items():
         _scalars(self).add("Loss/%s" % ("total" if key == "loss" else key), "Train", val, step)
@@ -77,7 +78,8 @@ def validation_step(self, batch, batch_idx):
     """step.py:43-50."""
     x, y = batch
     with torch.no_grad():
-        result_dict = self.criterion(self.forward(x), y)
+        out = self.forward(x)
+        result_dict = self.criterion(out, y)
     if hasattr(self, "log_dict"):
         try:
             self.log_dict({"val_loss": result_dict["loss"]}, logger=True, on_epoch=True)

@@ -4,7 +4,7 @@ import torch
 
 from ... import _lib
 
-ACT = {"linear": 0, "mish": 1, "leaky": 2}
+ACT = {"linear": 0, "mish": 1, "leaky": 2, "relu": 3}
 _ws = {}
 
 

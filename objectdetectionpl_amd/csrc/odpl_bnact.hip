@@ -28,6 +28,7 @@ __device__ __forceinline__ float mish_t(float z, float& n) {
 __device__ __forceinline__ float act_fwd(float z, int act) {
     if (act == ODPL_ACT_MISH) { float n; return z * mish_t(z, n); }            // x * tanh(softplus(x))
     if (act == ODPL_ACT_LEAKY) return z > 0.f ? z : 0.1f * z;
+    if (act == ODPL_ACT_RELU) return z > 0.f ? z : 0.f;
     return z;
 }
 __device__ __forceinline__ float act_grad(float z, int act) {
@@ -38,6 +39,7 @@ __device__ __forceinline__ float act_grad(float z, int act) {
         return ts + z * sg * (1.0f - ts * ts);
     }
     if (act == ODPL_ACT_LEAKY) return z > 0.f ? 1.0f : 0.1f;
+    if (act == ODPL_ACT_RELU) return z > 0.f ? 1.0f : 0.f;
     return 1.0f;
 }
 
@@ -205,7 +207,7 @@ extern "C" int odpl_bn_act_forward(const float* x, int64_t R, int32_t C, const f
                                    size_t workspace_bytes, int64_t* num_batches_tracked, void* stream_) {
     int rpb, nblk; size_t lds;
     if (!x || !y || !gamma || !beta || !save_mean || !save_invstd || !plan(R, C, &rpb, &nblk, &lds)) return ODPL_EINVAL;
-    if (act < 0 || act > 2 || (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)save_mean | (uintptr_t)save_invstd) & 15)) return ODPL_EINVAL;
+    if (act < 0 || act > 3 || (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)save_mean | (uintptr_t)save_invstd) & 15)) return ODPL_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
     BnParams P = {};
     P.x = x; P.y = y; P.gamma = gamma; P.beta = beta; P.mean = save_mean; P.invstd = save_invstd;
@@ -233,7 +235,7 @@ extern "C" int odpl_bn_act_backward(const float* x, const float* grad_y, int64_t
     int rpb, nblk; size_t lds;
     if (!x || !grad_y || !grad_x || !gamma || !beta || !save_mean || !save_invstd || !grad_gamma || !grad_beta || !plan(R, C, &rpb, &nblk, &lds))
         return ODPL_EINVAL;
-    if (!workspace || workspace_bytes < odpl_bn_act_workspace_bytes(R, C) || act < 0 || act > 2) return ODPL_EINVAL;
+    if (!workspace || workspace_bytes < odpl_bn_act_workspace_bytes(R, C) || act < 0 || act > 3) return ODPL_EINVAL;
     if (((uintptr_t)x | (uintptr_t)grad_y | (uintptr_t)grad_x | (uintptr_t)grad_gamma | (uintptr_t)grad_beta | (uintptr_t)workspace) & 15) return ODPL_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
     BnParams P = {};

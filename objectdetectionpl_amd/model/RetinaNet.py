@@ -1,0 +1,154 @@
+"""RetinaNet (ResNet-50 FPN + two 4-conv heads) as the CALLER of the hot path; mirrors `model/RetinaNet.py:44-178`
+and `model/backbone/RetinaNetbone.py`: class name, ctor `(classes, args)`, `forward(x) -> (loc_preds [B,An,4],
+cls_preds [B,An,C])`, `.iou_boxes`, `.criterion`, `.non_max_suppression`, identical `state_dict` keys.
+Convolutions are plain `nn.Conv2d` (MIOpen); BN+ReLU epilogues use the fused HIP kernels on channels-last inputs."""
+import os
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..LightningFunc import step as _step
+from ..LightningFunc.losses import configure_loss
+from ..LightningFunc.nms import greedy_non_max_suppression
+from ..LightningFunc.utils import bnact as _bnact
+from ..LightningFunc.utils.RetinaUtils import get_anchor_boxes
+
+try:
+    import pytorch_lightning as pl
+    _Base = pl.LightningModule
+except Exception:  # noqa: BLE001
+    _Base = nn.Module
+
+
+def _bn(x, bn, act):
+    if _bnact.fusable(x, bn):
+        return _bnact.bn_act(x, bn, act)
+    y = bn(x)
+    return F.relu(y) if act == "relu" else y
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, in_planes, planes, stride=1):
+        super().__init__()
+        out = self.expansion * planes
+        self.conv1 = nn.Conv2d(in_planes, planes, 1, bias=False); self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False); self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, out, 1, bias=False); self.bn3 = nn.BatchNorm2d(out)
+        self.downsample = nn.Sequential()
+        if stride != 1 or in_planes != out:
+            self.downsample = nn.Sequential(nn.Conv2d(in_planes, out, 1, stride, bias=False), nn.BatchNorm2d(out))
+
+    def forward(self, x):
+        y = _bn(self.conv1(x), self.bn1, "relu")
+        y = _bn(self.conv2(y), self.bn2, "relu")
+        y = _bn(self.conv3(y), self.bn3, "linear")
+        s = _bn(self.downsample[0](x), self.downsample[1], "linear") if len(self.downsample) else x
+        return F.relu(y + s)
+
+
+class FPN(nn.Module):
+    def __init__(self, block, num_blocks):
+        super().__init__()
+        self.in_planes = 64
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        for i, (planes, stride) in enumerate(((64, 1), (128, 2), (256, 2), (512, 2)), 1):
+            setattr(self, f"layer{i}", self._stage(block, planes, num_blocks[i - 1], stride))
+        self.conv6 = nn.Conv2d(2048, 256, 3, 2, 1)
+        self.conv7 = nn.Conv2d(256, 256, 3, 2, 1)
+        self.latlayer1 = nn.Conv2d(2048, 256, 1)
+        self.latlayer2 = nn.Conv2d(1024, 256, 1)
+        self.latlayer3 = nn.Conv2d(512, 256, 1)
+        self.toplayer1 = nn.Conv2d(256, 256, 3, 1, 1)
+        self.toplayer2 = nn.Conv2d(256, 256, 3, 1, 1)
+
+    def _stage(self, block, planes, n, stride):
+        layers = []
+        for s in [stride] + [1] * (n - 1):
+            layers.append(block(self.in_planes, planes, s))
+            self.in_planes = planes * block.expansion
+        return nn.Sequential(*layers)
+
+    @staticmethod
+    def _up_add(x, y):
+        return F.interpolate(x, size=y.shape[2:], mode="bilinear", align_corners=False) + y     # F.upsample(bilinear), :57
+
+    def forward(self, x):
+        c1 = F.max_pool2d(_bn(self.conv1(x), self.bn1, "relu"), 3, 2, 1)
+        c2 = self.layer1(c1); c3 = self.layer2(c2); c4 = self.layer3(c3); c5 = self.layer4(c4)
+        p6 = self.conv6(c5)
+        p7 = self.conv7(F.relu(p6))
+        p5 = self.latlayer1(c5)
+        p4 = self.toplayer1(self._up_add(p5, self.latlayer2(c4)))
+        p3 = self.toplayer2(self._up_add(p4, self.latlayer3(c3)))
+        return p3, p4, p5, p6, p7
+
+
+class RetinaNet(_Base):
+    num_anchors = 9
+    img_size = 600
+
+    def __init__(self, classes, args, device=None):
+        super().__init__()
+        self.classes = classes
+        self.num_classes = len(classes)
+        self.args = args
+        self.backbone = "RetinaNet"
+        self.fpn = FPN(Bottleneck, [3, 4, 6, 3])
+        self.loc_head = self._make_head(self.num_anchors * 4)
+        self.cls_head = self._make_head(self.num_anchors * self.num_classes)
+        self.sample = (1, 3, self.img_size, self.img_size)
+        self._anchor_device = device
+        self.iou_boxes = None
+        self.criterion = None
+        self.checkname = self.backbone
+        self.dir = os.path.join("log_dir", getattr(args, "data_module", "synthetic"), self.checkname)
+        if device is not None:
+            self._build_anchors(torch.device(device))
+
+    def _build_anchors(self, dev):
+        """RetinaNet.py:57-59: the anchor table for (img_size, img_size), built on the device."""
+        self.iou_boxes = get_anchor_boxes(torch.Tensor([self.img_size, self.img_size]), dev)
+        self.criterion = configure_loss(self.args, self.iou_boxes, None, None, self.num_classes, self.img_size)
+
+    def _apply(self, fn, *a, **k):
+        super()._apply(fn, *a, **k)
+        p = next(self.parameters())
+        if p.is_cuda and (self.iou_boxes is None or self.iou_boxes.device != p.device):
+            self._build_anchors(p.device)        # the reference builds them in the ctor with .cuda() (RetinaNet.py:57-59)
+        return self
+
+    @staticmethod
+    def _make_head(out_planes):
+        layers = []
+        for _ in range(4):
+            layers += [nn.Conv2d(256, 256, 3, 1, 1), nn.ReLU(True)]
+        layers.append(nn.Conv2d(256, out_planes, 3, 1, 1))
+        return nn.Sequential(*layers)
+
+    def forward(self, x):
+        if self.iou_boxes is None or self.iou_boxes.device != x.device:
+            self._build_anchors(x.device)
+        loc, cls = [], []
+        for fm in self.fpn(x):
+            loc.append(self.loc_head(fm).permute(0, 2, 3, 1).contiguous().view(x.size(0), -1, 4))
+            cls.append(self.cls_head(fm).permute(0, 2, 3, 1).contiguous().view(x.size(0), -1, self.num_classes))
+        return torch.cat(loc, 1), torch.cat(cls, 1)
+
+    def freeze_bn(self):
+        for m in self.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.eval()
+
+    def non_max_suppression(self, predictions, topk=100, nms_thresh=0.5, class_thresh=0.45, mode="union"):
+        return greedy_non_max_suppression(predictions, self.iou_boxes, topk, nms_thresh, class_thresh, mode)
+
+    training_step = _step.training_step
+    training_epoch_end = _step.training_epoch_end
+    validation_step = _step.validation_step
+    validation_epoch_end = _step.validation_epoch_end
+    test_step = _step.test_step
+    test_epoch_end = _step.test_epoch_end

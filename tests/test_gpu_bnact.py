@@ -7,7 +7,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("shape", [(4, 64, 26, 26), (2, 32, 52, 52), (3, 1024, 13, 13), (1, 12, 5, 7), (2, 2048, 4, 4)])
-@pytest.mark.parametrize("act", ["mish", "leaky", "linear"])
+@pytest.mark.parametrize("act", ["mish", "leaky", "linear", "relu"])
 @pytest.mark.parametrize("training", [True, False])
 def test_bn_act_matches_torch(shape, act, training):
     from objectdetectionpl_amd.LightningFunc.utils.bnact import bn_act, fusable
@@ -27,7 +27,7 @@ def test_bn_act_matches_torch(shape, act, training):
     assert fusable(x1, b1)
     y1 = bn_act(x1, b1, act)
     z = b2(x2)
-    y2 = F.mish(z) if act == "mish" else (F.leaky_relu(z, 0.1) if act == "leaky" else z)
+    y2 = F.mish(z) if act == "mish" else (F.leaky_relu(z, 0.1) if act == "leaky" else (F.relu(z) if act == "relu" else z))
     assert torch.allclose(y1, y2, rtol=1e-4, atol=1e-5), float((y1 - y2).abs().max())
     w = torch.randn(y2.shape, generator=torch.Generator().manual_seed(5)).cuda().contiguous(memory_format=torch.channels_last)
     (y1 * w).sum().backward(); (y2 * w).sum().backward()

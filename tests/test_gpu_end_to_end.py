@@ -35,3 +35,30 @@ def test_fit_validate_test_yolov4_small():
     for g, d in res.items():
         assert set(d) == {"cls_acc", "recall50", "recall75", "precision", "conf_obj", "conf_noobj"}
         assert 0.0 <= d["conf_noobj"] <= 1.0
+
+
+def test_fit_and_test_retinanet_small():
+    """RetinaNet flow: FPN forward -> HIP focal/SmoothL1 loss -> backward -> greedy NMS -> batch statistics -> AP."""
+    from objectdetectionpl_amd.dataset.Synthetic import SyntheticCocoModule
+    from objectdetectionpl_amd.model.RetinaNet import RetinaNet
+    from objectdetectionpl_amd.trainer import Trainer
+
+    class RArgs(Args):
+        model_name = "RetinaNet"; cls_criterion = "focal_loss"
+
+    torch.manual_seed(0)
+    dm = SyntheticCocoModule(batch_size=2, img_size=128, num_classes=4, targets_per_image=3, steps_per_epoch=3, device="cuda:0")
+    model = RetinaNet(dm.get_class(), RArgs())
+    model.img_size = 128
+    tr = Trainer(max_epochs=1, limit_val_batches=1, limit_test_batches=2, device="cuda:0")
+    hist = tr.fit(model.to("cuda:0").to(memory_format=torch.channels_last), dm)
+    assert [h[0] for h in hist] == ["train", "val"]
+    for _, _, scalars in hist:
+        assert {"Epoch/loss", "Epoch/Localization", "Epoch/Classification"} <= {t for t, _, _, _ in scalars}     # + pending per-step "Loss/*"
+        assert all(math.isfinite(v) for _, _, v, _ in scalars)
+    assert model.iou_boxes.shape == (3069, 4)
+    with torch.no_grad():                       # make a few anchors fire so that the NMS / AP path does real work
+        model.cls_head[-1].bias.fill_(0.5)
+    res = tr.test(model, dm)
+    assert {"precision", "recall", "AP", "f1", "ap_class"} <= set(res)
+    assert 0.0 <= res["AP"] <= 1.0
