@@ -249,6 +249,22 @@ class _V5LossFn(torch.autograd.Function):
         return (None, None) + tuple(grads)
 
 
+class _PosWeight(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.register_buffer("pos_weight", torch.tensor([1.0]))
+
+
+class _FocalShell(nn.Module):
+    """Parameter-free stand-in for FocalLoss(nn.BCEWithLogitsLoss(pos_weight=[1.0])): keeps the buffer keys only;
+    gamma 1.5 / alpha 0.25 are evaluated inside the HIP kernels."""
+
+    def __init__(self, gamma=1.5, alpha=0.25):
+        super().__init__()
+        self.loss_fcn = _PosWeight()
+        self.gamma, self.alpha, self.reduction = gamma, alpha, "mean"
+
+
 class MultiScaleRegionLoss_v5(nn.Module):
     """losses.py:70-156.  ctor keeps the reference's signature (the three criterion arguments are unused there
     as well: BCE-with-logits + focal gamma 1.5 are hard-wired, losses.py:78-89).  `iou_mode` selects the
@@ -266,6 +282,9 @@ class MultiScaleRegionLoss_v5(nn.Module):
         self.anchor_grid = torch.tensor(anchors).float().view(self.nl, 1, -1, 1, 1, 2)
         self.anchors = self.anchor_grid.view(self.nl, -1, 2) / self.stride[:self.nl].view(-1, 1, 1)   # :95-96 (f32)
         self.red = "mean"
+        # state_dict parity: the reference's criterion holds two FocalLoss(BCEWithLogitsLoss(pos_weight=[1.0])) modules
+        # (losses.py:79-89) whose `pos_weight` buffers appear in the model's state_dict
+        self.BCEcls, self.BCEobj = _FocalShell(), _FocalShell()
         self.iou_mode = iou_mode
         self._ws = None
         self._clean_key = None
