@@ -86,3 +86,27 @@ def test_fit_and_test_yolov5s_small():
         assert all(math.isfinite(v) for _, _, v, _ in scalars)
     res = tr.test(model, dm)
     assert {"precision", "recall", "AP", "f1", "ap_class"} <= set(res) and 0.0 <= res["AP"] <= 1.0
+
+
+def test_config1_yolov2_288_bs2_one_epoch():
+    """BASELINE config 1 (YOLOv2, C = 20, 288x288, bs 2, 8 synthetic batches): finite loss, the reference's dict keys,
+    head [2,125,9,9]; then the v2 test path (5-anchor merge NMS + get_yolo_statistics)."""
+    from objectdetectionpl_amd.dataset.Synthetic import SyntheticCocoModule
+    from objectdetectionpl_amd.model.YOLOV2 import YOLOv2
+    from objectdetectionpl_amd.trainer import Trainer
+
+    class V2(Args):
+        model_name = "YOLOv2"
+
+    torch.manual_seed(0)
+    dm = SyntheticCocoModule(batch_size=2, img_size=288, num_classes=20, targets_per_image=4, steps_per_epoch=8, device="cuda:0")
+    model = YOLOv2(dm.get_class(), V2())
+    model.img_size = 288; model.criterion.img_dim = 288
+    tr = Trainer(max_epochs=1, limit_val_batches=2, limit_test_batches=1, device="cuda:0")
+    hist = tr.fit(model.to("cuda:0").to(memory_format=torch.channels_last), dm)
+    assert model(torch.rand(2, 3, 288, 288, device="cuda:0")).shape == (2, 125, 9, 9)
+    keys = {"Epoch/" + k for k in ("loss", "Localization", "Size", "Conf", "Classification", "Conf_obj", "Conf_noobj")}
+    for _, _, scalars in hist:
+        assert keys <= {t for t, _, _, _ in scalars} and all(math.isfinite(v) for _, _, v, _ in scalars)
+    res = tr.test(model, dm)
+    assert set(res.keys()) == {9}
