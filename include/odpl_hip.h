@@ -92,6 +92,7 @@ int odpl_yolo_region_loss(const odpl_yolo_loss_desc_t* desc, void* workspace, si
  * Used by the backward of the fused loss, whose gradient was produced for a unit upstream gradient.
  */
 int odpl_scale_inplace_if_not_one(float* grad, size_t n, const float* scale, void* stream);
+int odpl_scale_inplace_if_not_one_bf16(void* grad_bf16, size_t n, const float* scale, void* stream);
 
 /*
  * Drop-in for accuracy.build_targets (accuracy.py:305-380): the reference's ten dense outputs.
@@ -163,8 +164,8 @@ int odpl_ssd_priors(const int32_t* host_fk, const int32_t* host_per_cell, const 
 /* ---- YOLOv5 loss: accuracy.py:472-521, losses.py:37-156, accuracy.py:71-114 ------------------- */
 
 typedef struct {
-    const float* p;                       /* [B, na, G, G, 5+nc] channel-LAST (Yolo_Layers.forward, YOLOV5.py:93-97) */
-    float* grad;                          /* same shape, or NULL on every layer: forward only */
+    const void* p;                        /* [B, na, G, G, 5+nc] channel-LAST (Yolo_Layers.forward, YOLOV5.py:93-97), fp32 or bf16 */
+    void* grad;                           /* same shape and dtype, or NULL on every layer: forward only */
     int32_t G;
     float anchor_w[ODPL_MAX_ANCHORS];     /* anchors / stride in f32 (losses.py:95-96) */
     float anchor_h[ODPL_MAX_ANCHORS];
@@ -174,6 +175,7 @@ typedef struct {
     int32_t nl, B, na, nc, nT;
     int32_t iou_mode;                     /* 0 IoU, 1 GIoU (what the reference calls, losses.py:118), 2 DIoU, 3 CIoU */
     int32_t flags;                        /* ODPL_YOLOV5_STATE_CLEAN */
+    int32_t bf16;                         /* 1: p / grad are bfloat16 (config 5); arithmetic and sums stay fp32 */
     const float* target;                  /* [nT, 6] */
     odpl_yolov5_layer_t layer[ODPL_MAX_SCALES];
 } odpl_yolov5_loss_desc_t;

@@ -244,8 +244,8 @@ class _V5LossFn(torch.autograd.Function):
         L = _lib.lib()
         for gr in grads:
             if gr is not None:
-                _lib.check(L.odpl_scale_inplace_if_not_one(_lib.ptr(gr), gr.numel(), _lib.ptr(g),
-                                                           _lib.current_stream(gr.device)), "odpl_scale_inplace_if_not_one")
+                fn = L.odpl_scale_inplace_if_not_one_bf16 if gr.dtype == torch.bfloat16 else L.odpl_scale_inplace_if_not_one
+                _lib.check(fn(_lib.ptr(gr), gr.numel(), _lib.ptr(g), _lib.current_stream(gr.device)), "odpl_scale_inplace_if_not_one")
         return (None, None) + tuple(grads)
 
 
@@ -298,10 +298,11 @@ class MultiScaleRegionLoss_v5(nn.Module):
         tgt = target.float().contiguous()
         d.nl, d.B, d.na, d.nc, d.nT = len(heads), heads[0].shape[0], self.na, self.nc, tgt.shape[0]
         d.iou_mode = _lib.IOU_MODES[self.iou_mode]
+        d.bf16 = 1 if heads[0].dtype == torch.bfloat16 else 0
         d.target = tgt.data_ptr() if d.nT else None
         for i, (h, g) in enumerate(zip(heads, grads)):
-            if h.dtype != torch.float32:
-                raise TypeError("YOLOv5 heads must be fp32 here (bf16 heads: cast first; losses accumulate in fp32)")
+            if h.dtype not in (torch.float32, torch.bfloat16) or h.dtype != heads[0].dtype:
+                raise TypeError("YOLOv5 heads must all be fp32 or all be bf16 (arithmetic and sums are fp32 either way)")
             if h.dim() != 5 or h.shape[1] != self.na or h.shape[4] != 5 + self.nc or h.shape[2] != h.shape[3]:
                 raise ValueError(f"layer {i}: expected [B,{self.na},G,G,{5 + self.nc}], got {tuple(h.shape)}")
             l = d.layer[i]

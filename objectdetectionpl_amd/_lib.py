@@ -65,7 +65,7 @@ class YoloV5Layer(ctypes.Structure):
 
 class YoloV5LossDesc(ctypes.Structure):
     _fields_ = [("nl", c_int32), ("B", c_int32), ("na", c_int32), ("nc", c_int32), ("nT", c_int32),
-                ("iou_mode", c_int32), ("flags", c_int32), ("target", c_void_p), ("layer", YoloV5Layer * MAX_SCALES)]
+                ("iou_mode", c_int32), ("flags", c_int32), ("bf16", c_int32), ("target", c_void_p), ("layer", YoloV5Layer * MAX_SCALES)]
 
 
 class SsdLossDesc(ctypes.Structure):
@@ -114,6 +114,7 @@ SIGNATURES = {
     "odpl_bn_act_backward": (c_int32, [c_void_p, c_void_p, ctypes.c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "odpl_tune_set": (c_int32, [c_int32, c_int32]),
+    "odpl_scale_inplace_if_not_one_bf16": (c_int32, [c_void_p, c_size_t, c_void_p, c_void_p]),
     "odpl_profile_enable": (c_int32, [c_int32, c_int32]),
     "odpl_profile_collect": (c_int32, [c_int32, POINTER(c_float), POINTER(c_float), c_int32]),
     "odpl_yolo_build_targets": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,

@@ -17,6 +17,7 @@
 //                                   gradients over the zeros, partial sums for x,y,w,h,cls and "Size"
 //   finalize (1 workgroup)          fixed-order reduction -> the reference's 7 scalars per scale and total
 // No atomics on floats anywhere: results are bitwise reproducible run to run.
+#include <hip/hip_bf16.h>
 #include "odpl_common.hpp"
 #include "odpl_yolo_dev.hpp"
 #include "odpl_profile.hpp"
@@ -404,6 +405,13 @@ __global__ void scale_if_not_one_kernel(float* __restrict__ g, size_t n, const f
     for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) g[i] *= f;
 }
 
+__global__ void scale_if_not_one_bf16_kernel(__hip_bfloat16* __restrict__ g, size_t n, const float* __restrict__ s) {
+    const float f = *s;
+    if (f == 1.0f) return;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) g[i] = __float2bfloat16(__bfloat162float(g[i]) * f);
+}
+
 // ------------------------------------------------------------------------------------------------
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -541,6 +549,15 @@ extern "C" int odpl_scale_inplace_if_not_one(float* grad, size_t n, const float*
     if (n == 0) return 0;
     size_t blocks = (n / 4 + 255) / 256; if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(scale_if_not_one_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, grad, n, scale);
+    ODPL_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int odpl_scale_inplace_if_not_one_bf16(void* grad, size_t n, const float* scale, void* stream_) {
+    if (!grad || !scale) return ODPL_EINVAL;
+    if (n == 0) return 0;
+    size_t blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(scale_if_not_one_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, (__hip_bfloat16*)grad, n, scale);
     ODPL_HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -16,6 +16,7 @@
 //   cells  (1 wave / row)  leader rows add the row gradients of all rows that share their cell, ascending row
 //                          order (index_put accumulate semantics, deterministic), over the zeros
 //   finalize (1 WG)        fixed-order sums -> lbox*0.05 + lobj*1.0 + lcls*0.58
+#include <hip/hip_bf16.h>
 #include "odpl_common.hpp"
 #include "odpl_yolo_dev.hpp"
 #include "odpl_profile.hpp"
@@ -28,7 +29,7 @@ constexpr int kDT = 256;              // dense threads
 constexpr int kChunkF4 = 4096;        // float4 per dense workgroup
 
 struct Layer {
-    const float* p; float* grad;
+    const void* p; void* grad;        // fp32 or bf16 (VParams.bf16): loads widen to fp32, sums stay fp32, the gradient is rounded once
     int G, cells;                     // cells = B*na*G*G
     float aw[ODPL_MAX_ANCHORS], ah[ODPL_MAX_ANCHORS];
     int* owner;                       // [cells]  -1 clean; max row index that maps here
@@ -48,7 +49,7 @@ struct Layer {
 struct VParams {
     Layer L[ODPL_MAX_SCALES];
     const float* target;
-    int nl, B, na, nc, no, nT, cap, iou_mode, want_grad;
+    int nl, B, na, nc, no, nT, cap, iou_mode, want_grad, bf16;
     int* status;
     float* out4; int* out_counts;
 };
@@ -119,6 +120,14 @@ __global__ __launch_bounds__(kAT) void v5_assign_kernel(const VParams P) {
 
 // ---------------------------------------------------------------------------------------------
 // forward-mode value + 4 tangents (d/d px, py, pw, ph); tie / clamp conventions follow torch autograd
+__device__ __forceinline__ float ld_head(const void* p, size_t i, int bf16) {
+    return bf16 ? __bfloat162float(reinterpret_cast<const __hip_bfloat16*>(p)[i]) : reinterpret_cast<const float*>(p)[i];
+}
+__device__ __forceinline__ void st_grad(void* p, size_t i, float v, int bf16) {
+    if (bf16) reinterpret_cast<__hip_bfloat16*>(p)[i] = __float2bfloat16(v); else reinterpret_cast<float*>(p)[i] = v;
+}
+__device__ __forceinline__ unsigned short bf16_bits(float v) { const __hip_bfloat16 h = __float2bfloat16(v); return *reinterpret_cast<const unsigned short*>(&h); }
+
 struct D4 { float v; float d[4]; };
 __device__ __forceinline__ D4 dconst(float c) { D4 r; r.v = c; r.d[0] = r.d[1] = r.d[2] = r.d[3] = 0.f; return r; }
 __device__ __forceinline__ D4 dvar(float c, int i) { D4 r = dconst(c); r.d[i] = 1.f; return r; }
@@ -191,7 +200,8 @@ __global__ __launch_bounds__(64) void v5_rows_kernel(const VParams P) {
         return;
     }
     const int t = S.row_t[r], ag = S.row_ag[r], a = ag >> 4, grp = ag & 15;
-    const float* ps = S.p + (size_t)cell * no;
+    const size_t pb = (size_t)cell * no;
+    auto ps = [&](int k) { return ld_head(S.p, pb + k, P.bf16); };
     const float* y = P.target + (size_t)t * 6;
     const float fG = (float)S.G, fn = (float)n;
     // ---- box (lane 0): losses.py:115-119, accuracy.py:512-517
@@ -200,7 +210,7 @@ __global__ __launch_bounds__(64) void v5_rows_kernel(const VParams P) {
         const float ox = grp == 1 ? 0.5f : (grp == 3 ? -0.5f : 0.0f), oy = grp == 2 ? 0.5f : (grp == 4 ? -0.5f : 0.0f);
         const float gi = (float)trunc_ll(gx - ox), gj = (float)trunc_ll(gy - oy);
         const float tx = gx - gi, ty = gy - gj;                     // tbox = (gxy - gij, gwh)
-        const float s0 = sigmoidf_(ps[0]), s1 = sigmoidf_(ps[1]), s2 = sigmoidf_(ps[2]), s3 = sigmoidf_(ps[3]);
+        const float s0 = sigmoidf_(ps(0)), s1 = sigmoidf_(ps(1)), s2 = sigmoidf_(ps(2)), s3 = sigmoidf_(ps(3));
         const float px = s0 * 2.0f - 0.5f, py = s1 * 2.0f - 0.5f;
         const float u2 = s2 * 2.0f, u3 = s3 * 2.0f;
         const float pw = (u2 * u2) * S.aw[a], ph = (u3 * u3) * S.ah[a];
@@ -222,7 +232,7 @@ __global__ __launch_bounds__(64) void v5_rows_kernel(const VParams P) {
         const float sc = 0.58f / (fn * (float)nc);
         for (int k = lane; k < nc; k += 64) {
             float l, dx;
-            focal_bce(ps[5 + k], k == tc ? 1.0f : 0.0f, l, dx);
+            focal_bce(ps(5 + k), k == tc ? 1.0f : 0.0f, l, dx);
             acc += l;
             rg[5 + k] = dx * sc;
         }
@@ -241,29 +251,30 @@ __global__ __launch_bounds__(64) void v5_rows_kernel(const VParams P) {
 //   phase 2: pure store stream: every quad is ONE 16-byte non-temporal store; a quad that contains a cell's
 //            objectness element takes that element from LDS.  No load sits in the store stream and no partial
 //            (dword) store is issued, so the fill runs at the HBM write ceiling.
-template <bool GRAD>
+template <bool GRAD, bool BF16>
 __global__ __launch_bounds__(kDT) void v5_dense_kernel(const VParams P) {
+    constexpr int EPQ = BF16 ? 8 : 4;                        // elements per 16-byte quad
     __shared__ float sh[kDT / 64];
-    __shared__ float s_g[kChunkF4 * 4 / 6 + 2];      // cells per chunk at the smallest row (no = 6)
+    __shared__ float s_g[kChunkF4 * 8 / 6 + 3];              // cells per chunk at the smallest row (no = 6), bf16 quads
     const int tid = threadIdx.x;
     int li = 0;
     for (int i = 0; i < P.nl; ++i) if ((int)blockIdx.x >= P.L[i].dense_blk0) li = i;
     const Layer& S = P.L[li];
     const unsigned no = (unsigned)P.no;
-    const size_t total = (size_t)S.cells * no, total4 = total / 4;
+    const size_t total = (size_t)S.cells * no, totalq = total / EPQ;
     const size_t q0 = (size_t)(blockIdx.x - S.dense_blk0) * kChunkF4;
-    const bool last = (q0 + kChunkF4) >= total4;
-    const size_t q1 = last ? total4 : (q0 + kChunkF4);
-    const size_t e0 = q0 * 4, e1 = last ? total : q1 * 4;     // the last chunk also owns the < 4 tail elements
+    const bool last = (q0 + kChunkF4) >= totalq;
+    const size_t q1 = last ? totalq : (q0 + kChunkF4);
+    const size_t e0 = q0 * EPQ, e1 = last ? total : q1 * EPQ; // the last chunk also owns the < EPQ tail elements
     const unsigned c_lo = e0 <= 4 ? 0u : (unsigned)((e0 - 4 + no - 1) / no);
     const int n_loc = e1 >= 5 ? (int)((e1 - 5) / no) - (int)c_lo + 1 : 0;        // cells with e0 <= no*c+4 < e1
     float acc = 0.f;
-    for (int i = tid; i < n_loc; i += kDT) {                  // one pass at no = 85 (<= 194 cells per chunk)
+    for (int i = tid; i < n_loc; i += kDT) {                  // one pass at no = 85 fp32 (<= 194 cells per chunk)
         const unsigned c = c_lo + i;
         const int ow = S.owner[c];
         const float tobj = ow >= 0 ? fmaxf(S.row_iou[ow], 0.0f) : 0.0f;         // losses.py:123 (gr = 1)
         float l, dx;
-        focal_bce(S.p[(size_t)c * no + 4], tobj, l, dx);
+        focal_bce(ld_head(S.p, (size_t)c * no + 4, BF16), tobj, l, dx);
         acc += l;
         s_g[i] = dx * (1.0f / (float)S.cells);                // mean over all cells, gain 1.0 (losses.py:135,138)
         if (ow >= 0) S.owner[c] = -1;                         // leave the map clean
@@ -279,17 +290,30 @@ __global__ __launch_bounds__(kDT) void v5_dense_kernel(const VParams P) {
     if (!GRAD) return;
     v4f* g4 = reinterpret_cast<v4f*>(S.grad);
     for (size_t q = q0 + tid; q < q1; q += kDT) {
-        v4f o = {0.f, 0.f, 0.f, 0.f};
-        const unsigned e = (unsigned)(q * 4);
+        const unsigned e = (unsigned)(q * EPQ);
         const unsigned c = (unsigned)(((unsigned long long)e * S.inv_no) >> 40);
         const unsigned r = e - c * no;
-        if (r >= 1u && r <= 4u) o[4 - r] = s_g[c - c_lo];     // this quad holds cell c's objectness element
-        __builtin_nontemporal_store(o, g4 + q);
+        if (!BF16) {
+            v4f o = {0.f, 0.f, 0.f, 0.f};
+            if (r >= 1u && r <= 4u) o[4 - r] = s_g[c - c_lo];      // this quad holds cell c's objectness element
+            __builtin_nontemporal_store(o, g4 + q);
+        } else {
+            // 8 bf16 per quad: it can hold cell c's objectness (offset 4 - r) and/or cell c+1's (offset no + 4 - r)
+            unsigned short h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (r <= 4u) h[4 - r] = bf16_bits(s_g[c - c_lo]);
+            const unsigned k2 = no + 4u - r;
+            if (k2 < 8u && (size_t)(c + 1) < (size_t)S.cells) h[k2] = bf16_bits(s_g[c + 1 - c_lo]);
+            v4f o;
+            unsigned* ob = reinterpret_cast<unsigned*>(&o);
+            ob[0] = h[0] | ((unsigned)h[1] << 16); ob[1] = h[2] | ((unsigned)h[3] << 16);
+            ob[2] = h[4] | ((unsigned)h[5] << 16); ob[3] = h[6] | ((unsigned)h[7] << 16);
+            __builtin_nontemporal_store(o, g4 + q);
+        }
     }
-    if (last && (size_t)tid < total - total4 * 4) {           // < 4 tail elements of the layer
-        const size_t e = total4 * 4 + tid;
+    if (last && (size_t)tid < total - totalq * EPQ) {         // < EPQ tail elements of the layer
+        const size_t e = totalq * EPQ + tid;
         const unsigned c = (unsigned)(e / no);
-        S.grad[e] = (e - (size_t)c * no) == 4 ? s_g[c - c_lo] : 0.f;
+        st_grad(S.grad, e, (e - (size_t)c * no) == 4 ? s_g[c - c_lo] : 0.f, BF16);
     }
 }
 
@@ -314,11 +338,11 @@ __global__ __launch_bounds__(64) void v5_cells_kernel(const VParams P) {
             if (lane + 192 < no) a3 += g[lane + 192];
         }
     }
-    float* dst = S.grad + (size_t)cell * no;
-    if (lane < no && lane != 4) dst[lane] = a0;
-    if (lane + 64 < no) dst[lane + 64] = a1;
-    if (lane + 128 < no) dst[lane + 128] = a2;
-    if (lane + 192 < no) dst[lane + 192] = a3;
+    const size_t db = (size_t)cell * no;
+    if (lane < no && lane != 4) st_grad(S.grad, db + lane, a0, P.bf16);
+    if (lane + 64 < no) st_grad(S.grad, db + lane + 64, a1, P.bf16);
+    if (lane + 128 < no) st_grad(S.grad, db + lane + 128, a2, P.bf16);
+    if (lane + 192 < no) st_grad(S.grad, db + lane + 192, a3, P.bf16);
 }
 
 __global__ __launch_bounds__(256) void v5_finalize_kernel(const VParams P) {
@@ -385,7 +409,7 @@ bool make_vplan(const odpl_yolov5_loss_desc_t* d, VPlan* p) {
     for (int i = 0; i < d->nl; ++i) {
         const size_t cap = (size_t)p->cap;
         const long long cells = (long long)d->B * d->na * d->layer[i].G * d->layer[i].G;
-        p->dense_nblk[i] = (int)(((size_t)cells * p->no / 4 + kChunkF4 - 1) / kChunkF4); if (p->dense_nblk[i] < 1) p->dense_nblk[i] = 1;
+        p->dense_nblk[i] = (int)(((size_t)cells * p->no / (d->bf16 ? 8 : 4) + kChunkF4 - 1) / kChunkF4); if (p->dense_nblk[i] < 1) p->dense_nblk[i] = 1;
         p->conf_nblk[i] = (int)((cells + kDT - 1) / kDT);
         p->row_t[i] = off;    off += align_up(cap * 4, 256);
         p->row_ag[i] = off;   off += align_up(cap * 4, 256);
@@ -416,6 +440,7 @@ extern "C" int odpl_yolov5_loss(const odpl_yolov5_loss_desc_t* d, void* workspac
     char* ws = (char*)workspace;
     VParams P;
     P.target = d->target; P.nl = d->nl; P.B = d->B; P.na = d->na; P.nc = d->nc; P.no = pl.no; P.nT = d->nT; P.cap = pl.cap;
+    P.bf16 = d->bf16 ? 1 : 0;
     P.iou_mode = d->iou_mode; P.status = (int*)(ws + pl.status); P.out4 = out4; P.out_counts = out_counts;
     int blk = 0, want = 0;
     for (int i = 0; i < d->nl; ++i) {
@@ -448,8 +473,13 @@ extern "C" int odpl_yolov5_loss(const odpl_yolov5_loss_desc_t* d, void* workspac
         ODPL_HIP_TRY(hipGetLastError());
     }
     prof_begin(ODPL_PROF_YOLOV5_DENSE, stream);
-    if (P.want_grad) hipLaunchKernelGGL(v5_dense_kernel<true>, dim3(blk), dim3(kDT), 0, stream, P);
-    else hipLaunchKernelGGL(v5_dense_kernel<false>, dim3(blk), dim3(kDT), 0, stream, P);
+    if (P.bf16) {
+        if (P.want_grad) hipLaunchKernelGGL((v5_dense_kernel<true, true>), dim3(blk), dim3(kDT), 0, stream, P);
+        else hipLaunchKernelGGL((v5_dense_kernel<false, true>), dim3(blk), dim3(kDT), 0, stream, P);
+    } else {
+        if (P.want_grad) hipLaunchKernelGGL((v5_dense_kernel<true, false>), dim3(blk), dim3(kDT), 0, stream, P);
+        else hipLaunchKernelGGL((v5_dense_kernel<false, false>), dim3(blk), dim3(kDT), 0, stream, P);
+    }
     prof_end(ODPL_PROF_YOLOV5_DENSE, stream);
     ODPL_HIP_TRY(hipGetLastError());
     if (d->nT > 0 && P.want_grad) {
