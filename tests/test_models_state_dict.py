@@ -47,3 +47,10 @@ def test_yolov3_state_dict():
     from objectdetectionpl_amd.model.YOLOV3 import YOLOv3
     _check(YOLOv3([str(i) for i in range(80)], A(model_name="YOLOv3", coord_criterion="mse_loss")),
            json.load(open(os.path.join(HERE, "golden", "state_dict_yolov3.json"))))
+
+
+def test_ssd_state_dict():
+    """Manifest derived from the reference's source text (torchvision is absent, so it was not captured from a run)."""
+    from objectdetectionpl_amd.model.SSD import SSD
+    g = json.load(open(os.path.join(HERE, "golden", "state_dict_ssd.json")))
+    _check(SSD([str(i) for i in range(g["num_classes"])], A(model_name="SSD", cls_criterion="ce_loss")), g["state_dict"])
