@@ -307,6 +307,17 @@ int odpl_spp_forward(const float* x, const int64_t* host_x_strides, int32_t B, i
 int odpl_spp_backward(const float* x, const int64_t* host_x_strides, int32_t B, int32_t C, int32_t H, int32_t W,
                       const float* grad_y, const int64_t* host_y_strides, float* grad_x, void* stream);
 
+/* ---- space-to-depth shuffles next to the stems/heads ------------------------------------------ */
+/* Focus, utils/YoloV5Utils.py:117-125: y[b, g*C+c, i, j] = x[b, c, 2i+(g&1), 2j+(g>>1)]; x is [B,C,H,W], y is
+ * [B,4C,H/2,W/2]; element strides (b,c,h,w) of dense tensors in any memory format.  inverse = 0: src = x, dst = y;
+ * inverse = 1: src = grad_y, dst = grad_x (the same permutation walked backwards). */
+int odpl_focus(const float* src, float* dst, int32_t B, int32_t C, int32_t H, int32_t W,
+               const int64_t* host_x_strides, const int64_t* host_y_strides, int32_t inverse, void* stream);
+/* YOLOv2 passthrough "reorg", model/YOLOV2.py:147-151: x is the CONTIGUOUS NCHW block [B,C,H,W] (C % 4 == 0), reinterpreted
+ * as [B,C/4,H,2,W,2] -> permute(0,3,5,1,2,4) -> [B,4C,H/2,W/2] with the given y strides. */
+int odpl_reorg(const float* src, float* dst, int32_t B, int32_t C, int32_t H, int32_t W,
+               const int64_t* host_y_strides, int32_t inverse, void* stream);
+
 /* ---- fused BatchNorm2d + activation on channels-last fp32: utils/YoloV4Utils.py:208-236 ---- */
 #define ODPL_ACT_LINEAR 0
 #define ODPL_ACT_MISH 1

@@ -106,6 +106,8 @@ SIGNATURES = {
     "odpl_ap_per_class": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_size_t] + [c_void_p] * 6 + [c_void_p]),
     "odpl_yolo_train_decode": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, POINTER(c_float), c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "odpl_yolo_stats_reduce": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_void_p, c_void_p]),
+    "odpl_focus": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, POINTER(ctypes.c_int64), POINTER(ctypes.c_int64), c_int32, c_void_p]),
+    "odpl_reorg": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, POINTER(ctypes.c_int64), c_int32, c_void_p]),
     "odpl_spp_forward": (c_int32, [c_void_p, POINTER(ctypes.c_int64), c_int32, c_int32, c_int32, c_int32, c_void_p, POINTER(ctypes.c_int64), c_void_p]),
     "odpl_spp_backward": (c_int32, [c_void_p, POINTER(ctypes.c_int64), c_int32, c_int32, c_int32, c_int32, c_void_p, POINTER(ctypes.c_int64), c_void_p, c_void_p]),
     "odpl_bn_act_workspace_bytes": (c_size_t, [ctypes.c_int64, c_int32]),

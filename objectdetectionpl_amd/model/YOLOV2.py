@@ -12,6 +12,7 @@ from ..LightningFunc.accuracy import get_yolo_statistics as _get_yolo_statistics
 from ..LightningFunc.losses import configure_loss
 from ..LightningFunc.nms import yolo_non_max_suppression
 from ..LightningFunc.utils import bnact as _bnact
+from ..LightningFunc.utils.s2d import reorg as _reorg
 
 try:
     import pytorch_lightning as pl
@@ -83,7 +84,10 @@ class YOLOv2(_Base):
             y = _run(getattr(self, name), y)
         z = _run(self.stage2_b_conv, residual)
         B, C, H, W = z.shape                                     # "reorg": YOLOV2.py:147-151
-        z = z.contiguous().view(B, C // 4, H, 2, W, 2).permute(0, 3, 5, 1, 2, 4).contiguous().view(B, -1, H // 2, W // 2)
+        if z.is_cuda and z.dtype == torch.float32 and C % 4 == 0 and H % 2 == 0 and W % 2 == 0:
+            z = _reorg(z, y.is_contiguous(memory_format=torch.channels_last) and not y.is_contiguous())
+        else:
+            z = z.contiguous().view(B, C // 4, H, 2, W, 2).permute(0, 3, 5, 1, 2, 4).contiguous().view(B, -1, H // 2, W // 2)
         return self.stage3_conv2(_run(self.stage3_conv1, torch.cat((y, z), 1)))
 
     def non_max_suppression(self, predictions, conf_thres=0.5, nms_thres=0.4):

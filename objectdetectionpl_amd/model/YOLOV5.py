@@ -13,6 +13,7 @@ from ..LightningFunc.accuracy import get_yolo_statistics as _get_yolo_statistics
 from ..LightningFunc.losses import configure_loss
 from ..LightningFunc.nms import yolo_non_max_suppression
 from ..LightningFunc.utils import bnact as _bnact
+from ..LightningFunc.utils.s2d import focus as _focus
 from ..LightningFunc.utils.spp import spp_cat
 
 try:
@@ -104,6 +105,9 @@ class Focus(nn.Module):
         self.conv = Conv(c1 * 4, _w(c2, width_multiple), k, 1)
 
     def forward(self, x):
+        if x.is_cuda and x.dtype == torch.float32 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0:
+            cl = self.conv.conv.weight.is_contiguous(memory_format=torch.channels_last) and not self.conv.conv.weight.is_contiguous()
+            return self.conv(_focus(x, cl or None))             # one HIP shuffle, written in the stem conv's memory format
         return self.conv(torch.cat([x[..., ::2, ::2], x[..., 1::2, ::2], x[..., ::2, 1::2], x[..., 1::2, 1::2]], 1))
 
 
