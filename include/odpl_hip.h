@@ -307,6 +307,23 @@ int odpl_spp_forward(const float* x, const int64_t* host_x_strides, int32_t B, i
 int odpl_spp_backward(const float* x, const int64_t* host_x_strides, int32_t B, int32_t C, int32_t H, int32_t W,
                       const float* grad_y, const int64_t* host_y_strides, float* grad_x, void* stream);
 
+/* ---- device-side collate: dataset/Pascal.py:121-186 == Coco.py:146-220 ------------------------- */
+/* One raw frame in HBM: uint8 [h, w, 3] interleaved (cv2.imread layout, BGR).  flip: bit 0 horizontal, bit 1 vertical
+ * (the host draws them, p = 0.2 each in the reference). */
+typedef struct {
+    const uint8_t* data;
+    int32_t h, w;
+    int32_t flip;
+    int32_t reserved;
+} odpl_image_t;
+/* x[b] = CHW( flip( resize_linear_u8(image b -> S x S) ) ) / 255, written with the given element strides (b, c, h, w). */
+int odpl_collate_images(const odpl_image_t* host_images, int32_t B, int32_t S, float* x,
+                        const int64_t* host_x_strides, void* stream);
+/* objects [nT, 5] = (x, y, w, h, label) in source pixels (COCO), row_image [nT] = image of each row, image_dims [B, 3] =
+ * (h, w, flip) (device arrays) -> y [nT, 6] = (img, label, x, y, w, h) normalised, after the flips. */
+int odpl_collate_targets(const float* objects, const int32_t* row_image, const int32_t* image_dims, int32_t nT,
+                         int32_t S, float* y, void* stream);
+
 /* ---- space-to-depth shuffles next to the stems/heads ------------------------------------------ */
 /* Focus, utils/YoloV5Utils.py:117-125: y[b, g*C+c, i, j] = x[b, c, 2i+(g&1), 2j+(g>>1)]; x is [B,C,H,W], y is
  * [B,4C,H/2,W/2]; element strides (b,c,h,w) of dense tensors in any memory format.  inverse = 0: src = x, dst = y;

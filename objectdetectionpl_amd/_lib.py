@@ -58,6 +58,10 @@ class YoloDecodeDesc(ctypes.Structure):
                 ("scale_x_y_offset", c_float), ("scale", YoloDecodeScale * MAX_SCALES)]
 
 
+class Image(ctypes.Structure):
+    _fields_ = [("data", c_void_p), ("h", c_int32), ("w", c_int32), ("flip", c_int32), ("reserved", c_int32)]
+
+
 class YoloV5Layer(ctypes.Structure):
     _fields_ = [("p", c_void_p), ("grad", c_void_p), ("G", c_int32),
                 ("anchor_w", c_float * MAX_ANCHORS), ("anchor_h", c_float * MAX_ANCHORS)]
@@ -106,6 +110,8 @@ SIGNATURES = {
     "odpl_ap_per_class": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_size_t] + [c_void_p] * 6 + [c_void_p]),
     "odpl_yolo_train_decode": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, POINTER(c_float), c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "odpl_yolo_stats_reduce": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_void_p, c_void_p]),
+    "odpl_collate_images": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, POINTER(ctypes.c_int64), c_void_p]),
+    "odpl_collate_targets": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "odpl_focus": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, POINTER(ctypes.c_int64), POINTER(ctypes.c_int64), c_int32, c_void_p]),
     "odpl_reorg": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, POINTER(ctypes.c_int64), c_int32, c_void_p]),
     "odpl_spp_forward": (c_int32, [c_void_p, POINTER(ctypes.c_int64), c_int32, c_int32, c_int32, c_int32, c_void_p, POINTER(ctypes.c_int64), c_void_p]),

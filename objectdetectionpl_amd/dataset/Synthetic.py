@@ -8,10 +8,14 @@ import torch
 class SyntheticCocoModule:
     name = "synthetic"
 
-    def __init__(self, batch_size, img_size, num_classes=80, targets_per_image=7, steps_per_epoch=8, device="cuda", seed=1):
+    def __init__(self, batch_size, img_size, num_classes=80, targets_per_image=7, steps_per_epoch=8, device="cuda", seed=1,
+                 raw_frames=False, channels_last=False):
         self.batch_size, self.img_size, self.num_classes = batch_size, img_size, num_classes
         self.targets_per_image, self.steps_per_epoch = targets_per_image, steps_per_epoch
         self.device, self.seed = torch.device(device), seed
+        # raw_frames: emit COCO-like uint8 frames of varying size + pixel boxes and run the device collate
+        # (resize / flips / normalise / row rewrite, dataset/collate.py) -- the train-time chain of Pascal.py:121-186
+        self.raw_frames, self.channels_last = raw_frames, channels_last
 
     def setup(self, stage=None):
         return self
@@ -28,10 +32,26 @@ class SyntheticCocoModule:
         xy = torch.rand(n, 2, generator=g, device=self.device) * (1 - wh)
         return x, torch.cat([b[:, None], cls[:, None], xy, wh], 1)
 
+    def _raw_batch(self, g, hg, train):
+        from .collate import draw_flips, gpu_collate
+        images, objects = [], []
+        for _ in range(self.batch_size):
+            h, w = [int(v) for v in torch.randint(320, 641, (2,), generator=hg)]            # COCO-sized frames
+            images.append(torch.randint(0, 256, (h, w, 3), generator=g, device=self.device, dtype=torch.uint8))
+            n = self.targets_per_image
+            wh = (torch.rand(n, 2, generator=g, device=self.device) * 0.48 + 0.02)
+            xy = torch.rand(n, 2, generator=g, device=self.device) * (1 - wh)
+            scale = torch.tensor([w, h], device=self.device, dtype=torch.float32)
+            cls = torch.randint(0, self.num_classes, (n, 1), generator=g, device=self.device).float()
+            objects.append(torch.cat([xy * scale, wh * scale, cls], 1))
+        flips = draw_flips(self.batch_size, hg) if train else None                         # val / test: Resize only
+        return gpu_collate(images, objects, self.img_size, flips, self.channels_last)
+
     def _loader(self, offset):
         g = torch.Generator(device=self.device).manual_seed(self.seed + offset)
+        hg = torch.Generator().manual_seed(self.seed + offset)
         for _ in range(self.steps_per_epoch):
-            yield self._batch(g)
+            yield self._raw_batch(g, hg, offset == 0) if self.raw_frames else self._batch(g)
 
     def train_dataloader(self):
         return self._loader(0)

@@ -1,0 +1,81 @@
+"""Device collate against oracle/collate.py: BIT-exact pixels (8-bit fixed-point bilinear, /255 in fp32) and rows.
+The oracle itself is unpinned against cv2 (absent here) -- documented in oracle/collate.py."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import collate as oc
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(sizes, S, flips, seed, n_obj=(0, 3, 5)):
+    rng = np.random.default_rng(seed)
+    images = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in sizes]
+    objs = []
+    for k, (h, w) in enumerate(sizes):
+        n = n_obj[k % len(n_obj)]
+        bw, bh = rng.uniform(0.25, 0.5, n) * w, rng.uniform(0.25, 0.5, n) * h
+        objs.append(np.stack([rng.uniform(0, w - bw), rng.uniform(0, h - bh), bw, bh, rng.integers(0, 20, n).astype(float)], 1).astype(np.float32)
+                    if n else np.zeros((0, 5), np.float32))
+    return images, objs, flips
+
+
+@pytest.mark.parametrize("channels_last", [False, True])
+@pytest.mark.parametrize("sizes,S", [([(37, 53), (64, 64), (128, 96), (500, 375)], 64), ([(16, 16), (33, 17)], 416),
+                                      ([(480, 640)] * 3, 416), ([(1, 1), (2, 7)], 8)])
+def test_collate_matches_oracle(sizes, S, channels_last):
+    from objectdetectionpl_amd.dataset.collate import gpu_collate
+    flips = [(i * 7 + 1) % 4 for i in range(len(sizes))]
+    images, objs, flips = _case(sizes, S, flips, seed=len(sizes) * 1000 + S)
+    want_x, want_y = oc.collate(images, objs, S, flips)
+    x, y = gpu_collate([torch.from_numpy(i).cuda() for i in images], [torch.from_numpy(o).cuda() for o in objs], S, flips, channels_last)
+    assert x.is_contiguous(memory_format=torch.channels_last if channels_last else torch.contiguous_format)
+    assert np.array_equal(x.cpu().numpy(), want_x)
+    assert np.array_equal(y.cpu().numpy(), want_y)
+
+
+def test_more_images_than_one_launch_holds():
+    from objectdetectionpl_amd.dataset.collate import draw_flips, gpu_collate
+    sizes = [(20 + i, 30 + 2 * i) for i in range(70)]
+    flips = draw_flips(70, torch.Generator().manual_seed(3), 0.5, 0.5)
+    images, objs, flips = _case(sizes, 32, flips, seed=9)
+    want_x, want_y = oc.collate(images, objs, 32, flips)
+    x, y = gpu_collate([torch.from_numpy(i).cuda() for i in images], [torch.from_numpy(o).cuda() for o in objs], 32, flips)
+    assert np.array_equal(x.cpu().numpy(), want_x) and np.array_equal(y.cpu().numpy(), want_y)
+
+
+def test_feeds_the_training_step():
+    """(x, y) from the device collate drive one YOLO loss evaluation -- the wire format is the one the criterion reads."""
+    from objectdetectionpl_amd.dataset.collate import gpu_collate
+    from objectdetectionpl_amd.LightningFunc.losses import configure_loss
+
+    class A:
+        model_name = "YOLOv4"; cls_criterion = "bce_loss"; coord_criterion = "smooth_l1_loss"
+    images, objs, flips = _case([(90, 120), (200, 150)], 64, [1, 0], seed=4, n_obj=(2, 3))
+    x, y = gpu_collate([torch.from_numpy(i).cuda() for i in images], [torch.from_numpy(o).cuda() for o in objs], 64, flips)
+    anchors = [[12, 16], [19, 36], [40, 28], [36, 75], [76, 55], [72, 146], [142, 110], [192, 243], [459, 401]]
+    crit = configure_loss(A(), None, anchors, [[0, 1, 2], [3, 4, 5], [6, 7, 8]], 20, 64)
+    heads = [torch.randn(2, 75, g, g, device="cuda", requires_grad=True) for g in (8, 4, 2)]
+    out = crit(heads, y)
+    assert torch.isfinite(out["loss"]) and float(x.min()) >= 0.0 and float(x.max()) <= 1.0
+
+
+def test_bad_arguments():
+    from objectdetectionpl_amd.dataset.collate import gpu_collate
+    with pytest.raises(TypeError):
+        gpu_collate([torch.zeros(4, 4, 3, device="cuda")], [torch.zeros(0, 5, device="cuda")], 8)
+    with pytest.raises(ValueError):
+        gpu_collate([], [], 8)
+
+
+def test_synthetic_module_raw_frames():
+    from objectdetectionpl_amd.dataset.Synthetic import SyntheticCocoModule
+    dm = SyntheticCocoModule(batch_size=3, img_size=96, num_classes=5, targets_per_image=2, steps_per_epoch=2, device="cuda:0", raw_frames=True)
+    batches = list(dm.train_dataloader())
+    assert len(batches) == 2
+    for x, y in batches:
+        assert x.shape == (3, 3, 96, 96) and y.shape == (6, 6)
+        assert float(x.min()) >= 0 and float(x.max()) <= 1
+        assert torch.equal(y[:, 0].cpu(), torch.tensor([0., 0., 1., 1., 2., 2.]))
+        assert bool(((y[:, 2:4] >= 0) & (y[:, 2:4] + y[:, 4:6] <= 1 + 1e-6)).all())
