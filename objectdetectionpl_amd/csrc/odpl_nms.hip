@@ -106,7 +106,8 @@ __global__ __launch_bounds__(kPrepT) void yolo_nms_prep_kernel(const YParams P) 
     }
 }
 
-__global__ __launch_bounds__(kImgT) void yolo_nms_image_kernel(const YParams P) {
+// Fallback (nv > kCap or more than kMaxCls classes): global-memory sort + one block-wide sweep per pivot.
+__device__ void yolo_nms_image_serial(const YParams& P) {
     __shared__ float s_red[6 * (kImgT / 64)];
     __shared__ int s_min[kImgT / 64];
     __shared__ int s_p;
@@ -165,6 +166,220 @@ __global__ __launch_bounds__(kImgT) void yolo_nms_image_kernel(const YParams P) 
         }
         __syncthreads();
         p = s_p; ++K;
+        __syncthreads();
+    }
+    if (tid == 0) { P.out_counts[b] = K; P.nvalid[b] = 0; }
+}
+
+constexpr int kCap = 16384;            // candidates per image sorted / bucketed in LDS (8 B each = 128 KB)
+constexpr int kMaxCls = 1024;
+constexpr int kRegE = 4;               // register-resident class lists: up to 64 * kRegE entries per wave
+
+__device__ __forceinline__ void bitonic_sort_lds(float* key, unsigned* idx, int npad) {
+    for (int k = 2; k <= npad; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < npad / 2; t += kImgT) {
+                const int i = ((t / j) * 2 * j) + (t % j), l = i + j;
+                const bool up = ((i & k) == 0);
+                const float ki = key[i], kl = key[l];
+                const unsigned ii = idx[i], il = idx[l];
+                const bool sw = up ? before(kl, il, ki, ii) : before(ki, ii, kl, il);
+                if (sw) { key[i] = kl; key[l] = ki; idx[i] = il; idx[l] = ii; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// Image kernel, class-parallel.  `invalid = IoU > thr & SAME LABEL` (YOLOV4.py:271-274) means a pivot only ever removes
+// boxes of its own class, so the reference's single sequential loop is the rank-ordered MERGE of independent per-class loops:
+//   1. stable compaction of the valid (score, index) pairs into LDS, LDS bitonic sort (score desc, index asc) -> global rank
+//   2. gather into rank order (global SoA), labels to LDS, class histogram + scan, per-class rank lists in LDS (ascending rank)
+//   3. one WAVE per class runs that class's pivot loop -- lists of <= 256 entries live in registers (no memory in the loop),
+//      longer ones walk LDS/L2 -- writes the merged row at the pivot's rank and raises its flag
+//   4. block scan over the flags compacts the rows in rank order = the reference's output order.
+// Sums are taken in a fixed order (lane partials in entry order, then one shuffle tree): reproducible run to run.
+__global__ __launch_bounds__(kImgT) void yolo_nms_image_kernel(const YParams P) {
+    extern __shared__ unsigned char s_dyn[];
+    __shared__ int s_cnt[kMaxCls];
+    __shared__ int s_off[kMaxCls];
+    __shared__ int s_wtot[kImgT / 64];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nv = P.nvalid[b], nc = P.no - 5;
+    if (nv == 0) {                                             // "continue": output[image_i] stays None
+        if (tid == 0) { P.out_counts[b] = -1; P.nvalid[b] = 0; }
+        return;
+    }
+    if (nv > kCap || nc > kMaxCls) { yolo_nms_image_serial(P); return; }
+    float* s_key = reinterpret_cast<float*>(s_dyn);
+    unsigned* s_idx = reinterpret_cast<unsigned*>(s_dyn + 4 * kCap);
+    const float* key = P.key + (size_t)b * P.Npad;
+    const unsigned* idx = P.idx + (size_t)b * P.Npad;
+    float* out = P.out + (size_t)b * P.N * 7;
+    const size_t o0 = (size_t)b * P.N;
+    const unsigned long long lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+    // ---- 1. compaction (index order) + sort
+    int base = 0;
+    for (int n0 = 0; n0 < P.N; n0 += kImgT) {
+        const int n = n0 + tid;
+        const bool v = n < P.N && idx[n] != 0xffffffffu;
+        const unsigned long long m = __ballot(v);
+        if (lane == 0) s_wtot[wv] = __popcll(m);
+        __syncthreads();
+        int woff = 0, tot = 0;
+        for (int w = 0; w < kImgT / 64; ++w) { const int c = s_wtot[w]; if (w < wv) woff += c; tot += c; }
+        if (v) { const int d = base + woff + __popcll(m & lt_mask); s_key[d] = key[n]; s_idx[d] = (unsigned)n; }
+        base += tot;
+        __syncthreads();
+    }
+    int npad = 2; while (npad < nv) npad <<= 1;
+    for (int r = nv + tid; r < npad; r += kImgT) { s_key[r] = -INFINITY; s_idx[r] = 0xffffffffu; }
+    __syncthreads();
+    bitonic_sort_lds(s_key, s_idx, npad);
+    // ---- 2. gather into rank order; labels, histogram, class offsets, class lists
+    for (int c = tid; c < kMaxCls; c += kImgT) s_cnt[c] = 0;
+    for (int r = tid; r < nv; r += kImgT) {
+        const unsigned n = s_idx[r];
+        P.sbox[o0 + r] = P.box[o0 + n]; P.sconf[o0 + r] = P.conf[o0 + n];
+        P.scconf[o0 + r] = P.cconf[o0 + n]; P.slabel[o0 + r] = P.label[o0 + n];
+    }
+    __syncthreads();                                            // s_key / s_idx are dead from here: the LDS block is re-cut
+    unsigned short* s_lab = reinterpret_cast<unsigned short*>(s_dyn);              // [kCap]  2 B
+    unsigned char* s_flag = reinterpret_cast<unsigned char*>(s_dyn + 2 * kCap);    // [kCap]  1 B
+    int* s_list = reinterpret_cast<int*>(s_dyn + 4 * kCap);                        // [kCap]  4 B
+    for (int r = tid; r < nv; r += kImgT) {
+        const int l = P.slabel[o0 + r];                         // written by this very thread above
+        s_lab[r] = (unsigned short)l; s_flag[r] = 0;
+        atomicAdd(&s_cnt[l], 1);
+    }
+    __syncthreads();
+    {   // exclusive scan of the class counts (kMaxCls == kImgT: one class per thread)
+        const int c = s_cnt[tid];
+        int inc = c;
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+        if (lane == 63) s_wtot[wv] = inc;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wv; ++w) woff += s_wtot[w];
+        s_off[tid] = woff + inc - c;
+        __syncthreads();
+    }
+    // ---- 3. per-class pivot loops, one wave per class
+    const float4* sbox = P.sbox + o0; const float* sconf = P.sconf + o0; const float* scconf = P.scconf + o0;
+    for (int c = wv; c < nc; c += kImgT / 64) {
+        const int m = s_cnt[c];
+        if (m == 0) continue;
+        int* list = s_list + s_off[c];
+        int run = 0;
+        for (int r0 = 0; r0 < nv && run < m; r0 += 64) {        // ranks of this class, ascending
+            const int r = r0 + lane;
+            const bool hit = r < nv && s_lab[r] == (unsigned short)c;
+            const unsigned long long mk = __ballot(hit);
+            if (hit) list[run + __popcll(mk & lt_mask)] = r;
+            run += __popcll(mk);
+        }
+        __threadfence_block();
+        if (m <= 64 * kRegE) {
+            float4 bx[kRegE]; float cf[kRegE], ccf[kRegE]; int rk[kRegE];
+            unsigned long long am[kRegE];
+#pragma unroll
+            for (int u = 0; u < kRegE; ++u) {
+                const int e = lane + 64 * u;
+                const bool in = e < m;
+                rk[u] = in ? list[e] : 0;
+                bx[u] = in ? sbox[rk[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
+                cf[u] = in ? sconf[rk[u]] : 0.f; ccf[u] = in ? scconf[rk[u]] : 0.f;
+                am[u] = __ballot(in);
+            }
+            for (;;) {
+                int pu = -1;
+#pragma unroll
+                for (int u = kRegE - 1; u >= 0; --u) if (am[u]) pu = u;
+                if (pu < 0) break;
+                float4 tb = make_float4(0.f, 0.f, 0.f, 0.f); float tcf = 0.f, tccf = 0.f; int trk = 0, pl = 0;
+#pragma unroll
+                for (int u = 0; u < kRegE; ++u) if (u == pu) {
+                    pl = __ffsll((long long)am[u]) - 1;
+                    tb.x = __shfl(bx[u].x, pl, 64); tb.y = __shfl(bx[u].y, pl, 64); tb.z = __shfl(bx[u].z, pl, 64); tb.w = __shfl(bx[u].w, pl, 64);
+                    tcf = __shfl(cf[u], pl, 64); tccf = __shfl(ccf[u], pl, 64); trk = __shfl(rk[u], pl, 64);
+                }
+                Box4 top; top.x1 = tb.x; top.y1 = tb.y; top.x2 = tb.z; top.y2 = tb.w;
+                float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < kRegE; ++u) {
+                    Box4 bj; bj.x1 = bx[u].x; bj.y1 = bx[u].y; bj.x2 = bx[u].z; bj.y2 = bx[u].w;
+                    const bool inv = ((am[u] >> lane) & 1ull) && (iou_plus1(top, bj) > P.nms_thres);      // YOLOV4.py:271-274
+                    if (inv) { const float w = cf[u]; acc[0] += w; acc[1] += w * bx[u].x; acc[2] += w * bx[u].y; acc[3] += w * bx[u].z; acc[4] += w * bx[u].w; }
+                    am[u] &= ~__ballot(inv);
+                }
+#pragma unroll
+                for (int u = 0; u < kRegE; ++u) if (u == pu) am[u] &= ~(1ull << pl);                       // the pivot is always retired
+#pragma unroll
+                for (int i = 0; i < 5; ++i) acc[i] = wave_sum(acc[i]);
+                if (lane == 0) {
+                    float* row = out + (size_t)trk * 7;                                                    // YOLOV4.py:275-279
+                    row[0] = acc[1] / acc[0]; row[1] = acc[2] / acc[0]; row[2] = acc[3] / acc[0]; row[3] = acc[4] / acc[0];
+                    row[4] = tcf; row[5] = tccf; row[6] = (float)c;
+                    s_flag[trk] = 1;
+                }
+            }
+        } else {
+            int first = 0;
+            for (;;) {
+                int p = -1;
+                for (int i0 = first; i0 < m; i0 += 64) {
+                    const int i = i0 + lane;
+                    const unsigned long long mk = __ballot(i < m && list[i] >= 0);
+                    if (mk) { p = i0 + __ffsll((long long)mk) - 1; break; }
+                }
+                if (p < 0) break;
+                const int rp = list[p];
+                const float4 tb = sbox[rp];
+                Box4 top; top.x1 = tb.x; top.y1 = tb.y; top.x2 = tb.z; top.y2 = tb.w;
+                float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+                for (int i = p + lane; i < m; i += 64) {
+                    const int r = list[i];
+                    if (r < 0) continue;
+                    const float4 q = sbox[r];
+                    Box4 bj; bj.x1 = q.x; bj.y1 = q.y; bj.x2 = q.z; bj.y2 = q.w;
+                    if (iou_plus1(top, bj) > P.nms_thres) {
+                        const float w = sconf[r];
+                        acc[0] += w; acc[1] += w * q.x; acc[2] += w * q.y; acc[3] += w * q.z; acc[4] += w * q.w;
+                        list[i] = ~r;
+                    }
+                }
+                __threadfence_block();
+                if (lane == 0 && list[p] >= 0) list[p] = ~rp;                                             // the pivot is always retired
+#pragma unroll
+                for (int i = 0; i < 5; ++i) acc[i] = wave_sum(acc[i]);
+                if (lane == 0) {
+                    float* row = out + (size_t)rp * 7;
+                    row[0] = acc[1] / acc[0]; row[1] = acc[2] / acc[0]; row[2] = acc[3] / acc[0]; row[3] = acc[4] / acc[0];
+                    row[4] = sconf[rp]; row[5] = scconf[rp]; row[6] = (float)c;
+                    s_flag[rp] = 1;
+                }
+                __threadfence_block();
+                first = p + 1;
+            }
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- 4. rows were written at their pivot's rank; compact them in rank order (destination <= source: chunked, read-then-write)
+    int K = 0;
+    for (int r0 = 0; r0 < nv; r0 += kImgT) {
+        const int r = r0 + tid;
+        const bool f = r < nv && s_flag[r];
+        float row[7];
+        if (f) { for (int i = 0; i < 7; ++i) row[i] = out[(size_t)r * 7 + i]; }
+        const unsigned long long mk = __ballot(f);
+        if (lane == 0) s_wtot[wv] = __popcll(mk);
+        __syncthreads();
+        int woff = 0, tot = 0;
+        for (int w = 0; w < kImgT / 64; ++w) { const int cw = s_wtot[w]; if (w < wv) woff += cw; tot += cw; }
+        if (f) { float* d = out + (size_t)(K + woff + __popcll(mk & lt_mask)) * 7; for (int i = 0; i < 7; ++i) d[i] = row[i]; }
+        K += tot;
+        __threadfence_block();
         __syncthreads();
     }
     if (tid == 0) { P.out_counts[b] = K; P.nvalid[b] = 0; }
@@ -232,7 +447,12 @@ extern "C" int odpl_yolo_nms(const odpl_yolo_nms_desc_t* d, void* workspace, siz
     prof_end(ODPL_PROF_YOLO_NMS_PREP, stream);
     ODPL_HIP_TRY(hipGetLastError());
     prof_begin(ODPL_PROF_YOLO_NMS_IMAGE, stream);
-    hipLaunchKernelGGL(yolo_nms_image_kernel, dim3(d->B), dim3(kImgT), 0, stream, P);
+    static bool lds_attr_set = false;                          // 128 KB of dynamic LDS needs the opt-in once per process
+    if (!lds_attr_set) {
+        ODPL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(yolo_nms_image_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * kCap));
+        lds_attr_set = true;
+    }
+    hipLaunchKernelGGL(yolo_nms_image_kernel, dim3(d->B), dim3(kImgT), 8 * kCap, stream, P);
     prof_end(ODPL_PROF_YOLO_NMS_IMAGE, stream);
     ODPL_HIP_TRY(hipGetLastError());
     return 0;

@@ -85,3 +85,54 @@ def test_yolo_nms_config2_size_vs_oracle():
         assert o.shape == r.shape
         assert torch.equal(o[:, 4:], r[:, 4:])
         assert torch.allclose(o[:, :4], r[:, :4], rtol=1e-5, atol=1e-3)
+
+
+def _clustered_heads(g, B, C, grids, conf_shift, spread=40.0):
+    heads = []
+    for G in grids:
+        h = torch.randn(B, 3, 5 + C, G, G, generator=g)
+        centres = torch.rand(B, 3, 2, 1, 1, generator=g) * 300 + 50
+        h[:, :, 0:2] = centres + torch.randn(B, 3, 2, G, G, generator=g) * spread
+        h[:, :, 2:4] = torch.rand(B, 3, 2, G, G, generator=g) * 80 + 20
+        h[:, :, 4] = torch.randn(B, 3, G, G, generator=g) * 0.8 + conf_shift
+        h[:, :, 5:] = torch.rand(B, 3, C, G, G, generator=g)
+        heads.append(h.view(B, 3 * (5 + C), G, G).contiguous())
+    return heads
+
+
+def _same_as_oracle(heads, **kw):
+    from objectdetectionpl_amd.LightningFunc.nms import yolo_non_max_suppression
+    ref = oracle_nms.yolo_weighted_nms(heads, **kw)
+    out = yolo_non_max_suppression([h.cuda() for h in heads], **kw)
+    for r, o in zip(ref, out):
+        if r is None:
+            assert o is None
+            continue
+        o = o.cpu()
+        assert o.shape == r.shape
+        assert torch.equal(o[:, 4:], r[:, 4:])
+        assert torch.allclose(o[:, :4], r[:, :4], rtol=1e-5, atol=1e-3)
+
+
+def test_yolo_nms_long_class_lists():
+    """Two classes and ~1500 valid candidates per image: per-class lists far above the 256 register-resident entries,
+    so the LDS/L2 walk of the class-parallel kernel runs (and many merges per pivot)."""
+    g = torch.Generator().manual_seed(67)
+    _same_as_oracle(_clustered_heads(g, 2, 2, (26, 13), conf_shift=0.3, spread=25.0))
+
+
+def test_yolo_nms_single_class_and_sparse():
+    g = torch.Generator().manual_seed(68)
+    _same_as_oracle(_clustered_heads(g, 2, 1, (13,), conf_shift=-0.5))
+    heads = _clustered_heads(g, 3, 20, (13, 7), conf_shift=-3.5)       # a handful of valid candidates, or none, per image
+    heads[0][1, :, :] = heads[0][1, :, :].clone()
+    heads[0].view(3, 3, 25, 13, 13)[1, :, 4] = -9.0                      # image 1: nothing valid on this scale ...
+    heads[1].view(3, 3, 25, 7, 7)[1, :, 4] = -9.0                        # ... nor on this one -> None
+    _same_as_oracle(heads)
+
+
+def test_yolo_nms_more_valid_candidates_than_the_lds_sort_holds():
+    """19 200 candidates, all valid (> 16 384): the kernel's global-memory fallback path."""
+    g = torch.Generator().manual_seed(69)
+    heads = _clustered_heads(g, 1, 3, (80,), conf_shift=4.0, spread=15.0)
+    _same_as_oracle(heads)

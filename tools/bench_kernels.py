@@ -112,7 +112,12 @@ def main():
     cells5 = sum(B * 3 * G * G for G in (80, 40, 20))
     measure("config5 YOLOv5 loss fwd+bwd (B=32, C=80, 640^2, fp32)", ["yolov5_dense"], lambda: c5(h5, t5),
             {"yolov5_dense": 4 * cells5 * 85 + 12 * cells5}, {"yolov5_dense": "grad write + objectness gather + owner map read/reset"})
+    h5b = [h.detach().bfloat16().requires_grad_() for h in h5]
+    del h5
+    measure("config5 YOLOv5 loss fwd+bwd (B=32, C=80, 640^2, bf16 heads -- the BASELINE dtype)", ["yolov5_dense"], lambda: c5(h5b, t5),
+            {"yolov5_dense": 2 * cells5 * 85 + 10 * cells5}, {"yolov5_dense": "bf16 grad write + objectness gather + owner map read/reset"})
 
 
 if __name__ == "__main__":
     main()
+
