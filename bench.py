@@ -137,6 +137,11 @@ def main():
                  f"(WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+    # REHEARSAL ONLY: ODPL_BENCH_BACKEND=gloo lets several ranks share one GPU (RCCL refuses duplicate devices) so that the
+    # multi-process control flow can be exercised on a 1-GPU box; the judged runs use the default, RCCL ("nccl").
+    backend = os.environ.get("ODPL_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_ddp = world > 1 or a.force_ddp
@@ -146,7 +151,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from objectdetectionpl_amd import _lib
     from objectdetectionpl_amd.model.YOLOV4 import YOLOv4
@@ -214,6 +222,26 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
 
+    allreduce = None
+    if use_ddp and world > 1:       # bus bandwidth of the gradient all-reduce, measured OUTSIDE the timed region
+        nparam = sum(p.numel() for p in model.parameters())
+        flat = torch.zeros(nparam, dtype=torch.float32, device=dev)
+        for _ in range(2):
+            dist.all_reduce(flat)
+        fence()
+        t1 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            dist.all_reduce(flat)
+        fence()
+        ar = torch.tensor([(time.perf_counter() - t1) / reps], dtype=torch.float64, device=dev)
+        dist.all_reduce(ar, op=dist.ReduceOp.MAX)
+        ar_s = float(ar.item())
+        allreduce = {"bytes": 4 * nparam, "ms": round(1e3 * ar_s, 3), "backend": backend,
+                     "bus_GBps": round(2 * (world - 1) / world * 4 * nparam / ar_s / 1e9, 1),
+                     "note": "one unbucketed fp32 all-reduce of all gradients, not overlapped; in the step it is bucketed and hidden under backward"}
+        del flat
+
     if rank == 0:
         CH = 5 + a.classes
         cells = sum(a.batch * 3 * G * G for G in (a.img // 8, a.img // 16, a.img // 32))
@@ -249,6 +277,8 @@ def main():
                          **({"in_kernel_stamp_us": round(sorted(stamps)[len(stamps) // 2], 2)} if stamps else {}),
                          "algorithmic_bytes": alg_bytes, "survey_8d_bytes": 2 * 4 * cells * CH},
         }
+        if allreduce is not None:
+            res["allreduce"] = allreduce
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a.cpu_sample_batch, a.classes, a.img, a.cpu_sample_steps)
         print(json.dumps(res), flush=True)
