@@ -324,6 +324,10 @@ int odpl_collate_images(const odpl_image_t* host_images, int32_t B, int32_t S, f
 int odpl_collate_targets(const float* objects, const int32_t* row_image, const int32_t* image_dims, int32_t nT,
                          int32_t S, float* y, void* stream);
 
+/* Bias gradient of a convolution from an NCHW-dense output gradient [B, C, HW]: grad_bias[c] = sum over (b, hw)
+ * (what ATen's convolution_backward computes with sum((0, 2, 3)); the linear head convs of model/YOLOV4.py:89-127). */
+int odpl_bias_grad_nchw(const float* grad_y, int32_t B, int32_t C, int64_t HW, float* grad_bias, void* stream);
+
 /* ---- space-to-depth shuffles next to the stems/heads ------------------------------------------ */
 /* Focus, utils/YoloV5Utils.py:117-125: y[b, g*C+c, i, j] = x[b, c, 2i+(g&1), 2j+(g>>1)]; x is [B,C,H,W], y is
  * [B,4C,H/2,W/2]; element strides (b,c,h,w) of dense tensors in any memory format.  inverse = 0: src = x, dst = y;
@@ -348,6 +352,13 @@ int odpl_bn_act_forward(const float* x, int64_t R, int32_t C, const float* gamma
                         float* running_mean, float* running_var, int32_t training, float momentum, float eps,
                         int32_t act, float* save_mean, float* save_invstd, float* y, void* workspace,
                         size_t workspace_bytes, int64_t* num_batches_tracked /* device int64[1] or NULL: += 1 */, void* stream);
+/* Same, with the residual add of the reference's ResBlock (utils/YoloV4Utils.py:239-262: `x = x + h`) folded into the
+ * write: y = act(bn(x)) + residual (residual: same layout as y, or NULL).  Backward is unchanged: the residual's gradient
+ * is grad_y itself. */
+int odpl_bn_act_forward_residual(const float* x, const float* residual, int64_t R, int32_t C, const float* gamma, const float* beta,
+                                 float* running_mean, float* running_var, int32_t training, float momentum, float eps,
+                                 int32_t act, float* save_mean, float* save_invstd, float* y, void* workspace,
+                                 size_t workspace_bytes, int64_t* num_batches_tracked, void* stream);
 int odpl_bn_act_backward(const float* x, const float* grad_y, int64_t R, int32_t C, const float* gamma, const float* beta,
                          const float* save_mean, const float* save_invstd, int32_t training, int32_t act,
                          float* grad_x, float* grad_gamma, float* grad_beta, void* workspace, size_t workspace_bytes,

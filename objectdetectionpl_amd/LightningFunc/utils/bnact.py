@@ -65,14 +65,45 @@ class _BnActFn(torch.autograd.Function):
         return gx, dg, db, None, None, None, None, None, None, None
 
 
-def bn_act(x, bn, act):
-    """act(bn(x)) for a channels-last fp32 tensor and an nn.BatchNorm2d module (its buffers are updated like
+def bn_act(x, bn, act, residual=None):
+    """act(bn(x)) [+ residual] for a channels-last fp32 tensor and an nn.BatchNorm2d module (its buffers are updated like
     nn.BatchNorm2d does in training mode).  Uses the C++ binding when built (10x less host time per call)."""
     ext = _lib.torch_ext()
     if ext is not None:
         y = ext.bn_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.training,
-                       bn.momentum, bn.eps, ACT[act])
+                       bn.momentum, bn.eps, ACT[act], residual)
         if y is not None:
             return y
+    if residual is not None:
+        return residual + bn_act(x, bn, act)
     return _BnActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.momentum, bn.eps, ACT[act],
                           bn.num_batches_tracked)
+
+
+class _BiasAddFn(torch.autograd.Function):
+    """z + bias[None, :, None, None] in place; backward sums the (NCHW-dense) output gradient per channel with one HIP
+    launch instead of ATen's `sum((0, 2, 3))` (0.2-0.5 ms on the head shapes)."""
+
+    @staticmethod
+    def forward(ctx, z, bias):
+        ctx.mark_dirty(z)
+        z.add_(bias.view(1, -1, 1, 1))
+        return z
+
+    @staticmethod
+    def backward(ctx, gy):
+        if gy.is_cuda and gy.dtype == torch.float32 and gy.is_contiguous():
+            B, C, H, W = gy.shape
+            gb = torch.empty(C, dtype=torch.float32, device=gy.device)
+            _lib.check(_lib.lib().odpl_bias_grad_nchw(_lib.ptr(gy), B, C, H * W, _lib.ptr(gb), _lib.current_stream(gy.device)),
+                       "odpl_bias_grad_nchw")
+        else:
+            gb = gy.sum((0, 2, 3))
+        return gy, gb
+
+
+def conv_bias(x, conv):
+    """`conv(x)` for an nn.Conv2d with a bias (the linear head convs, `model/YOLOV4.py:89-127`): bias-free convolution on
+    MIOpen, bias added in place, bias gradient by the HIP channel-sum kernel."""
+    z = torch.nn.functional.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+    return _BiasAddFn.apply(z, conv.bias)

@@ -48,6 +48,7 @@ struct BnParams {
     const float* gamma; const float* beta;
     float* mean; float* invstd;                  // [C] batch statistics (saved for backward)
     float* running_mean; float* running_var;     // [C] or null
+    const float* res;                            // optional residual added after the activation (same layout as y)
     double* part;                                // [nblk][C][2]
     float* dgamma; float* dbeta;                 // [C]
     long long* num_batches_tracked;              // nn.BatchNorm2d buffer, +1 per training forward (or null)
@@ -174,6 +175,7 @@ __global__ __launch_bounds__(kT) void bn_apply_kernel(const BnParams P) {
         float4 o;
         o.x = act_fwd(ga.x * ((v.x - mu.x) * is.x) + be.x, P.act); o.y = act_fwd(ga.y * ((v.y - mu.y) * is.y) + be.y, P.act);
         o.z = act_fwd(ga.z * ((v.z - mu.z) * is.z) + be.z, P.act); o.w = act_fwd(ga.w * ((v.w - mu.w) * is.w) + be.w, P.act);
+        if (P.res) { const float4 r = reinterpret_cast<const float4*>(P.res)[i]; o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
         reinterpret_cast<float4*>(P.y)[i] = o;
     }
 }
@@ -199,6 +201,34 @@ __global__ __launch_bounds__(kT) void bn_bwd_dx_kernel(const BnParams P) {
     }
 }
 
+// Bias gradient of a conv whose output gradient is NCHW-dense (the three linear head convs: the region loss hands
+// its gradient back in the heads' own NCHW layout).  ATen's sum over (0, 2, 3) takes 0.2-0.5 ms on these shapes
+// (255 outputs => a few workgroups); here one workgroup per channel streams its B planes, double accumulation,
+// fixed-order block reduction (bitwise reproducible).
+__global__ __launch_bounds__(kT) void bias_grad_nchw_kernel(const float* __restrict__ g, int B, int C, long long HW, float* __restrict__ out) {
+    __shared__ double sh[kT / 64];
+    const int c = blockIdx.x;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    for (int b = 0; b < B; ++b) {
+        const float* p = g + ((long long)b * C + c) * HW;
+        long long i = threadIdx.x;
+        for (; i + 3LL * kT < HW; i += 4LL * kT) {             // four independent loads in flight per lane
+            const float v0 = p[i], v1 = p[i + kT], v2 = p[i + 2 * kT], v3 = p[i + 3 * kT];
+            a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+        }
+        for (; i < HW; i += kT) a0 += p[i];
+    }
+    double a = (a0 + a1) + (a2 + a3);
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0;
+        for (int w = 0; w < kT / 64; ++w) t += sh[w];
+        out[c] = (float)t;
+    }
+}
+
 bool plan(long long R, int C, int* rows_per_blk, int* nblk, size_t* lds) {
     if (R < 1 || C < 4 || (C & 3)) return false;
     long long rpb = R / 1024; if (rpb < 16) rpb = 16; if (rpb > 512) rpb = 512;
@@ -220,12 +250,20 @@ extern "C" int odpl_bn_act_forward(const float* x, int64_t R, int32_t C, const f
                                    float* running_mean, float* running_var, int32_t training, float momentum, float eps,
                                    int32_t act, float* save_mean, float* save_invstd, float* y, void* workspace,
                                    size_t workspace_bytes, int64_t* num_batches_tracked, void* stream_) {
+    return odpl_bn_act_forward_residual(x, nullptr, R, C, gamma, beta, running_mean, running_var, training, momentum, eps, act,
+                                        save_mean, save_invstd, y, workspace, workspace_bytes, num_batches_tracked, stream_);
+}
+
+extern "C" int odpl_bn_act_forward_residual(const float* x, const float* residual, int64_t R, int32_t C, const float* gamma, const float* beta,
+                                            float* running_mean, float* running_var, int32_t training, float momentum, float eps,
+                                            int32_t act, float* save_mean, float* save_invstd, float* y, void* workspace,
+                                            size_t workspace_bytes, int64_t* num_batches_tracked, void* stream_) {
     int rpb, nblk; size_t lds;
     if (!x || !y || !gamma || !beta || !save_mean || !save_invstd || !plan(R, C, &rpb, &nblk, &lds)) return ODPL_EINVAL;
-    if (act < 0 || act > 3 || (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)save_mean | (uintptr_t)save_invstd) & 15)) return ODPL_EINVAL;
+    if (act < 0 || act > 3 || (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)save_mean | (uintptr_t)save_invstd | (uintptr_t)residual) & 15)) return ODPL_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
     BnParams P = {};
-    P.x = x; P.y = y; P.gamma = gamma; P.beta = beta; P.mean = save_mean; P.invstd = save_invstd;
+    P.x = x; P.y = y; P.res = residual; P.gamma = gamma; P.beta = beta; P.mean = save_mean; P.invstd = save_invstd;
     P.running_mean = running_mean; P.running_var = running_var; P.R = R; P.C = C; P.act = act; P.nblk = nblk;
     P.rows_per_blk = rpb; P.training = training; P.eps = eps; P.momentum = momentum; P.part = (double*)workspace;
     P.num_batches_tracked = (long long*)num_batches_tracked;
@@ -264,6 +302,13 @@ extern "C" int odpl_bn_act_backward(const float* x, const float* grad_y, int64_t
     const long long n4 = R * (C >> 2);
     long long blocks = (n4 + kT - 1) / kT; if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(bn_bwd_dx_kernel, dim3((unsigned)blocks), dim3(kT), 0, stream, P);
+    ODPL_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int odpl_bias_grad_nchw(const float* grad_y, int32_t B, int32_t C, int64_t HW, float* grad_bias, void* stream_) {
+    if (!grad_y || !grad_bias || B < 1 || C < 1 || HW < 1) return ODPL_EINVAL;
+    hipLaunchKernelGGL(bias_grad_nchw_kernel, dim3(C), dim3(kT), 0, (hipStream_t)stream_, grad_y, B, C, (long long)HW, grad_bias);
     ODPL_HIP_TRY(hipGetLastError());
     return 0;
 }

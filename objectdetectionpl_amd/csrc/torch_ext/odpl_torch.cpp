@@ -20,7 +20,8 @@ bool fusable(const Tensor& x, const Tensor& w) {
 
 struct BnActFn : public torch::autograd::Function<BnActFn> {
     static Tensor forward(AutogradContext* ctx, Tensor x, Tensor weight, Tensor bias, Tensor running_mean, Tensor running_var,
-                          Tensor nbt, bool training, double momentum, double eps, int64_t act) {
+                          Tensor nbt, bool training, double momentum, double eps, int64_t act, c10::optional<Tensor> residual_opt) {
+        const Tensor residual = residual_opt.has_value() ? *residual_opt : Tensor();
         const int64_t C = x.size(1), R = x.numel() / C;
         auto y = at::empty_like(x);
         Tensor mean, invstd;
@@ -34,7 +35,8 @@ struct BnActFn : public torch::autograd::Function<BnActFn> {
         const size_t need = odpl_bn_act_workspace_bytes(R, (int32_t)C);
         auto ws = at::empty({(int64_t)need}, x.options().dtype(at::kByte));
         auto stream = c10::hip::getCurrentHIPStream(x.device().index()).stream();
-        check(odpl_bn_act_forward(x.data_ptr<float>(), R, (int32_t)C, weight.data_ptr<float>(), bias.data_ptr<float>(),
+        check(odpl_bn_act_forward_residual(x.data_ptr<float>(), residual.defined() ? residual.data_ptr<float>() : nullptr, R, (int32_t)C,
+                                  weight.data_ptr<float>(), bias.data_ptr<float>(),
                                   running_mean.data_ptr<float>(), running_var.data_ptr<float>(), training ? 1 : 0, (float)momentum,
                                   (float)eps, (int32_t)act, mean.data_ptr<float>(), invstd.data_ptr<float>(), y.data_ptr<float>(),
                                   ws.data_ptr(), need, (training && nbt.defined()) ? nbt.data_ptr<int64_t>() : nullptr, stream),
@@ -42,6 +44,7 @@ struct BnActFn : public torch::autograd::Function<BnActFn> {
         ctx->save_for_backward({x, weight, bias, mean, invstd});
         ctx->saved_data["training"] = training;
         ctx->saved_data["act"] = act;
+        ctx->saved_data["has_res"] = residual.defined();
         return y;
     }
 
@@ -63,18 +66,27 @@ struct BnActFn : public torch::autograd::Function<BnActFn> {
         check(odpl_bn_act_backward(x.data_ptr<float>(), gy.data_ptr<float>(), R, (int32_t)C, weight.data_ptr<float>(), bias.data_ptr<float>(),
                                    mean.data_ptr<float>(), invstd.data_ptr<float>(), training ? 1 : 0, (int32_t)act, gx.data_ptr<float>(),
                                    dg.data_ptr<float>(), db.data_ptr<float>(), ws.data_ptr(), need, stream), "odpl_bn_act_backward");
-        return {gx, dg, db, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+        return {gx, dg, db, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(),
+                ctx->saved_data["has_res"].toBool() ? grads[0] : Tensor()};
     }
 };
 
 // act(bn(x)); falls back to ATen (returns an undefined tensor) when the layout is not fusable
 Tensor bn_act(Tensor x, Tensor weight, Tensor bias, Tensor running_mean, Tensor running_var, Tensor num_batches_tracked,
-              bool training, double momentum, double eps, int64_t act) {
+              bool training, double momentum, double eps, int64_t act, c10::optional<Tensor> residual) {
     if (!fusable(x, weight)) return Tensor();
-    return BnActFn::apply(x, weight, bias, running_mean, running_var, num_batches_tracked, training, momentum, eps, act);
+    c10::optional<Tensor> res;
+    if (residual.has_value() && residual->defined()) {
+        res = *residual;
+        if (res->sizes() != x.sizes() || res->scalar_type() != at::kFloat || !res->is_contiguous(at::MemoryFormat::ChannelsLast)) return Tensor();
+    }
+    return BnActFn::apply(x, weight, bias, running_mean, running_var, num_batches_tracked, training, momentum, eps, act, res);
 }
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
-    m.def("bn_act", &bn_act, "fused BatchNorm2d + activation (channels-last fp32); returns None when not fusable");
+    m.def("bn_act", &bn_act, "fused BatchNorm2d + activation [+ residual] (channels-last fp32); returns None when not fusable",
+          pybind11::arg("x"), pybind11::arg("weight"), pybind11::arg("bias"), pybind11::arg("running_mean"), pybind11::arg("running_var"),
+          pybind11::arg("num_batches_tracked"), pybind11::arg("training"), pybind11::arg("momentum"), pybind11::arg("eps"), pybind11::arg("act"),
+          pybind11::arg("residual") = c10::optional<Tensor>());
 }

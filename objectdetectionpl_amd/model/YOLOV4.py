@@ -44,8 +44,21 @@ class ConvUnit(nn.Module):
             raise ValueError(act)
         self.conv = nn.ModuleList(layers)
         self._act = act if bn else None
+        self._plain_bias = (not bn) and bias and act == "linear"
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
+        """act(bn(conv(x))) [+ residual]: the skip add of a ResBlock rides on the epilogue's write."""
+        if residual is not None:
+            if self._act is not None and ConvUnit.fuse_epilogue:
+                z = self.conv[0](x)
+                if _bnact.fusable(z, self.conv[1]):
+                    return _bnact.bn_act(z, self.conv[1], self._act, residual)
+                for l in list(self.conv)[1:]:
+                    z = l(z)
+                return residual + z
+            return residual + self.forward(x)
+        if self._plain_bias and ConvUnit.fuse_epilogue and x.is_cuda and x.dtype == torch.float32:
+            return _bnact.conv_bias(x, self.conv[0])                 # head conv: bias gradient by the HIP channel sum
         if self._act is not None and ConvUnit.fuse_epilogue:
             z = self.conv[0](x)
             if _bnact.fusable(z, self.conv[1]):
@@ -71,7 +84,7 @@ class ResChain(nn.Module):
 
     def forward(self, x):
         for a, b in self.module_list:
-            x = x + b(a(x))
+            x = b(a(x), residual=x)
         return x
 
 
@@ -89,7 +102,7 @@ class CSPFirst(nn.Module):
         x2 = self.conv2(self.conv1(x))
         x3 = self.conv3(x2)
         x4 = self.conv4(x2)
-        x6 = self.conv6(self.conv5(x4)) + x4
+        x6 = self.conv6(self.conv5(x4), residual=x4)
         return self.conv8(torch.cat([self.conv7(x6), x3], 1))
 
 
