@@ -107,3 +107,14 @@ def conv_bias(x, conv):
     MIOpen, bias added in place, bias gradient by the HIP channel-sum kernel."""
     z = torch.nn.functional.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
     return _BiasAddFn.apply(z, conv.bias)
+
+
+def bn_act_cat(x1, bn1, act1, x2, bn2, act2):
+    """`torch.cat((act1(bn1(x1)), act2(bn2(x2))), 1)` with both epilogues writing their column slice of the result (no cat
+    copy forward, no slice copies backward).  Returns None when the C++ binding is absent or the layout is not fusable."""
+    ext = _lib.torch_ext()
+    if ext is None or bn1.training != bn2.training:
+        return None
+    return ext.bn_act_cat(x1, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, bn1.num_batches_tracked, bn1.momentum, bn1.eps, ACT[act1],
+                          x2, bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var, bn2.num_batches_tracked, bn2.momentum, bn2.eps, ACT[act2],
+                          bn1.training)

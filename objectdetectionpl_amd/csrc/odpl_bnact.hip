@@ -53,6 +53,7 @@ struct BnParams {
     float* dgamma; float* dbeta;                 // [C]
     long long* num_batches_tracked;              // nn.BatchNorm2d buffer, +1 per training forward (or null)
     long long R; int C, act, nblk, rows_per_blk, training;
+    long long y_rs4, gy_rs4;                     // row strides of y / grad_y in float4 units (== C/4 when dense)
     float eps, momentum;
 };
 
@@ -94,14 +95,14 @@ __global__ __launch_bounds__(kT) void bn_reduce_kernel(const BnParams P) {
             for (; r + 3LL * rows_par < r1; r += 4LL * rows_par) {
                 float4 v[4], g[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { v[u] = x4[(r + (long long)u * rows_par) * c4n + q]; if (BWD) g[u] = g4[(r + (long long)u * rows_par) * c4n + q]; }
+                for (int u = 0; u < 4; ++u) { v[u] = x4[(r + (long long)u * rows_par) * c4n + q]; if (BWD) g[u] = g4[(r + (long long)u * rows_par) * P.gy_rs4 + q]; }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) body(v[u], g[u]);
             }
             for (; r < r1; r += rows_par) {
                 const float4 v = x4[r * c4n + q];
                 float4 g = v;
-                if (BWD) g = g4[r * c4n + q];
+                if (BWD) g = g4[r * P.gy_rs4 + q];
                 body(v, g);
             }
         }
@@ -166,9 +167,11 @@ __global__ __launch_bounds__(kT) void bn_apply_kernel(const BnParams P) {
     const int c4n = P.C >> 2;
     const long long n4 = P.R * c4n, stride = (long long)gridDim.x * kT;
     const unsigned sq = (unsigned)(stride % c4n);            // the channel quad advances by a constant per iteration
+    const long long sr = stride / c4n;                       // ... and the row by a constant (+1 on wrap)
     long long i = (long long)blockIdx.x * kT + threadIdx.x;
     unsigned q = (unsigned)(i % c4n);
-    for (; i < n4; i += stride, q = (q + sq >= (unsigned)c4n) ? q + sq - c4n : q + sq) {
+    long long r = i / c4n;
+    for (; i < n4; i += stride) {
         const float4 v = reinterpret_cast<const float4*>(P.x)[i];
         const float4 mu = reinterpret_cast<const float4*>(P.mean)[q], is = reinterpret_cast<const float4*>(P.invstd)[q];
         const float4 ga = reinterpret_cast<const float4*>(P.gamma)[q], be = reinterpret_cast<const float4*>(P.beta)[q];
@@ -176,7 +179,9 @@ __global__ __launch_bounds__(kT) void bn_apply_kernel(const BnParams P) {
         o.x = act_fwd(ga.x * ((v.x - mu.x) * is.x) + be.x, P.act); o.y = act_fwd(ga.y * ((v.y - mu.y) * is.y) + be.y, P.act);
         o.z = act_fwd(ga.z * ((v.z - mu.z) * is.z) + be.z, P.act); o.w = act_fwd(ga.w * ((v.w - mu.w) * is.w) + be.w, P.act);
         if (P.res) { const float4 r = reinterpret_cast<const float4*>(P.res)[i]; o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
-        reinterpret_cast<float4*>(P.y)[i] = o;
+        reinterpret_cast<float4*>(P.y)[r * P.y_rs4 + q] = o;
+        q += sq; r += sr;
+        if (q >= (unsigned)c4n) { q -= c4n; ++r; }
     }
 }
 
@@ -185,10 +190,12 @@ __global__ __launch_bounds__(kT) void bn_bwd_dx_kernel(const BnParams P) {
     const long long n4 = P.R * c4n, stride = (long long)gridDim.x * kT;
     const float invR = P.training ? (float)(1.0 / (double)P.R) : 0.0f;     // eval mode: statistics are constants
     const unsigned sq = (unsigned)(stride % c4n);
+    const long long sr = stride / c4n;
     long long i = (long long)blockIdx.x * kT + threadIdx.x;
     unsigned q = (unsigned)(i % c4n);
-    for (; i < n4; i += stride, q = (q + sq >= (unsigned)c4n) ? q + sq - c4n : q + sq) {
-        const float4 v = reinterpret_cast<const float4*>(P.x)[i], g = reinterpret_cast<const float4*>(P.gy)[i];
+    long long r = i / c4n;
+    for (; i < n4; i += stride) {
+        const float4 v = reinterpret_cast<const float4*>(P.x)[i], g = reinterpret_cast<const float4*>(P.gy)[r * P.gy_rs4 + q];
         const float4 mu = reinterpret_cast<const float4*>(P.mean)[q], is = reinterpret_cast<const float4*>(P.invstd)[q];
         const float4 ga = reinterpret_cast<const float4*>(P.gamma)[q], be = reinterpret_cast<const float4*>(P.beta)[q];
         const float4 db = reinterpret_cast<const float4*>(P.dbeta)[q], dg = reinterpret_cast<const float4*>(P.dgamma)[q];
@@ -198,6 +205,8 @@ __global__ __launch_bounds__(kT) void bn_bwd_dx_kernel(const BnParams P) {
         ODPL_DX(x) ODPL_DX(y) ODPL_DX(z) ODPL_DX(w)
 #undef ODPL_DX
         reinterpret_cast<float4*>(P.gx)[i] = o;
+        q += sq; r += sr;
+        if (q >= (unsigned)c4n) { q -= c4n; ++r; }
     }
 }
 
@@ -258,6 +267,16 @@ extern "C" int odpl_bn_act_forward_residual(const float* x, const float* residua
                                             float* running_mean, float* running_var, int32_t training, float momentum, float eps,
                                             int32_t act, float* save_mean, float* save_invstd, float* y, void* workspace,
                                             size_t workspace_bytes, int64_t* num_batches_tracked, void* stream_) {
+    return odpl_bn_act_forward_strided(x, residual, R, C, gamma, beta, running_mean, running_var, training, momentum, eps, act,
+                                       save_mean, save_invstd, y, C, workspace, workspace_bytes, num_batches_tracked, stream_);
+}
+
+extern "C" int odpl_bn_act_forward_strided(const float* x, const float* residual, int64_t R, int32_t C, const float* gamma, const float* beta,
+                                           float* running_mean, float* running_var, int32_t training, float momentum, float eps,
+                                           int32_t act, float* save_mean, float* save_invstd, float* y, int64_t y_row_stride,
+                                           void* workspace, size_t workspace_bytes, int64_t* num_batches_tracked, void* stream_) {
+    if (y_row_stride < C || (y_row_stride & 3)) return ODPL_EINVAL;
+    if (residual && y_row_stride != C) return ODPL_EINVAL;
     int rpb, nblk; size_t lds;
     if (!x || !y || !gamma || !beta || !save_mean || !save_invstd || !plan(R, C, &rpb, &nblk, &lds)) return ODPL_EINVAL;
     if (act < 0 || act > 3 || (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)save_mean | (uintptr_t)save_invstd | (uintptr_t)residual) & 15)) return ODPL_EINVAL;
@@ -266,6 +285,7 @@ extern "C" int odpl_bn_act_forward_residual(const float* x, const float* residua
     P.x = x; P.y = y; P.res = residual; P.gamma = gamma; P.beta = beta; P.mean = save_mean; P.invstd = save_invstd;
     P.running_mean = running_mean; P.running_var = running_var; P.R = R; P.C = C; P.act = act; P.nblk = nblk;
     P.rows_per_blk = rpb; P.training = training; P.eps = eps; P.momentum = momentum; P.part = (double*)workspace;
+    P.y_rs4 = y_row_stride >> 2; P.gy_rs4 = C >> 2;
     P.num_batches_tracked = (long long*)num_batches_tracked;
     if (training) {
         if (!workspace || workspace_bytes < odpl_bn_act_workspace_bytes(R, C) || ((uintptr_t)workspace & 15)) return ODPL_EINVAL;
@@ -285,6 +305,15 @@ extern "C" int odpl_bn_act_backward(const float* x, const float* grad_y, int64_t
                                     const float* save_mean, const float* save_invstd, int32_t training, int32_t act,
                                     float* grad_x, float* grad_gamma, float* grad_beta, void* workspace, size_t workspace_bytes,
                                     void* stream_) {
+    return odpl_bn_act_backward_strided(x, grad_y, C, R, C, gamma, beta, save_mean, save_invstd, training, act, grad_x, grad_gamma, grad_beta,
+                                        workspace, workspace_bytes, stream_);
+}
+
+extern "C" int odpl_bn_act_backward_strided(const float* x, const float* grad_y, int64_t gy_row_stride, int64_t R, int32_t C,
+                                            const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
+                                            int32_t training, int32_t act, float* grad_x, float* grad_gamma, float* grad_beta,
+                                            void* workspace, size_t workspace_bytes, void* stream_) {
+    if (gy_row_stride < C || (gy_row_stride & 3)) return ODPL_EINVAL;
     int rpb, nblk; size_t lds;
     if (!x || !grad_y || !grad_x || !gamma || !beta || !save_mean || !save_invstd || !grad_gamma || !grad_beta || !plan(R, C, &rpb, &nblk, &lds))
         return ODPL_EINVAL;
@@ -294,6 +323,7 @@ extern "C" int odpl_bn_act_backward(const float* x, const float* grad_y, int64_t
     BnParams P = {};
     P.x = x; P.gy = grad_y; P.gx = grad_x; P.gamma = gamma; P.beta = beta; P.mean = (float*)save_mean; P.invstd = (float*)save_invstd;
     P.R = R; P.C = C; P.act = act; P.nblk = nblk; P.rows_per_blk = rpb; P.training = training; P.part = (double*)workspace;
+    P.y_rs4 = C >> 2; P.gy_rs4 = gy_row_stride >> 2;
     P.dgamma = grad_gamma; P.dbeta = grad_beta;
     hipLaunchKernelGGL(bn_reduce_kernel<true>, dim3(nblk), dim3(kT), lds, stream, P);
     ODPL_HIP_TRY(hipGetLastError());

@@ -30,16 +30,21 @@ class Conv2dBatchReLU(nn.Module):
         self.layers = nn.Sequential(nn.Conv2d(cin, cout, k, stride, pad, bias=False), nn.BatchNorm2d(cout, momentum=momentum),
                                     nn.LeakyReLU(0.1))
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
         z = self.layers[0](x)
         if _bnact.fusable(z, self.layers[1]):
-            return _bnact.bn_act(z, self.layers[1], "leaky")
-        return self.layers[2](self.layers[1](z))
+            return _bnact.bn_act(z, self.layers[1], "leaky", residual)      # the skip add rides on the epilogue's write
+        z = self.layers[2](self.layers[1](z))
+        return z if residual is None else residual + z
 
 
 class Residual(nn.Sequential):
     def forward(self, x):
-        return x + super().forward(x)
+        mods = list(self)
+        y = x
+        for m in mods[:-1]:
+            y = m(y)
+        return mods[-1](y, residual=x) if isinstance(mods[-1], Conv2dBatchReLU) else x + mods[-1](y)
 
 
 class SelectiveSequential(nn.Sequential):

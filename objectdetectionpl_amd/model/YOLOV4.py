@@ -74,6 +74,22 @@ class ConvUnit(nn.Module):
     fuse_epilogue = True          # class switch: False = plain nn.BatchNorm2d + nn.Mish / nn.LeakyReLU
 
 
+def cat_units(u1, x1, u2, x2):
+    """torch.cat([u1(x1), u2(x2)], 1) for two conv+BN+activation units: their epilogues write straight into the merged tensor."""
+    if ConvUnit.fuse_epilogue and u1._act is not None and u2._act is not None:
+        z1, z2 = u1.conv[0](x1), u2.conv[0](x2)
+        if _bnact.fusable(z1, u1.conv[1]) and _bnact.fusable(z2, u2.conv[1]):
+            y = _bnact.bn_act_cat(z1, u1.conv[1], u1._act, z2, u2.conv[1], u2._act)
+            if y is not None:
+                return y
+        for l in list(u1.conv)[1:]:
+            z1 = l(z1)
+        for l in list(u2.conv)[1:]:
+            z2 = l(z2)
+        return torch.cat([z1, z2], 1)
+    return torch.cat([u1(x1), u2(x2)], 1)
+
+
 class ResChain(nn.Module):
     """n x (1x1 mish -> 3x3 mish, + skip); parameters under `module_list.<i>.<0|1>`."""
 
@@ -100,10 +116,9 @@ class CSPFirst(nn.Module):
 
     def forward(self, x):
         x2 = self.conv2(self.conv1(x))
-        x3 = self.conv3(x2)
         x4 = self.conv4(x2)
         x6 = self.conv6(self.conv5(x4), residual=x4)
-        return self.conv8(torch.cat([self.conv7(x6), x3], 1))
+        return self.conv8(cat_units(self.conv7, x6, self.conv3, x2))          # cat([conv7(x6), conv3(x2)], 1)
 
 
 class CSPStage(nn.Module):
@@ -120,8 +135,7 @@ class CSPStage(nn.Module):
 
     def forward(self, x):
         x1 = self.conv1(x)
-        y = self.conv4(self.resblock(self.conv3(x1)))
-        return self.conv5(torch.cat([y, self.conv2(x1)], 1))
+        return self.conv5(cat_units(self.conv4, self.resblock(self.conv3(x1)), self.conv2, x1))   # cat([conv4(...), conv2(x1)], 1)
 
 
 class PANNeck(nn.Module):

@@ -29,11 +29,12 @@ def _w(c, wm):
     return int(round(c * wm, 1))                 # YoloV5Utils.py:41-44
 
 
-def _bn_act(x, bn, act):
+def _bn_act(x, bn, act, residual=None):
     if _bnact.fusable(x, bn):
-        return _bnact.bn_act(x, bn, "leaky" if act else "linear")
+        return _bnact.bn_act(x, bn, "leaky" if act else "linear", residual)
     y = bn(x)
-    return F.leaky_relu(y, 0.1) if act else y
+    y = F.leaky_relu(y, 0.1) if act else y
+    return y if residual is None else residual + y
 
 
 class Conv(nn.Module):
@@ -47,8 +48,8 @@ class Conv(nn.Module):
         self.act = nn.LeakyReLU(0.1, inplace=True) if act else nn.Identity()
         self._has_act = bool(act)
 
-    def forward(self, x):
-        return _bn_act(self.conv(x), self.bn, self._has_act)
+    def forward(self, x, residual=None):
+        return _bn_act(self.conv(x), self.bn, self._has_act, residual)
 
 
 class Bottleneck(nn.Module):
@@ -61,8 +62,7 @@ class Bottleneck(nn.Module):
         self.add = shortcut and c1 == c2
 
     def forward(self, x):
-        y = self.cv2(self.cv1(x))
-        return x + y if self.add else y
+        return self.cv2(self.cv1(x), residual=x if self.add else None)
 
 
 class BottleneckCSP(nn.Module):

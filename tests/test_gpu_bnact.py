@@ -90,3 +90,39 @@ def test_bn_act_with_residual(act, training):
     assert torch.equal(r1.grad, r0.grad)
     assert torch.allclose(bn1.weight.grad, bn0.weight.grad, rtol=1e-4, atol=1e-4)
     assert torch.allclose(bn1.running_var, bn0.running_var, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_bn_act_cat(training):
+    """cat((mish(bn1(x1)), leaky(bn2(x2))), 1) written in place by the two epilogues: outputs, every gradient and the
+    running statistics equal the torch composition."""
+    from objectdetectionpl_amd.LightningFunc.utils.bnact import bn_act_cat
+    torch.manual_seed(13)
+    N, H, W, C1, C2 = 3, 26, 26, 64, 32
+    mods = []
+    for C in (C1, C2, C1, C2):
+        bn = nn.BatchNorm2d(C).cuda()
+        mods.append(bn)
+    for a, b in ((0, 2), (1, 3)):
+        with torch.no_grad():
+            mods[a].weight.uniform_(0.5, 1.5); mods[a].bias.uniform_(-0.5, 0.5); mods[a].running_mean.uniform_(-0.2, 0.2); mods[a].running_var.uniform_(0.5, 1.5)
+        mods[b].load_state_dict(mods[a].state_dict())
+    for m in mods:
+        m.train(training)
+    cl = dict(memory_format=torch.channels_last)
+    x1 = torch.randn(N, C1, H, W, device="cuda").contiguous(**cl).requires_grad_()
+    x2 = torch.randn(N, C2, H, W, device="cuda").contiguous(**cl).requires_grad_()
+    x1r, x2r = x1.detach().clone().requires_grad_(), x2.detach().clone().requires_grad_()
+    w = torch.randn(N, C1 + C2, H, W, device="cuda").contiguous(**cl)
+    ref = torch.cat((F.mish(mods[0](x1r)), F.leaky_relu(mods[1](x2r), 0.1)), 1)
+    (ref * w).sum().backward()
+    y = bn_act_cat(x1, mods[2], "mish", x2, mods[3], "leaky")
+    assert y is not None and y.is_contiguous(**cl)
+    (y * w).sum().backward()
+    assert torch.allclose(y, ref, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(x1.grad, x1r.grad, rtol=1e-4, atol=1e-5) and torch.allclose(x2.grad, x2r.grad, rtol=1e-4, atol=1e-5)
+    for a, b in ((0, 2), (1, 3)):
+        assert torch.allclose(mods[b].weight.grad, mods[a].weight.grad, rtol=1e-4, atol=1e-4)
+        assert torch.allclose(mods[b].bias.grad, mods[a].bias.grad, rtol=1e-4, atol=1e-4)
+        assert torch.allclose(mods[b].running_mean, mods[a].running_mean, rtol=1e-5, atol=1e-6)
+        assert torch.equal(mods[b].num_batches_tracked, mods[a].num_batches_tracked)
