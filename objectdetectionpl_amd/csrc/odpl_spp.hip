@@ -7,7 +7,7 @@
 //   backward: plane -> LDS, arg-max position of every window recomputed into LDS, then a GATHER: every input
 //             position sums the gradients of the windows that selected it -- no atomics, deterministic.
 // Arbitrary (dense) strides: works for NCHW and channels-last tensors alike.  First maximum in row-major window
-// order wins ties and a NaN wins, like ATen.
+// order wins ties; a NaN wins (the last one in the window), like ATen.
 #include "odpl_common.hpp"
 #include "../../include/odpl_hip.h"
 
@@ -23,7 +23,7 @@ struct SppParams {
 
 __device__ __forceinline__ void window_scan(const float* s, int H, int W, int py, int px, float* mx, int* am) {
     // nested windows r = 2, 4, 6: visit the 13x13 window once in row-major order and update each level whose
-    // window contains the element -- first maximum wins, NaN wins and sticks
+    // window contains the element -- first maximum wins; every NaN takes over (ATen's scan)
     float m0 = 0.f, m1 = 0.f, m2 = 0.f; int a0 = -1, a1 = -1, a2 = -1;
     for (int dy = -6; dy <= 6; ++dy) {
         const int yy = py + dy;
@@ -34,9 +34,10 @@ __device__ __forceinline__ void window_scan(const float* s, int H, int W, int py
             const int q = yy * W + xx;
             const float v = s[q];
             const int ady = dy < 0 ? -dy : dy, adx = dx < 0 ? -dx : dx;
-            if (a2 < 0 || (m2 == m2 && (v > m2 || v != v))) { m2 = v; a2 = q; }
-            if (ady <= 4 && adx <= 4 && (a1 < 0 || (m1 == m1 && (v > m1 || v != v)))) { m1 = v; a1 = q; }
-            if (ady <= 2 && adx <= 2 && (a0 < 0 || (m0 == m0 && (v > m0 || v != v)))) { m0 = v; a0 = q; }
+            // ATen: `if ((val > maxval) || isnan(val))` -- strict > keeps the first maximum, EVERY NaN takes over (the last one wins)
+            if (a2 < 0 || v != v || v > m2) { m2 = v; a2 = q; }
+            if (ady <= 4 && adx <= 4 && (a1 < 0 || v != v || v > m1)) { m1 = v; a1 = q; }
+            if (ady <= 2 && adx <= 2 && (a0 < 0 || v != v || v > m0)) { m0 = v; a0 = q; }
         }
     }
     mx[0] = m0; mx[1] = m1; mx[2] = m2; am[0] = a0; am[1] = a1; am[2] = a2;
@@ -99,6 +100,157 @@ __global__ __launch_bounds__(256) void spp_bwd_kernel(const SppParams P) {
     }
 }
 
+// ---- channels-last fast path ------------------------------------------------------------------------------------
+// The per-plane kernels above read an NHWC tensor with a stride of C floats (one 64-B sector per element).  Here a workgroup
+// owns a [H*W positions] x [CT channels] tile: loads and stores are 16-B, 4*CT-byte contiguous per position, lanes run along
+// the channels in LDS (bank-conflict free), and the three pools are a CASCADE of separable 5x5 pools
+// (maxpool9 = maxpool5 o maxpool5, maxpool13 = maxpool5 o maxpool9 for stride 1 / same padding): 30 LDS reads per output
+// instead of 169.  Backward carries (value, ORIGINAL position) pairs through the same cascade with the order
+// "NaN (later position) > larger value > smaller position", which is associative and commutative, so the arg-max of every
+// window is exactly ATen's `if (val > maxval || isnan(val))` row-major scan (first maximum; the last NaN); then the same
+// deterministic gather as above.
+constexpr int kTileT = 256;
+
+__device__ __forceinline__ bool better(float av, int ai, float mv, int mi) {
+    const bool an = av != av, mn = mv != mv;
+    if (an) return !mn || ai > mi;                 // a NaN beats any number; among NaNs the LAST position wins (ATen's scan order)
+    return !mn && (av > mv || (av == mv && ai < mi));
+}
+
+template <int CT, bool IDX>
+__device__ __forceinline__ void pool5_stage(const float* sv, const unsigned short* si, float* tv, unsigned short* ti,
+                                            float* dv, unsigned short* di, int H, int W) {
+    const int ch = threadIdx.x % CT, pl = threadIdx.x / CT, HW = H * W;
+    constexpr int PL = kTileT / CT;
+    for (int p = pl; p < HW; p += PL) {                       // rows
+        const int py = p / W, px = p - py * W;
+        const int x0 = px - 2 < 0 ? 0 : px - 2, x1 = px + 2 > W - 1 ? W - 1 : px + 2;
+        float m = sv[(py * W + x0) * CT + ch]; int mi = IDX ? si[(py * W + x0) * CT + ch] : 0;
+        for (int xx = x0 + 1; xx <= x1; ++xx) {
+            const float a = sv[(py * W + xx) * CT + ch]; const int ai = IDX ? si[(py * W + xx) * CT + ch] : 0;
+            if (IDX ? better(a, ai, m, mi) : (m == m && (a > m || a != a))) { m = a; mi = ai; }
+        }
+        tv[p * CT + ch] = m; if (IDX) ti[p * CT + ch] = (unsigned short)mi;
+    }
+    __syncthreads();
+    for (int p = pl; p < HW; p += PL) {                       // columns
+        const int py = p / W, px = p - py * W;
+        const int y0 = py - 2 < 0 ? 0 : py - 2, y1 = py + 2 > H - 1 ? H - 1 : py + 2;
+        float m = tv[(y0 * W + px) * CT + ch]; int mi = IDX ? ti[(y0 * W + px) * CT + ch] : 0;
+        for (int yy = y0 + 1; yy <= y1; ++yy) {
+            const float a = tv[(yy * W + px) * CT + ch]; const int ai = IDX ? ti[(yy * W + px) * CT + ch] : 0;
+            if (IDX ? better(a, ai, m, mi) : (m == m && (a > m || a != a))) { m = a; mi = ai; }
+        }
+        dv[p * CT + ch] = m; if (IDX) di[p * CT + ch] = (unsigned short)mi;
+    }
+    __syncthreads();
+}
+
+template <int CT>
+__device__ __forceinline__ void tile_store(const float* lds, float* g, long long row_stride, int HW) {
+    constexpr int Q = CT / 4;
+    for (int i = threadIdx.x; i < HW * Q; i += kTileT) {
+        const int pos = i / Q, q = i - pos * Q;
+        *reinterpret_cast<float4*>(g + pos * row_stride + 4 * q) = *reinterpret_cast<const float4*>(lds + pos * CT + 4 * q);
+    }
+}
+template <int CT>
+__device__ __forceinline__ void tile_load(float* lds, const float* g, long long row_stride, int HW) {
+    constexpr int Q = CT / 4;
+    for (int i = threadIdx.x; i < HW * Q; i += kTileT) {
+        const int pos = i / Q, q = i - pos * Q;
+        *reinterpret_cast<float4*>(lds + pos * CT + 4 * q) = *reinterpret_cast<const float4*>(g + pos * row_stride + 4 * q);
+    }
+}
+
+template <int CT>
+__global__ __launch_bounds__(kTileT) void spp_fwd_nhwc_kernel(const SppParams P) {
+    extern __shared__ float lds[];
+    const int HW = P.H * P.W, C = P.C;
+    float* A = lds; float* Bf = lds + HW * CT; float* T = lds + 2 * HW * CT;
+    const float* xb = P.x + blockIdx.y * P.xs[0] + blockIdx.x * CT;
+    float* yb = P.y + blockIdx.y * P.ys[0] + blockIdx.x * CT;
+    tile_load<CT>(A, xb, C, HW);
+    __syncthreads();
+    tile_store<CT>(A, yb + 3LL * C, 4LL * C, HW);                                 // [m13 | m9 | m5 | x]  (YoloV4Utils.py:418)
+    pool5_stage<CT, false>(A, nullptr, T, nullptr, Bf, nullptr, P.H, P.W);
+    tile_store<CT>(Bf, yb + 2LL * C, 4LL * C, HW);
+    pool5_stage<CT, false>(Bf, nullptr, T, nullptr, A, nullptr, P.H, P.W);
+    tile_store<CT>(A, yb + 1LL * C, 4LL * C, HW);
+    pool5_stage<CT, false>(A, nullptr, T, nullptr, Bf, nullptr, P.H, P.W);
+    tile_store<CT>(Bf, yb, 4LL * C, HW);
+}
+
+template <int CT, int KMAX>
+__global__ __launch_bounds__(kTileT) void spp_bwd_nhwc_kernel(const SppParams P) {
+    extern __shared__ float lds[];
+    const int HW = P.H * P.W, C = P.C, n = HW * CT;
+    float* V0 = lds; float* V1 = lds + n; float* TV = lds + 2 * n; float* G = lds + 3 * n;
+    unsigned short* I0 = reinterpret_cast<unsigned short*>(lds + 4 * n); unsigned short* I1 = I0 + n; unsigned short* TI = I0 + 2 * n;
+    const int ch = threadIdx.x % CT, pl = threadIdx.x / CT;
+    constexpr int PL = kTileT / CT;
+    const float* xb = P.x + blockIdx.y * P.xs[0] + blockIdx.x * CT;
+    const float* gb = P.gy + blockIdx.y * P.ys[0] + blockIdx.x * CT;
+    tile_load<CT>(V0, xb, C, HW);
+    float acc[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int p = pl + k * PL;
+        acc[k] = 0.f;
+        if (p < HW) { I0[p * CT + ch] = (unsigned short)p; acc[k] = gb[p * 4LL * C + 3LL * C + ch]; }           // identity branch
+    }
+    __syncthreads();
+    auto gather = [&](const unsigned short* I, int r) {
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int p = pl + k * PL;
+            if (p < HW) {
+                const int py = p / P.W, px = p - py * P.W;
+                const int y0 = py - r < 0 ? 0 : py - r, y1 = py + r > P.H - 1 ? P.H - 1 : py + r;
+                const int x0 = px - r < 0 ? 0 : px - r, x1 = px + r > P.W - 1 ? P.W - 1 : px + r;
+                float a = acc[k];
+                for (int yy = y0; yy <= y1; ++yy)
+                    for (int xx = x0; xx <= x1; ++xx) {                      // windows that contain p, fixed row-major order
+                        const int q = (yy * P.W + xx) * CT + ch;
+                        if (I[q] == p) a += G[q];
+                    }
+                acc[k] = a;
+            }
+        }
+    };
+    pool5_stage<CT, true>(V0, I0, TV, TI, V1, I1, P.H, P.W);          // m5 / arg5
+    tile_load<CT>(G, gb + 2LL * C, 4LL * C, HW);
+    __syncthreads();
+    gather(I1, 2);
+    __syncthreads();
+    pool5_stage<CT, true>(V1, I1, TV, TI, V0, I0, P.H, P.W);          // m9 / arg9
+    tile_load<CT>(G, gb + 1LL * C, 4LL * C, HW);
+    __syncthreads();
+    gather(I0, 4);
+    __syncthreads();
+    pool5_stage<CT, true>(V0, I0, TV, TI, V1, I1, P.H, P.W);          // m13 / arg13
+    tile_load<CT>(G, gb, 4LL * C, HW);
+    __syncthreads();
+    gather(I1, 6);
+    float* gxb = P.gx + blockIdx.y * P.xs[0] + blockIdx.x * CT;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int p = pl + k * PL;
+        if (p < HW) gxb[(long long)p * C + ch] = acc[k];
+    }
+}
+
+// dense NHWC on both sides?  -> channel-tile width (32, 16) or 0 for the per-plane kernels
+int nhwc_tile(const SppParams& P) {
+    const long long C = P.C, W = P.W, H = P.H;
+    const bool x_ok = P.xs[1] == 1 && P.xs[3] == C && P.xs[2] == W * C && P.xs[0] == H * W * C;
+    const bool y_ok = P.ys[1] == 1 && P.ys[3] == 4 * C && P.ys[2] == W * 4 * C && P.ys[0] == H * W * 4 * C;
+    if (!x_ok || !y_ok) return 0;
+    if (C % 32 == 0 && H * W <= 176) return 32;
+    if (C % 16 == 0 && H * W <= 400) return 16;
+    return 0;
+}
+
 bool fill(SppParams& P, const float* x, const int64_t* xs, int B, int C, int H, int W, const int64_t* ys) {
     if (!x || !xs || !ys || B < 1 || C < 1 || H < 1 || W < 1 || H * W > kMaxHW || B > 65535) return false;
     P.x = x; P.B = B; P.C = C; P.H = H; P.W = W;
@@ -112,6 +264,20 @@ extern "C" int odpl_spp_forward(const float* x, const int64_t* x_strides, int32_
     SppParams P;
     if (!y || !fill(P, x, x_strides, B, C, H, W, y_strides)) return ODPL_EINVAL;
     P.y = y; P.gy = nullptr; P.gx = nullptr;
+    const int ct = (((uintptr_t)x | (uintptr_t)y) & 15) ? 0 : nhwc_tile(P);
+    if (ct) {
+        const size_t lds = (size_t)3 * H * W * ct * sizeof(float);
+        static bool attr32 = false, attr16 = false;
+        if (ct == 32) {
+            if (!attr32) { ODPL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(spp_fwd_nhwc_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 176 * 32 * 4)); attr32 = true; }
+            hipLaunchKernelGGL(spp_fwd_nhwc_kernel<32>, dim3(C / 32, B), dim3(kTileT), lds, (hipStream_t)stream, P);
+        } else {
+            if (!attr16) { ODPL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(spp_fwd_nhwc_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 400 * 16 * 4)); attr16 = true; }
+            hipLaunchKernelGGL(spp_fwd_nhwc_kernel<16>, dim3(C / 16, B), dim3(kTileT), lds, (hipStream_t)stream, P);
+        }
+        ODPL_HIP_TRY(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(spp_fwd_kernel, dim3(C, B), dim3(256), 0, (hipStream_t)stream, P);
     ODPL_HIP_TRY(hipGetLastError());
     return 0;
@@ -122,6 +288,20 @@ extern "C" int odpl_spp_backward(const float* x, const int64_t* x_strides, int32
     SppParams P;
     if (!grad_y || !grad_x || !fill(P, x, x_strides, B, C, H, W, y_strides)) return ODPL_EINVAL;
     P.y = nullptr; P.gy = grad_y; P.gx = grad_x;
+    const int ct = (((uintptr_t)x | (uintptr_t)grad_y | (uintptr_t)grad_x) & 15) ? 0 : nhwc_tile(P);
+    if (ct) {
+        const size_t lds = (size_t)H * W * ct * (4 * sizeof(float) + 3 * sizeof(unsigned short));
+        static bool attr32 = false, attr16 = false;
+        if (ct == 32) {
+            if (!attr32) { ODPL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(spp_bwd_nhwc_kernel<32, 22>), hipFuncAttributeMaxDynamicSharedMemorySize, 176 * 32 * 22)); attr32 = true; }
+            hipLaunchKernelGGL((spp_bwd_nhwc_kernel<32, 22>), dim3(C / 32, B), dim3(kTileT), lds, (hipStream_t)stream, P);
+        } else {
+            if (!attr16) { ODPL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(spp_bwd_nhwc_kernel<16, 25>), hipFuncAttributeMaxDynamicSharedMemorySize, 400 * 16 * 22)); attr16 = true; }
+            hipLaunchKernelGGL((spp_bwd_nhwc_kernel<16, 25>), dim3(C / 16, B), dim3(kTileT), lds, (hipStream_t)stream, P);
+        }
+        ODPL_HIP_TRY(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(spp_bwd_kernel, dim3(C, B), dim3(256), 0, (hipStream_t)stream, P);
     ODPL_HIP_TRY(hipGetLastError());
     return 0;

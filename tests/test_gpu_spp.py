@@ -9,7 +9,8 @@ def _ref(x):
     return torch.cat([F.max_pool2d(x, 13, 1, 6), F.max_pool2d(x, 9, 1, 4), F.max_pool2d(x, 5, 1, 2), x], 1)
 
 
-@pytest.mark.parametrize("shape", [(2, 8, 13, 13), (3, 5, 7, 9), (1, 3, 4, 4), (2, 4, 26, 26)])
+@pytest.mark.parametrize("shape", [(2, 8, 13, 13), (3, 5, 7, 9), (1, 3, 4, 4), (2, 4, 26, 26),
+                                   (2, 64, 13, 13), (1, 32, 9, 14), (2, 48, 19, 19), (1, 16, 20, 20), (1, 32, 16, 16), (3, 96, 1, 1)])   # + channel-tile path (C % 16 == 0, channels-last)
 @pytest.mark.parametrize("cl", [False, True])
 def test_spp_matches_torch(shape, cl):
     from objectdetectionpl_amd.LightningFunc.utils.spp import spp_cat
@@ -24,3 +25,24 @@ def test_spp_matches_torch(shape, cl):
     (ya * w).sum().backward(); (yb * w).sum().backward()
     # same terms, different summation order (gather here, scatter-add in ATen): compare at the scale of the gradient
     assert torch.allclose(xa.grad, xb.grad, rtol=1e-4, atol=1e-5 * float(xb.grad.abs().max()))
+
+
+@pytest.mark.parametrize("C,cl", [(4, False), (32, True), (16, True)])
+def test_ties_and_nan_follow_aten(C, cl):
+    """Quantised inputs (many exact ties in every window) and NaNs: values bit-equal to ATen's, and the gradient lands on
+    ATen's arg-max (first maximum in row-major window order; a NaN wins) -- per-plane and channel-tile kernels."""
+    from objectdetectionpl_amd.LightningFunc.utils.spp import spp_cat
+    g = torch.Generator().manual_seed(17)
+    x = torch.randint(0, 3, (2, C, 9, 11), generator=g).float()
+    x[0, 1, 4, 4] = float("nan")
+    x[1, 3, 1, 7] = float("nan"); x[1, 3, 6, 2] = float("nan")
+    x = x.cuda()
+    if cl:
+        x = x.contiguous(memory_format=torch.channels_last)
+    xa = x.clone().requires_grad_(); xb = x.clone().requires_grad_()
+    ya, yb = spp_cat(xa), _ref(xb)
+    assert torch.equal(torch.isnan(ya), torch.isnan(yb))
+    assert torch.equal(torch.nan_to_num(ya, nan=-7.0), torch.nan_to_num(yb, nan=-7.0))
+    w = torch.randint(1, 4, yb.shape, generator=g).float().cuda()          # small integers: sums are exact in any order
+    (ya * w).sum().backward(); (yb * w).sum().backward()
+    assert torch.equal(xa.grad, xb.grad)
