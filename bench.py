@@ -119,6 +119,8 @@ def main():
     ap.add_argument("--cpu-sample-batch", type=int, default=8)
     ap.add_argument("--cpu-sample-steps", type=int, default=4)
     ap.add_argument("--bucket-mb", type=int, default=48)
+    ap.add_argument("--ddp-impl", default="bucketed", choices=["bucketed", "torch"],
+                    help="gradient exchange: own bucketed averager (7 launches/step) or torch DistributedDataParallel")
     ap.add_argument("--force-ddp", action="store_true", help="wrap in DDP (RCCL) even at world size 1: exercises the N>1 code path on one GPU")
     ap.add_argument("--stamp", action="store_true", help="diagnostic: in-kernel 100 MHz stamps of yolo_dense_kernel (first start -> last end)")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="libodpl_hip tunable, e.g. yolo_fill_nt=1")
@@ -129,6 +131,11 @@ def main():
     a = ap.parse_args()
 
     t_start = time.perf_counter()
+    # stdout carries exactly ONE line (the JSON): libraries that print banners there (RCCL's version block, MIOpen) are sent
+    # to stderr by pointing fd 1 at fd 2 for the duration of the run; the result is written to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -169,7 +176,7 @@ def main():
     if a.channels_last:
         model = model.to(memory_format=torch.channels_last)
     crit = model.criterion
-    net = wrap_data_parallel(model, dev, bucket_mb=a.bucket_mb) if use_ddp else model
+    net = wrap_data_parallel(model, dev, bucket_mb=a.bucket_mb, impl=a.ddp_impl) if use_ddp else model
     opt = torch.optim.Adam(model.parameters(), lr=Args.lr, weight_decay=Args.weight_decay, fused=bool(a.fused_adam))
     x, y = synthetic_batch(1 + rank, a.batch, a.classes, a.img, dev)
     if a.channels_last:
@@ -281,7 +288,8 @@ def main():
             res["allreduce"] = allreduce
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a.cpu_sample_batch, a.classes, a.img, a.cpu_sample_steps)
-        print(json.dumps(res), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(res) + "\n").encode())
     if use_ddp:
         dist.barrier()
         dist.destroy_process_group()

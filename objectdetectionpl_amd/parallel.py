@@ -4,8 +4,13 @@ The reference has no explicit collective: `Trainer(gpus=-1)` (run.py:109, config
 makes PL 1.2.6 wrap the module in DistributedDataParallel.  This is that exchange, re-hosted:
   * the per-image detector kernels need no collective (targets carry a LOCAL image index, loss means
     are per rank, no SyncBN) -- the only exchange is the mean of fp32 gradients, 257.5 MB for YOLOv4;
-  * buckets are views of the gradients (`gradient_as_bucket_view`), filled in reverse parameter order
-    and all-reduced from autograd hooks while the rest of backward still runs;
+  * `GradAverager` (default): parameters are grouped into flat fp32 buckets in reverse registration order
+    (~ the order backward produces them).  When the last gradient of a bucket lands, ONE multi-tensor copy
+    packs the bucket, `.grad` of its parameters is re-pointed at views of the flat buffer, and an asynchronous
+    all-reduce(AVG) of the whole bucket is issued on RCCL's stream while backward keeps running; a callback at
+    the end of backward waits for the outstanding collectives.  torch's DDP does the same exchange but, with
+    `zero_grad(set_to_none=True)`, pays one copy + one scale kernel PER PARAMETER per step (609 launches, 2 ms
+    for YOLOv4, `profiles/r01_ddp_*`); here it is 7 launches;
   * xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring is per-link bound, so buckets are
     kept large (default 48 MB -> 6 buckets for YOLOv4) to amortise per-collective latency, and the
     first (head/neck) bucket is small so the exchange starts early.
@@ -28,8 +33,104 @@ def init_process_group_from_env(device=None):
     return dist.get_rank(), dist.get_world_size()
 
 
-def wrap_data_parallel(model, device=None, bucket_mb=48, first_bucket_mb=4, broadcast_buffers=True):
-    """DDP with bucket views and overlap; BN statistics stay per rank (no SyncBN), as in the reference."""
+class _Bucket:
+    __slots__ = ("params", "flat", "views", "pending", "work")
+
+    def __init__(self, params):
+        self.params = params
+        n = sum(p.numel() for p in params)
+        self.flat = torch.zeros(n, dtype=params[0].dtype, device=params[0].device)
+        self.views, o = [], 0
+        for p in params:
+            # same sizes AND strides as the parameter (conv weights may be channels-last): fused optimisers require
+            # grad and param layouts to match, and the pack becomes a straight copy
+            self.views.append(self.flat[o:o + p.numel()].as_strided(p.size(), p.stride()))
+            o += p.numel()
+        self.pending = len(params)
+        self.work = None
+
+
+class GradAverager:
+    """Bucketed, overlapped mean of gradients over the process group (see the module docstring)."""
+
+    def __init__(self, params, bucket_mb=48, first_bucket_mb=4, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.avg_op = dist.ReduceOp.AVG if dist.get_backend(group) == "nccl" else None     # gloo: SUM, then one scale per bucket
+        params = [p for p in params if p.requires_grad][::-1]
+        self.buckets, cur, cur_bytes, cap = [], [], 0, first_bucket_mb * 2 ** 20
+        for p in params:
+            if cur and (cur_bytes + p.numel() * p.element_size() > cap or p.dtype != cur[0].dtype or p.device != cur[0].device):
+                self.buckets.append(_Bucket(cur))
+                cur, cur_bytes, cap = [], 0, bucket_mb * 2 ** 20
+            cur.append(p)
+            cur_bytes += p.numel() * p.element_size()
+        if cur:
+            self.buckets.append(_Bucket(cur))
+        self._bucket_of = {}
+        self._armed = False
+        self._handles = []
+        for b in self.buckets:
+            for p in b.params:
+                self._bucket_of[p] = b
+                self._handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    def _on_grad(self, p):
+        if not self._armed:                       # first gradient of this backward pass: arrange the final wait
+            self._armed = True
+            torch.autograd.Variable._execution_engine.queue_callback(self.finish)
+        b = self._bucket_of[p]
+        b.pending -= 1
+        if b.pending == 0:
+            self._launch(b)
+
+    def _launch(self, b):
+        torch._foreach_copy_(b.views, [p.grad for p in b.params])      # one multi-tensor kernel per bucket
+        for p, v in zip(b.params, b.views):
+            p.grad = v                                                  # the optimiser reads the averaged flat buffer
+        if self.avg_op is not None:
+            b.work = dist.all_reduce(b.flat, op=self.avg_op, group=self.group, async_op=True)
+        else:
+            b.work = dist.all_reduce(b.flat, group=self.group, async_op=True)
+
+    def finish(self):
+        """End of backward: wait for the outstanding collectives (the current stream waits; the host does not block on RCCL)."""
+        for b in self.buckets:
+            if b.pending != 0:
+                raise RuntimeError("a bucket did not fill: every parameter must receive a gradient each step "
+                                   "(static graph, like the reference's training step)")
+            b.work.wait()
+            if self.avg_op is None:
+                b.flat.div_(self.world)
+            b.work, b.pending = None, len(b.params)
+        self._armed = False
+
+    def remove(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []
+
+
+class DataParallelHost(torch.nn.Module):
+    """`.module` + forward passthrough (the DDP surface the training loops use); gradients are averaged by `GradAverager`."""
+
+    def __init__(self, module, bucket_mb=48, first_bucket_mb=4, group=None):
+        super().__init__()
+        self.module = module
+        with torch.no_grad():                      # replicas start from rank 0's weights and buffers, like DDP
+            for t in list(module.parameters()) + list(module.buffers()):
+                dist.broadcast(t, 0, group=group)
+        self.averager = GradAverager(module.parameters(), bucket_mb, first_bucket_mb, group)
+
+    def forward(self, *a, **k):
+        return self.module(*a, **k)
+
+
+def wrap_data_parallel(model, device=None, bucket_mb=48, first_bucket_mb=4, broadcast_buffers=True, impl="bucketed"):
+    """Data-parallel wrapper; BN statistics stay per rank (no SyncBN), as in the reference.
+    impl="bucketed": `DataParallelHost` (default).  impl="torch": torch's DistributedDataParallel with bucket views."""
+    if impl == "bucketed":
+        return DataParallelHost(model, bucket_mb, first_bucket_mb)
     dev = None if device is None else torch.device(device)
     ids = [dev.index] if dev is not None and dev.type == "cuda" else None
     # the first bucket's size is a torch-internal default (1 MiB); raise it so the tail of backward is

@@ -30,14 +30,14 @@ def _batch():
     return x, y
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, impl="bucketed"):
     sys.path.insert(0, REPO)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.set_num_threads(1)
     from objectdetectionpl_amd.parallel import init_process_group_from_env, shard_batch, wrap_data_parallel
     init_process_group_from_env(None)
     net = _tiny_net()
-    ddp = wrap_data_parallel(net, None, bucket_mb=1)
+    ddp = wrap_data_parallel(net, None, bucket_mb=1, first_bucket_mb=0.001, impl=impl)      # tiny first bucket: several buckets even here
     x, y = _batch()
     xs, ys = shard_batch(x, y, rank, world)
     _loss(ddp, xs, ys).backward()
@@ -48,11 +48,12 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_ddp_two_ranks_matches_mean_of_rank_gradients():
+@pytest.mark.parametrize("impl", ["bucketed", "torch"])
+def test_ddp_two_ranks_matches_mean_of_rank_gradients(impl):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + (7 if impl == "torch" else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, impl)) for r in range(2)]
     for p in procs:
         p.start()
     got = q.get(timeout=120)
