@@ -108,7 +108,7 @@ def test_step(self, batch, batch_idx):
         y[:, 2:] *= self.img_size
     if self.checkname in ["RetinaNet", "SSD", "YOLOv5"]:
         return {"sample_metric": get_batch_statistics(suppress_output, y, iou_threshold=0.5), "label": y[:, 1].tolist()}
-    return {"sample_metric": self.get_yolo_statistics(out, y), "detections": suppress_output}
+    return {"sample_metric": self.get_yolo_statistics(out, y, output_to_cpu=False), "detections": suppress_output}
 
 
 def test_epoch_end(self, outputs):
