@@ -347,7 +347,8 @@ int odpl_reorg(const float* src, float* dst, int32_t B, int32_t C, int32_t H, in
 size_t odpl_bn_act_workspace_bytes(int64_t R, int32_t C);
 /* x, y: row-major [R = N*H*W, C] (a channels-last NCHW tensor), C % 4 == 0.  training != 0: batch statistics are
  * computed, written to save_mean / save_invstd and folded into running_mean / running_var (momentum, unbiased var);
- * training == 0: the caller pre-fills save_mean / save_invstd from the running statistics. */
+ * training == 0: the caller pre-fills save_mean / save_invstd from the running statistics (needed when a backward will
+ * follow), or passes both as NULL (inference) and the apply pass derives them from running_mean / running_var itself. */
 int odpl_bn_act_forward(const float* x, int64_t R, int32_t C, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, int32_t training, float momentum, float eps,
                         int32_t act, float* save_mean, float* save_invstd, float* y, void* workspace,

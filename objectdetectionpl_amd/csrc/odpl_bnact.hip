@@ -173,7 +173,13 @@ __global__ __launch_bounds__(kT) void bn_apply_kernel(const BnParams P) {
     long long r = i / c4n;
     for (; i < n4; i += stride) {
         const float4 v = reinterpret_cast<const float4*>(P.x)[i];
-        const float4 mu = reinterpret_cast<const float4*>(P.mean)[q], is = reinterpret_cast<const float4*>(P.invstd)[q];
+        float4 mu, is;
+        if (P.mean) { mu = reinterpret_cast<const float4*>(P.mean)[q]; is = reinterpret_cast<const float4*>(P.invstd)[q]; }
+        else {                                               // inference: statistics straight from the running buffers
+            mu = reinterpret_cast<const float4*>(P.running_mean)[q];
+            const float4 rv = reinterpret_cast<const float4*>(P.running_var)[q];
+            is = make_float4(rsqrtf(rv.x + P.eps), rsqrtf(rv.y + P.eps), rsqrtf(rv.z + P.eps), rsqrtf(rv.w + P.eps));
+        }
         const float4 ga = reinterpret_cast<const float4*>(P.gamma)[q], be = reinterpret_cast<const float4*>(P.beta)[q];
         float4 o;
         o.x = act_fwd(ga.x * ((v.x - mu.x) * is.x) + be.x, P.act); o.y = act_fwd(ga.y * ((v.y - mu.y) * is.y) + be.y, P.act);
@@ -278,7 +284,10 @@ extern "C" int odpl_bn_act_forward_strided(const float* x, const float* residual
     if (y_row_stride < C || (y_row_stride & 3)) return ODPL_EINVAL;
     if (residual && y_row_stride != C) return ODPL_EINVAL;
     int rpb, nblk; size_t lds;
-    if (!x || !y || !gamma || !beta || !save_mean || !save_invstd || !plan(R, C, &rpb, &nblk, &lds)) return ODPL_EINVAL;
+    if (!x || !y || !gamma || !beta || !plan(R, C, &rpb, &nblk, &lds)) return ODPL_EINVAL;
+    // save_mean / save_invstd may both be NULL in inference (training == 0): the apply pass then reads running_mean / running_var
+    if ((!save_mean || !save_invstd) && (training || save_mean || save_invstd || !running_mean || !running_var)) return ODPL_EINVAL;
+    if (((uintptr_t)running_mean | (uintptr_t)running_var) & 15) return ODPL_EINVAL;
     if (act < 0 || act > 3 || (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)save_mean | (uintptr_t)save_invstd | (uintptr_t)residual) & 15)) return ODPL_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
     BnParams P = {};

@@ -136,6 +136,19 @@ Tensor bn_act_cat(Tensor x1, Tensor w1, Tensor b1, Tensor rm1, Tensor rv1, Tenso
     return BnActCatFn::apply(x1, w1, b1, rm1, rv1, nbt1, x2, w2, b2, rm2, rv2, nbt2, training, mom1, eps1, act1, mom2, eps2, act2);
 }
 
+// inference (eval mode, no gradient wanted): one launch, statistics read from the running buffers inside the kernel
+Tensor bn_act_infer(const Tensor& x, const Tensor& weight, const Tensor& bias, const Tensor& running_mean, const Tensor& running_var,
+                    double eps, int64_t act, const Tensor& residual) {
+    const int64_t C = x.size(1), R = x.numel() / C;
+    auto y = at::empty_like(x);
+    auto stream = c10::hip::getCurrentHIPStream(x.device().index()).stream();
+    check(odpl_bn_act_forward_strided(x.data_ptr<float>(), residual.defined() ? residual.data_ptr<float>() : nullptr, R, (int32_t)C,
+                                      weight.data_ptr<float>(), bias.data_ptr<float>(), running_mean.data_ptr<float>(), running_var.data_ptr<float>(),
+                                      0, 0.f, (float)eps, (int32_t)act, nullptr, nullptr, y.data_ptr<float>(), C, nullptr, 0, nullptr, stream),
+          "odpl_bn_act_forward_strided");
+    return y;
+}
+
 // act(bn(x)); falls back to ATen (returns an undefined tensor) when the layout is not fusable
 Tensor bn_act(Tensor x, Tensor weight, Tensor bias, Tensor running_mean, Tensor running_var, Tensor num_batches_tracked,
               bool training, double momentum, double eps, int64_t act, c10::optional<Tensor> residual) {
@@ -145,6 +158,9 @@ Tensor bn_act(Tensor x, Tensor weight, Tensor bias, Tensor running_mean, Tensor 
         res = *residual;
         if (res->sizes() != x.sizes() || res->scalar_type() != at::kFloat || !res->is_contiguous(at::MemoryFormat::ChannelsLast)) return Tensor();
     }
+    const bool wants_grad = at::GradMode::is_enabled() && (x.requires_grad() || weight.requires_grad() || bias.requires_grad() ||
+                                                           (res.has_value() && res->requires_grad()));
+    if (!training && !wants_grad) return bn_act_infer(x, weight, bias, running_mean, running_var, eps, act, res.has_value() ? *res : Tensor());
     return BnActFn::apply(x, weight, bias, running_mean, running_var, num_batches_tracked, training, momentum, eps, act, res);
 }
 }  // namespace

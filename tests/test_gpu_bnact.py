@@ -127,3 +127,31 @@ def test_bn_act_cat(training):
         assert torch.allclose(mods[b].bias.grad, mods[a].bias.grad, rtol=1e-4, atol=1e-4)
         assert torch.allclose(mods[b].running_mean, mods[a].running_mean, rtol=1e-5, atol=1e-6)
         assert torch.equal(mods[b].num_batches_tracked, mods[a].num_batches_tracked)
+
+
+@pytest.mark.parametrize("act", ["mish", "leaky", "relu"])
+def test_bn_act_inference_path(act):
+    """eval mode under no_grad: one launch that reads the running buffers itself -- same numbers as the torch modules, and the
+    running statistics / num_batches_tracked are left untouched."""
+    from objectdetectionpl_amd.LightningFunc.utils.bnact import bn_act
+    torch.manual_seed(21)
+    C = 96
+    bn = nn.BatchNorm2d(C).cuda()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5); bn.running_mean.uniform_(-0.3, 0.3); bn.running_var.uniform_(0.2, 2.0)
+    bn.eval()
+    before = (bn.running_mean.clone(), bn.running_var.clone(), int(bn.num_batches_tracked))
+    x = torch.randn(3, C, 20, 20, device="cuda").contiguous(memory_format=torch.channels_last)
+    r = torch.randn_like(x)
+    f = {"mish": F.mish, "leaky": lambda t: F.leaky_relu(t, 0.1), "relu": F.relu}[act]
+    with torch.no_grad():
+        y = bn_act(x, bn, act)
+        yr = bn_act(x, bn, act, r)
+        ref = f(bn(x))
+    assert torch.allclose(y, ref, rtol=1e-5, atol=1e-5) and torch.allclose(yr, ref + r, rtol=1e-5, atol=1e-5)
+    assert torch.equal(bn.running_mean, before[0]) and torch.equal(bn.running_var, before[1]) and int(bn.num_batches_tracked) == before[2]
+    xg = x.clone().requires_grad_()          # eval mode WITH a gradient (RetinaNet.freeze_bn): the autograd path, statistics as constants
+    bn_act(xg, bn, act).sum().backward()
+    xr = x.clone().requires_grad_()
+    f(bn(xr)).sum().backward()
+    assert torch.allclose(xg.grad, xr.grad, rtol=1e-4, atol=1e-5)
