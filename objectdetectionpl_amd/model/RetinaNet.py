@@ -8,6 +8,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ..LightningFunc import lightningUtils as _lu
 from ..LightningFunc import step as _step
 from ..LightningFunc.losses import configure_loss
 from ..LightningFunc.nms import greedy_non_max_suppression
@@ -152,3 +153,5 @@ class RetinaNet(_Base):
     validation_epoch_end = _step.validation_epoch_end
     test_step = _step.test_step
     test_epoch_end = _step.test_epoch_end
+    write_Best_model_path = _lu.write_Best_model_path
+    read_Best_model_path = _lu.read_Best_model_path

@@ -14,6 +14,7 @@ import os
 import torch
 import torch.nn as nn
 
+from ..LightningFunc import lightningUtils as _lu
 from ..LightningFunc import step as _step
 from ..LightningFunc.losses import configure_loss
 from ..LightningFunc.nms import greedy_non_max_suppression
@@ -132,3 +133,5 @@ class SSD(_Base):
     validation_epoch_end = _step.validation_epoch_end
     test_step = _step.test_step
     test_epoch_end = _step.test_epoch_end
+    write_Best_model_path = _lu.write_Best_model_path
+    read_Best_model_path = _lu.read_Best_model_path

@@ -9,6 +9,7 @@ from collections import OrderedDict
 import torch
 import torch.nn as nn
 
+from ..LightningFunc import lightningUtils as _lu
 from ..LightningFunc import step as _step
 from ..LightningFunc.accuracy import get_yolo_statistics as _get_yolo_statistics
 from ..LightningFunc.losses import configure_loss
@@ -139,4 +140,6 @@ class YOLOv3(_Base):
     validation_epoch_end = _step.validation_epoch_end
     test_step = _step.test_step
     test_epoch_end = _step.test_epoch_end
+    write_Best_model_path = _lu.write_Best_model_path
+    read_Best_model_path = _lu.read_Best_model_path
     get_yolo_statistics = _get_yolo_statistics

@@ -8,6 +8,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ..LightningFunc import lightningUtils as _lu
 from ..LightningFunc import step as _step
 from ..LightningFunc.accuracy import get_yolo_statistics as _get_yolo_statistics
 from ..LightningFunc.losses import configure_loss
@@ -197,4 +198,6 @@ class YOLOv5(_Base):
     validation_epoch_end = _step.validation_epoch_end
     test_step = _step.test_step
     test_epoch_end = _step.test_epoch_end
+    write_Best_model_path = _lu.write_Best_model_path
+    read_Best_model_path = _lu.read_Best_model_path
     get_yolo_statistics = _get_yolo_statistics

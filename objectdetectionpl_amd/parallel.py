@@ -68,6 +68,7 @@ class GradAverager:
         if cur:
             self.buckets.append(_Bucket(cur))
         self._bucket_of = {}
+        self.enabled = True
         self._armed = False
         self._handles = []
         for b in self.buckets:
@@ -75,7 +76,23 @@ class GradAverager:
                 self._bucket_of[p] = b
                 self._handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
+    def no_sync(self):
+        """Context manager for gradient accumulation: inside it gradients accumulate locally and nothing is exchanged; the
+        first backward outside it averages the accumulated gradients (the `DistributedDataParallel.no_sync` contract)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def _cm():
+            prev, self.enabled = self.enabled, False
+            try:
+                yield
+            finally:
+                self.enabled = prev
+        return _cm()
+
     def _on_grad(self, p):
+        if not self.enabled:
+            return
         if not self._armed:                       # first gradient of this backward pass: arrange the final wait
             self._armed = True
             torch.autograd.Variable._execution_engine.queue_callback(self.finish)
@@ -124,6 +141,9 @@ class DataParallelHost(torch.nn.Module):
 
     def forward(self, *a, **k):
         return self.module(*a, **k)
+
+    def no_sync(self):
+        return self.averager.no_sync()
 
 
 def wrap_data_parallel(model, device=None, bucket_mb=48, first_bucket_mb=4, broadcast_buffers=True, impl="bucketed"):

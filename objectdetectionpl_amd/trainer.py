@@ -1,7 +1,11 @@
 """A minimal stand-in for the subset of `pytorch_lightning.Trainer` that `run.py:109-118` uses (fit / test with
 max_epochs, limit_*_batches, accumulate_grad_batches), for machines without PL.  One process per GPU; with
-WORLD_SIZE > 1 the module is wrapped by `parallel.wrap_data_parallel` (DDP over RCCL).  Not a training framework:
-checkpointing, early stopping and TensorBoard stay with PL (out of scope)."""
+WORLD_SIZE > 1 the module is wrapped by `parallel.wrap_data_parallel` (bucketed gradient averaging over RCCL) and
+micro-steps that do not end in an optimiser step run under `no_sync`.  `callbacks` may hold a
+`LightningFunc.lightningUtils.ModelCheckpoint` (run.py:86-93): rank 0 writes the top-k `val_loss` checkpoints and the
+model's `write_Best_model_path` records the best one.  Not a training framework: early stopping, LR monitors and
+TensorBoard stay with PL (out of scope)."""
+import contextlib
 import os
 
 import torch
@@ -11,12 +15,14 @@ from . import parallel
 
 class Trainer:
     def __init__(self, max_epochs=1, limit_train_batches=None, limit_val_batches=None, limit_test_batches=None,
-                 accumulate_grad_batches=1, device=None, **_ignored):
+                 accumulate_grad_batches=1, device=None, callbacks=(), **_ignored):
         self.max_epochs = max_epochs
         self.limits = dict(train=limit_train_batches, val=limit_val_batches, test=limit_test_batches)
         self.accumulate = max(1, int(accumulate_grad_batches))
         self.device = torch.device(device or ("cuda:%d" % int(os.environ.get("LOCAL_RANK", "0"))))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.checkpoint_callback = next((c for c in callbacks if hasattr(c, "on_validation_end")), None)
 
     @classmethod
     def from_argparse_args(cls, args, **kw):
@@ -56,7 +62,9 @@ class Trainer:
                     out = model.training_step((x, y), i)
                 finally:
                     model.forward = fwd
-                (out["loss"] / self.accumulate).backward()
+                last_micro = (i + 1) % self.accumulate == 0
+                with (contextlib.nullcontext() if last_micro or not hasattr(net, "no_sync") else net.no_sync()):
+                    (out["loss"] / self.accumulate).backward()
                 if (i + 1) % self.accumulate == 0:
                     opt.step()
                     opt.zero_grad(set_to_none=True)
@@ -67,6 +75,10 @@ class Trainer:
             model.eval()
             vouts = [model.validation_step(b, i) for i, b in self._take(datamodule.val_dataloader(), "val")]
             if vouts:
+                if self.checkpoint_callback is not None and self.rank == 0:
+                    model.checkpoint_callback = self.checkpoint_callback
+                    val_loss = float(torch.stack([o["loss"].detach() for o in vouts]).mean())
+                    self.checkpoint_callback.on_validation_end(model, epoch, val_loss)
                 history.append(("val", epoch, model.validation_epoch_end(vouts)))
         return history
 

@@ -1,6 +1,7 @@
 """End to end on the device: YOLOv4 (reduced input) trained for a few steps on the synthetic module, validated and
 tested through NMS + get_yolo_statistics -- every hot-path kernel family of the YOLO flow in one run."""
 import math
+import os
 
 import pytest
 import torch
@@ -158,3 +159,34 @@ def test_fit_and_test_ssd300():
             getattr(model, f"cl{i}")[0].bias.fill_(0.5)
     res = tr.test(model, dm)
     assert {"precision", "recall", "AP", "f1", "ap_class"} <= set(res)
+
+
+def test_checkpoint_roundtrip_and_grad_accumulation(tmp_path):
+    """run.py:86-96 flow without PL: ModelCheckpoint(monitor=val_loss, top-k) written by the trainer, best path recorded by
+    `write_Best_model_path`, weights restored by `read_Best_model_path`; accumulate_grad_batches = 2 path."""
+    from objectdetectionpl_amd.dataset.Synthetic import SyntheticCocoModule
+    from objectdetectionpl_amd.LightningFunc.lightningUtils import ModelCheckpoint
+    from objectdetectionpl_amd.model.YOLOV2 import YOLOv2
+    from objectdetectionpl_amd.trainer import Trainer
+
+    class V2(Args):
+        model_name = "YOLOv2"
+
+    torch.manual_seed(0)
+    dm = SyntheticCocoModule(batch_size=2, img_size=96, num_classes=3, targets_per_image=2, steps_per_epoch=4, device="cuda:0")
+    model = YOLOv2(dm.get_class(), V2())
+    model.img_size = 96; model.criterion.img_dim = 96
+    model.dir = str(tmp_path / "log")
+    cb = ModelCheckpoint(monitor="val_loss", dirpath=str(tmp_path / "ck"), filename="YOLOv2-{epoch:02d}-{val_loss:.2f}", save_top_k=2, mode="min")
+    tr = Trainer(max_epochs=3, limit_val_batches=1, accumulate_grad_batches=2, device="cuda:0", callbacks=[cb])
+    tr.fit(model, dm)
+    files = sorted(os.listdir(tmp_path / "ck"))
+    assert 1 <= len(files) <= 2 and all(f.startswith("YOLOv2-epoch=") and f.endswith(".ckpt") for f in files)
+    assert cb.best_model_path and os.path.exists(cb.best_model_path)
+    assert open(os.path.join(model.dir, "best_model_path.txt")).read().strip() == cb.best_model_path
+    fresh = YOLOv2(dm.get_class(), V2())
+    fresh.dir = model.dir
+    assert fresh.read_Best_model_path() == cb.best_model_path
+    best = torch.load(cb.best_model_path, map_location="cpu", weights_only=True)["state_dict"]
+    for k, v in fresh.state_dict().items():
+        assert torch.equal(v.cpu(), best[k])

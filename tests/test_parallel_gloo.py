@@ -81,3 +81,53 @@ def test_shard_batch_rebases_image_index():
     assert xs.shape[0] == 2 and ys[:, 0].tolist() == [0.0, 1.0, 1.0]
     with pytest.raises(ValueError):
         shard_batch(x[:3], y, 0, 2)
+
+
+def _worker_accum(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    from objectdetectionpl_amd.parallel import init_process_group_from_env, shard_batch, wrap_data_parallel
+    init_process_group_from_env(None)
+    net = _tiny_net()
+    host = wrap_data_parallel(net, None, bucket_mb=1, first_bucket_mb=0.001)
+    x, y = _batch()
+    xs, ys = shard_batch(x, y, rank, world)
+    with host.no_sync():                               # micro-step 1: local accumulation only
+        _loss(host, xs, ys).backward()
+    local_after_first = [p.grad.clone() for p in net.parameters()]
+    _loss(host, xs.flip(3), ys).backward()             # micro-step 2: exchange of the accumulated gradients
+    if rank == 0:
+        q.put(([g.numpy() for g in local_after_first], [p.grad.clone().numpy() for p in net.parameters()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_no_sync_accumulates_locally_then_averages():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + 13
+    procs = [ctx.Process(target=_worker_accum, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    first, final = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    sys.path.insert(0, REPO)
+    from objectdetectionpl_amd.parallel import shard_batch
+    x, y = _batch()
+    tot, rank0_first = None, None
+    for r in range(2):
+        net = _tiny_net()
+        xs, ys = shard_batch(x, y, r, 2)
+        _loss(net, xs, ys).backward()
+        if r == 0:
+            rank0_first = [p.grad.clone() for p in net.parameters()]
+        _loss(net, xs.flip(3), ys).backward()
+        gs = [p.grad for p in net.parameters()]
+        tot = gs if tot is None else [a + b for a, b in zip(tot, gs)]
+    for a, b in zip(first, rank0_first):               # nothing was exchanged inside no_sync
+        assert torch.allclose(torch.from_numpy(a), b, rtol=1e-4, atol=1e-6)
+    for a, b in zip(final, tot):
+        assert torch.allclose(torch.from_numpy(a), b / 2, rtol=1e-4, atol=1e-6)
