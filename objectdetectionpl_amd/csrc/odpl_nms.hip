@@ -29,6 +29,7 @@ namespace {
 using namespace odpl;
 
 constexpr int kPrepT = 256;
+constexpr int kPrepU = 24;             // class planes loaded per lane before the first compare
 constexpr int kImgT = 1024;
 
 struct YParams {
@@ -40,7 +41,7 @@ struct YParams {
     float4* box; float* conf; float* cconf; int* label; float* score;
     float4* sbox; float* sconf; float* scconf; int* slabel;
     float* key; unsigned* idx;           // [B*Npad] sort buffers
-    int* nvalid;                          // [B] (kept 0 between calls)
+    int* nvalid;                          // [B] unused since the image kernel counts for itself (slot kept: workspace layout)
     float* out; int* out_counts;
 };
 
@@ -63,18 +64,21 @@ __global__ __launch_bounds__(kPrepT) void yolo_nms_prep_kernel(const YParams P) 
     }
     const int k0 = (int)(((long long)nc * q) / 4), k1 = (int)(((long long)nc * (q + 1)) / 4);
     float best = -INFINITY; int bi = 0x7fffffff; bool have = false;
+    float bx_[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     if (base) {
-        int k = k0;
-        for (; k + 8 <= k1; k += 8) {                                        // 8 independent loads in flight per lane
-            float v[8];
+        // ONE trip to memory for the common case: the wave's whole class range (<= kPrepU loads per lane, 20 at C = 80) and,
+        // in wave 0, the five box / confidence planes are issued before anything is consumed
+        if (q == 0) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = base[(size_t)(5 + k + u) * G2];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) if (!have || (best == best && (v[u] > best || v[u] != v[u]))) { best = v[u]; bi = k + u; have = true; }
+            for (int u = 0; u < 5; ++u) bx_[u] = base[(size_t)u * G2];
         }
-        for (; k < k1; ++k) {
-            const float v = base[(size_t)(5 + k) * G2];
-            if (!have || (best == best && (v > best || v != v))) { best = v; bi = k; have = true; }
+        for (int k = k0; k < k1; k += kPrepU) {
+            float v[kPrepU];
+#pragma unroll
+            for (int u = 0; u < kPrepU; ++u) { const int kk = k + u < k1 ? k + u : k1 - 1; v[u] = base[(size_t)(5 + kk) * G2]; }
+#pragma unroll
+            for (int u = 0; u < kPrepU; ++u)
+                if (k + u < k1 && (!have || (best == best && (v[u] > best || v[u] != v[u])))) { best = v[u]; bi = k + u; have = true; }
         }
     }
     s_best[q][lane] = best; s_bi[q][lane] = have ? bi : 0x7fffffff;
@@ -88,8 +92,8 @@ __global__ __launch_bounds__(kPrepT) void yolo_nms_prep_kernel(const YParams P) 
                 if (ok == 0x7fffffff) continue;
                 if (bk == 0x7fffffff || (bv == bv && (ov > bv || ov != ov))) { bv = ov; bk = ok; }
             }
-            const float x = base[0], y = base[(size_t)G2], w = base[(size_t)2 * G2], h = base[(size_t)3 * G2];
-            const float cf = base[(size_t)4 * G2];
+            const float x = bx_[0], y = bx_[1], w = bx_[2], h = bx_[3];
+            const float cf = bx_[4];
             const Box4 bx = corners_of(x, y, w, h);                          // xywh2xyxy, YOLOV4.py:253
             const size_t o = (size_t)b * P.N + n;
             P.box[o] = make_float4(bx.x1, bx.y1, bx.x2, bx.y2);
@@ -102,22 +106,21 @@ __global__ __launch_bounds__(kPrepT) void yolo_nms_prep_kernel(const YParams P) 
             P.idx[(size_t)b * P.Npad + n] = 0xffffffffu;
         }
         const unsigned long long m = __ballot(valid);
-        if (lane == 0 && m) atomicAdd(&P.nvalid[b], __popcll(m));
+        (void)m;                                                 // the image kernel counts the valid candidates itself (no same-address atomics)
     }
 }
 
 // Fallback (nv > kCap or more than kMaxCls classes): global-memory sort + one block-wide sweep per pivot.
-__device__ void yolo_nms_image_serial(const YParams& P) {
+__device__ void yolo_nms_image_serial(const YParams& P, int nv) {
     __shared__ float s_red[6 * (kImgT / 64)];
     __shared__ int s_min[kImgT / 64];
     __shared__ int s_p;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int nv = P.nvalid[b];
     float* key = P.key + (size_t)b * P.Npad;
     unsigned* idx = P.idx + (size_t)b * P.Npad;
     float* out = P.out + (size_t)b * P.N * 7;
     if (nv == 0) {                                             // "continue": output[image_i] stays None
-        if (tid == 0) { P.out_counts[b] = -1; P.nvalid[b] = 0; }
+        if (tid == 0) P.out_counts[b] = -1;
         return;
     }
     bitonic_sort_global(key, idx, P.Npad);
@@ -168,7 +171,7 @@ __device__ void yolo_nms_image_serial(const YParams& P) {
         p = s_p; ++K;
         __syncthreads();
     }
-    if (tid == 0) { P.out_counts[b] = K; P.nvalid[b] = 0; }
+    if (tid == 0) P.out_counts[b] = K;
 }
 
 constexpr int kCap = 16384;            // candidates per image sorted / bucketed in LDS (8 B each = 128 KB)
@@ -205,16 +208,26 @@ __global__ __launch_bounds__(kImgT) void yolo_nms_image_kernel(const YParams P) 
     __shared__ int s_off[kMaxCls];
     __shared__ int s_wtot[kImgT / 64];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int nv = P.nvalid[b], nc = P.no - 5;
-    if (nv == 0) {                                             // "continue": output[image_i] stays None
-        if (tid == 0) { P.out_counts[b] = -1; P.nvalid[b] = 0; }
-        return;
-    }
-    if (nv > kCap || nc > kMaxCls) { yolo_nms_image_serial(P); return; }
-    float* s_key = reinterpret_cast<float*>(s_dyn);
-    unsigned* s_idx = reinterpret_cast<unsigned*>(s_dyn + 4 * kCap);
+    const int nc = P.no - 5;
     const float* key = P.key + (size_t)b * P.Npad;
     const unsigned* idx = P.idx + (size_t)b * P.Npad;
+    int nv = 0;                                                // valid candidates of this image (YOLOV4.py:258)
+    {
+        int c = 0;
+        for (int n = tid; n < P.N; n += kImgT) c += idx[n] != 0xffffffffu;
+        c = wave_sum_i(c);
+        if (lane == 0) s_wtot[wv] = c;
+        __syncthreads();
+        for (int w = 0; w < kImgT / 64; ++w) nv += s_wtot[w];
+        __syncthreads();
+    }
+    if (nv == 0) {                                             // "continue": output[image_i] stays None
+        if (tid == 0) P.out_counts[b] = -1;
+        return;
+    }
+    if (nv > kCap || nc > kMaxCls) { yolo_nms_image_serial(P, nv); return; }
+    float* s_key = reinterpret_cast<float*>(s_dyn);
+    unsigned* s_idx = reinterpret_cast<unsigned*>(s_dyn + 4 * kCap);
     float* out = P.out + (size_t)b * P.N * 7;
     const size_t o0 = (size_t)b * P.N;
     const unsigned long long lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
@@ -382,7 +395,7 @@ __global__ __launch_bounds__(kImgT) void yolo_nms_image_kernel(const YParams P) 
         __threadfence_block();
         __syncthreads();
     }
-    if (tid == 0) { P.out_counts[b] = K; P.nvalid[b] = 0; }
+    if (tid == 0) P.out_counts[b] = K;
 }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -441,7 +454,6 @@ extern "C" int odpl_yolo_nms(const odpl_yolo_nms_desc_t* d, void* workspace, siz
     P.sbox = (float4*)(ws + pl.sbox); P.sconf = (float*)(ws + pl.sconf); P.scconf = (float*)(ws + pl.scconf);
     P.slabel = (int*)(ws + pl.slabel); P.key = (float*)(ws + pl.key); P.idx = (unsigned*)(ws + pl.idx);
     P.nvalid = (int*)(ws + pl.nvalid); P.out = out_dets; P.out_counts = out_counts;
-    if (!(d->flags & ODPL_NMS_STATE_CLEAN)) ODPL_HIP_TRY(hipMemsetAsync(P.nvalid, 0, (size_t)d->B * sizeof(int), stream));
     prof_begin(ODPL_PROF_YOLO_NMS_PREP, stream);
     hipLaunchKernelGGL(yolo_nms_prep_kernel, dim3((pl.Npad + 63) / 64, d->B), dim3(kPrepT), 0, stream, P);
     prof_end(ODPL_PROF_YOLO_NMS_PREP, stream);
