@@ -475,6 +475,7 @@ extern "C" int odpl_yolo_nms(const odpl_yolo_nms_desc_t* d, void* workspace, siz
 namespace {
 constexpr int kRows = 64;             // anchors per LDS sub-tile in the prep kernel (4 lanes scan one row)
 constexpr int kMaxTopk = 1024;
+constexpr int kKeyRegs = 48;           // candidate keys per thread held in registers during the top-k bisection (49 152 candidates)
 
 struct GParams {
     const float* loc; const float* cls; const float* anchors;
@@ -482,6 +483,7 @@ struct GParams {
     float nms_thresh, class_thresh;
     float* score; int* label;          // [B*An] all anchors
     float* ckey; int* cidx;            // [B*An] candidates (compacted, index order)
+    int* tile_cnt; int ntiles;         // [B*ntiles] candidates per kRows-anchor tile (written by the prep kernel)
     float* out; int* out_counts;
 };
 
@@ -535,11 +537,18 @@ __global__ __launch_bounds__(256) void greedy_nms_prep_kernel(const GParams P) {
         const size_t o = (size_t)b * P.An + a0 + r;
         P.score[o] = best; P.label[o] = bi;
     }
+    // candidates of this tile (RetinaNet.py:129: score > class_thresh): the image kernel scans these counts instead of
+    // sweeping all An scores behind workgroup barriers
+    __shared__ int s_tc[4];
+    const unsigned long long pm = __ballot(r < nr && q == 0 && best > P.class_thresh);
+    if ((tid & 63) == 0) s_tc[tid >> 6] = __popcll(pm);
+    __syncthreads();
+    if (tid == 0) P.tile_cnt[(size_t)b * P.ntiles + blockIdx.x] = s_tc[0] + s_tc[1] + s_tc[2] + s_tc[3];
 }
 
 __global__ __launch_bounds__(kImgT) void greedy_nms_image_kernel(const GParams P) {
-    __shared__ int s_wcnt[kImgT / 64];
-    __shared__ int s_off, s_cnt, s_p;
+    __shared__ int s_wcnt[kImgT / 64], s_wcnt2[kImgT / 64];
+    __shared__ int s_off, s_p;
     __shared__ float s_key[kMaxTopk]; __shared__ int s_pos[kMaxTopk];
     __shared__ float4 s_box[kMaxTopk]; __shared__ float s_area[kMaxTopk]; __shared__ int s_alive[kMaxTopk];
     __shared__ int s_keep[kMaxTopk];
@@ -547,38 +556,74 @@ __global__ __launch_bounds__(kImgT) void greedy_nms_image_kernel(const GParams P
     const size_t o0 = (size_t)b * P.An;
     const float* score = P.score + o0;
     float* ckey = P.ckey + o0; int* cidx = P.cidx + o0;
+    // ---- stable compaction of score > class_thresh (RetinaNet.py:129-130) from the per-tile counts of the prep kernel:
+    //      block scan of the counts (tile offsets, in place), then every wave walks its tiles and touches only non-empty ones
+    int* tcnt = P.tile_cnt + (size_t)b * P.ntiles;
     if (tid == 0) s_off = 0;
     __syncthreads();
-    // ---- stable compaction of score > class_thresh (RetinaNet.py:129-130)
-    for (int base = 0; base < P.An; base += kImgT) {
-        const int a = base + tid;
-        const float s = a < P.An ? score[a] : 0.f;
-        const bool f = a < P.An && s > P.class_thresh;
-        const unsigned long long m = __ballot(f);
-        if (lane == 0) s_wcnt[wv] = __popcll(m);
+    for (int base = 0; base < P.ntiles; base += kImgT) {
+        const int t = base + tid;
+        const int c = t < P.ntiles ? tcnt[t] : 0;
+        int inc = c;
+        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
+        if (lane == 63) s_wcnt[wv] = inc;
         __syncthreads();
         int off = s_off, tot = 0;
         for (int w = 0; w < kImgT / 64; ++w) { if (w < wv) off += s_wcnt[w]; tot += s_wcnt[w]; }
-        if (f) { const int pos = off + __popcll(m & ((1ull << lane) - 1ull)); ckey[pos] = s; cidx[pos] = a; }
+        if (t < P.ntiles) tcnt[t] = c ? ((off + inc - c) | (c << 24)) : -1;      // offset (24 bits) | count (<= 64); -1 = empty tile
         __syncthreads();
         if (tid == 0) s_off += tot;
         __syncthreads();
     }
+    constexpr int kTU = 8;                                                        // tiles in flight per wave: independent loads first
+    for (int t0 = wv; t0 < P.ntiles; t0 += kTU * (kImgT / 64)) {
+        int oc[kTU]; float sc[kTU];
+#pragma unroll
+        for (int u = 0; u < kTU; ++u) {
+            const int t = t0 + u * (kImgT / 64);
+            oc[u] = t < P.ntiles ? tcnt[t] : -1;                                  // written by this workgroup above (barrier in between)
+            const int a = t * kRows + lane;
+            sc[u] = (t < P.ntiles && a < P.An) ? score[a] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < kTU; ++u) {
+            if (oc[u] < 0) continue;
+            const int a = (t0 + u * (kImgT / 64)) * kRows + lane;
+            const bool f = a < P.An && sc[u] > P.class_thresh;
+            const unsigned long long mk = __ballot(f);
+            if (f) { const int pos = (oc[u] & 0xffffff) + __popcll(mk & ((1ull << lane) - 1ull)); ckey[pos] = sc[u]; cidx[pos] = a; }
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
     const int n = s_off;
     float* out = P.out + (size_t)b * P.topk * 7;
     if (n <= 1) {            // 0: nothing; 1: the reference raises IndexError (0-dim squeeze) -- reported via counts
         if (tid == 0) { P.out_counts[b * 2] = 0; P.out_counts[b * 2 + 1] = n; }
         return;
     }
-    // ---- top-k by score (RetinaNet.py:140-141): k-th largest by bisection on the float bits
+    // ---- top-k by score (RetinaNet.py:140-141): k-th largest by bisection on the float bits.  Up to kKeyRegs * 1024
+    //      candidate keys are held in registers, so the <= 31 bisection rounds are compares + one block reduction each
+    //      (no memory traffic); more candidates than that fall back to re-reading the keys from L2.
     int m = n < P.topk ? n : P.topk;
     unsigned T = 0;
+    unsigned kreg[kKeyRegs];
+    const bool in_regs = n <= kKeyRegs * kImgT;
+    if (in_regs) {
+#pragma unroll
+        for (int j = 0; j < kKeyRegs; ++j) { const int i = tid + j * kImgT; kreg[j] = i < n ? __float_as_uint(ckey[i]) : 0u; }
+    }
     if (n > P.topk) {
         unsigned lo = 0u, hi = 0x7f800000u;                 // scores are positive finite floats
         while (lo < hi) {                                   // largest T with count(bits >= T) >= topk
             const unsigned mid = lo + (hi - lo + 1) / 2;
             int c = 0;
-            for (int i = tid; i < n; i += kImgT) c += (__float_as_uint(ckey[i]) >= mid);
+            if (in_regs) {
+#pragma unroll
+                for (int j = 0; j < kKeyRegs; ++j) c += (kreg[j] >= mid);       // padding keys are 0 < mid
+            } else {
+                for (int i = tid; i < n; i += kImgT) c += (__float_as_uint(ckey[i]) >= mid);
+            }
             c = wave_sum_i(c);
             __syncthreads();
             if (lane == 0) s_wcnt[wv] = c;
@@ -589,25 +634,31 @@ __global__ __launch_bounds__(kImgT) void greedy_nms_image_kernel(const GParams P
         }
         T = lo;
     }
-    // gather the selected candidates: bits > T first (all of them), then bits == T in index order until m
-    if (tid == 0) s_cnt = 0;
-    __syncthreads();
-    for (int pass = 0; pass < 2; ++pass) {
-        for (int base = 0; base < n; base += kImgT) {
-            const int i = base + tid;
-            const unsigned u = i < n ? __float_as_uint(ckey[i]) : 0u;
-            const bool f = i < n && (pass == 0 ? u > T : (u == T));
-            const unsigned long long mk = __ballot(f);
-            if (lane == 0) s_wcnt[wv] = __popcll(mk);
-            __syncthreads();
-            int off = s_cnt, tot = 0;
-            for (int w = 0; w < kImgT / 64; ++w) { if (w < wv) off += s_wcnt[w]; tot += s_wcnt[w]; }
-            if (f) { const int pos = off + __popcll(mk & ((1ull << lane) - 1ull)); if (pos < m) { s_key[pos] = ckey[i]; s_pos[pos] = i; } }
-            __syncthreads();
-            if (tid == 0) s_cnt = min(s_cnt + tot, m);
-            __syncthreads();
+    // gather the selected candidates in index order: every key > T, then keys == T until m are taken.  Each wave owns a
+    // contiguous slice of the candidate list: count, one block scan, then write -- no barrier inside the sweeps.
+    {
+        const int per = ((n + kImgT / 64 - 1) / (kImgT / 64) + 63) / 64 * 64;   // slice length, multiple of 64
+        const int i0 = wv * per, i1 = (i0 + per) < n ? (i0 + per) : n;
+        int cg = 0, ce = 0;
+        for (int i = i0 + lane; i < i1; i += 64) { const unsigned u = __float_as_uint(ckey[i]); cg += (u > T); ce += (u == T); }
+        cg = wave_sum_i(cg); ce = wave_sum_i(ce);
+        __syncthreads();
+        if (lane == 0) { s_wcnt[wv] = cg; s_wcnt2[wv] = ce; }
+        __syncthreads();
+        int og = 0, oe = 0, totg = 0;
+        for (int w = 0; w < kImgT / 64; ++w) { if (w < wv) { og += s_wcnt[w]; oe += s_wcnt2[w]; } totg += s_wcnt[w]; }
+        oe += totg;                                                              // the == T block follows all > T entries
+        for (int base = i0; base < i1; base += 64) {
+            const int i = base + lane;
+            const unsigned u = i < i1 ? __float_as_uint(ckey[i]) : 0u;
+            const bool fg = i < i1 && u > T, fe = i < i1 && u == T && n > P.topk;
+            const unsigned long long mg = __ballot(fg), me = __ballot(fe);
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            if (fg) { const int pos = og + __popcll(mg & lt); if (pos < m) { s_key[pos] = __uint_as_float(u); s_pos[pos] = i; } }
+            if (fe) { const int pos = oe + __popcll(me & lt); if (pos < m) { s_key[pos] = __uint_as_float(u); s_pos[pos] = i; } }
+            og += __popcll(mg); oe += __popcll(me);
         }
-        if (n <= P.topk) break;                             // T == 0: pass 0 took everything
+        __syncthreads();
     }
     // ---- sort the m survivors by (score desc, filtered position asc) in LDS
     int mp = 1; while (mp < m) mp <<= 1;
@@ -633,44 +684,34 @@ __global__ __launch_bounds__(kImgT) void greedy_nms_image_kernel(const GParams P
         s_area[tid] = (bx.x2 - bx.x1 + 1.0f) * (bx.y2 - bx.y1 + 1.0f);
         s_alive[tid] = 1;
     }
-    if (tid == 0) s_p = 0;
     __syncthreads();
-    // ---- greedy loop (RetinaNet.py:143-169): stop WITHOUT keeping when one box is left
-    int K = 0;
-    while (true) {
-        int c = (tid < m && s_alive[tid]) ? 1 : 0;
-        c = wave_sum_i(c);
-        __syncthreads();
-        if (lane == 0) s_wcnt[wv] = c;
-        __syncthreads();
-        int alive = 0;
-        for (int w = 0; w < kImgT / 64; ++w) alive += s_wcnt[w];
-        if (alive <= 1) break;
-        const int p = s_p;
-        const float4 tb = s_box[p]; const float ta = s_area[p];
-        int nxt = INT_MAX;
-        if (tid < m && tid != p && s_alive[tid]) {
-            const float4 q = s_box[tid];
-            const float w = fmaxf(fminf(q.z, tb.z) - fmaxf(q.x, tb.x) + 1.0f, 0.0f);     // clamp(min=x1[i]) etc.
-            const float h = fmaxf(fminf(q.w, tb.w) - fmaxf(q.y, tb.y) + 1.0f, 0.0f);
-            const float inter = w * h;
-            const float ovr = inter / (ta + s_area[tid] - inter);
-            if (ovr <= P.nms_thresh) nxt = tid; else s_alive[tid] = 0;
+    // ---- greedy loop (RetinaNet.py:143-169): stop WITHOUT keeping when one box is left.  <= topk boxes: ONE wave runs the
+    //      whole loop out of LDS (entry j always belongs to lane j % 64), wave reductions only -- the 4 workgroup barriers per
+    //      pivot of a block-wide loop were ~2 us x 100 pivots.
+    if (wv == 0) {
+        int K = 0, p = 0, alive = m;
+        while (alive > 1) {
+            const float4 tb = s_box[p]; const float ta = s_area[p];
+            int nxt = INT_MAX, killed = 0;
+            for (int j = lane; j < m; j += 64) {
+                if (j == p || !s_alive[j]) continue;
+                const float4 q = s_box[j];
+                const float w = fmaxf(fminf(q.z, tb.z) - fmaxf(q.x, tb.x) + 1.0f, 0.0f);     // clamp(min=x1[i]) etc.
+                const float h = fmaxf(fminf(q.w, tb.w) - fmaxf(q.y, tb.y) + 1.0f, 0.0f);
+                const float inter = w * h;
+                const float ovr = inter / (ta + s_area[j] - inter);
+                if (ovr <= P.nms_thresh) nxt = min(nxt, j); else { s_alive[j] = 0; ++killed; }
+            }
+            for (int o = 32; o > 0; o >>= 1) { nxt = min(nxt, __shfl_xor(nxt, o, 64)); killed += __shfl_xor(killed, o, 64); }
+            if (lane == (p & 63)) { s_alive[p] = 0; s_keep[K] = s_pos[p]; }
+            ++K;
+            alive -= killed + 1;
+            p = nxt == INT_MAX ? 0 : nxt;
         }
-        for (int o = 32; o > 0; o >>= 1) nxt = min(nxt, __shfl_down(nxt, o, 64));
-        __syncthreads();
-        if (lane == 0) s_wcnt[wv] = nxt;
-        __syncthreads();
-        if (tid == 0) {
-            int mn = INT_MAX;
-            for (int w = 0; w < kImgT / 64; ++w) mn = min(mn, s_wcnt[w]);
-            s_keep[K] = s_pos[p];
-            s_alive[p] = 0;
-            s_p = mn == INT_MAX ? 0 : mn;
-        }
-        ++K;
-        __syncthreads();
+        if (lane == 0) s_p = K;
     }
+    __syncthreads();
+    const int K = s_p;
     // ---- output rows (RetinaNet.py:170-176): boxes / labels indexed by the FILTERED position in the UNFILTERED arrays
     if (tid < K) {
         const int k = s_keep[tid];
@@ -682,9 +723,9 @@ __global__ __launch_bounds__(kImgT) void greedy_nms_image_kernel(const GParams P
     if (tid == 0) { P.out_counts[b * 2] = K; P.out_counts[b * 2 + 1] = n; }
 }
 
-struct GPlan { size_t score, label, ckey, cidx, total; };
+struct GPlan { size_t score, label, ckey, cidx, tile_cnt, total; int ntiles; };
 bool make_gplan(const odpl_greedy_nms_desc_t* d, GPlan* p) {
-    if (!d || d->B < 1 || d->An < 1 || d->C < 1 || d->topk < 1 || d->topk > kMaxTopk) return false;
+    if (!d || d->B < 1 || d->An < 1 || d->An >= (1 << 24) || d->C < 1 || d->topk < 1 || d->topk > kMaxTopk) return false;
     if (!d->loc || !d->cls || !d->anchors) return false;
     if ((size_t)kRows * (d->C + 4) * 4 > 60 * 1024) return false;
     const size_t BN = (size_t)d->B * d->An;
@@ -693,6 +734,8 @@ bool make_gplan(const odpl_greedy_nms_desc_t* d, GPlan* p) {
     p->label = off; off += align_up(BN * 4, 256);
     p->ckey = off;  off += align_up(BN * 4, 256);
     p->cidx = off;  off += align_up(BN * 4, 256);
+    p->ntiles = (d->An + kRows - 1) / kRows;
+    p->tile_cnt = off; off += align_up((size_t)d->B * p->ntiles * 4, 256);
     p->total = off;
     return true;
 }
@@ -713,6 +756,7 @@ extern "C" int odpl_greedy_nms(const odpl_greedy_nms_desc_t* d, void* workspace,
     P.loc = d->loc; P.cls = d->cls; P.anchors = d->anchors; P.B = d->B; P.An = d->An; P.C = d->C; P.topk = d->topk;
     P.nms_thresh = d->nms_thresh; P.class_thresh = d->class_thresh;
     P.score = (float*)(ws + pl.score); P.label = (int*)(ws + pl.label); P.ckey = (float*)(ws + pl.ckey); P.cidx = (int*)(ws + pl.cidx);
+    P.tile_cnt = (int*)(ws + pl.tile_cnt); P.ntiles = pl.ntiles;
     P.out = out_dets; P.out_counts = out_counts;
     prof_begin(ODPL_PROF_GREEDY_NMS_PREP, stream);
     hipLaunchKernelGGL(greedy_nms_prep_kernel, dim3((d->An + kRows - 1) / kRows, d->B), dim3(256), (size_t)kRows * (d->C + 4) * 4, stream, P);
