@@ -15,6 +15,7 @@ namespace {
 using namespace odpl;
 constexpr int kCells = 64;
 constexpr int kThreads = 256;
+constexpr int kLoads = 11;
 
 struct DParams {
     const float* head[ODPL_MAX_SCALES];
@@ -34,15 +35,15 @@ __global__ __launch_bounds__(kThreads) void yolo_decode_kernel(const DParams P) 
     const int lb = blockIdx.x - P.blk0[s], a = lb / tiles, sp0 = (lb - a * tiles) * kCells;
     const int nc = (HW - sp0) < kCells ? (HW - sp0) : kCells;
     const float* src = P.head[s] + ((size_t)(b * P.A[s] + a) * CH) * HW + sp0;
-    for (int e = tid; e < CH * kCells; e += 4 * kThreads) {   // channel rows: 64 consecutive floats per row, 4 loads in flight
-        float v[4];
+    for (int e = tid; e < CH * kCells; e += kLoads * kThreads) {   // channel rows: 64 consecutive floats per row; kLoads loads in
+        float v[kLoads];                                            // flight per lane (C = 80: the whole tile in two trips)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kLoads; ++u) {
             const int ee = e + u * kThreads, c = ee >> 6, i = ee & 63;
             v[u] = (c < CH && i < nc) ? src[(size_t)c * HW + i] : 0.f;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kLoads; ++u) {
             const int ee = e + u * kThreads, c = ee >> 6, i = ee & 63;
             if (c < CH && i < nc) s_t[c * ld + i] = v[u];
         }
