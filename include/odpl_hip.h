@@ -368,13 +368,16 @@ int odpl_bn_act_backward(const float* x, const float* grad_y, int64_t R, int32_t
  * stride in elements (multiple of 4, slice start 16-byte aligned) -- the epilogue writes straight into its half of a
  * `torch.cat((a, b), 1)` buffer (the CSP merges of utils/YoloV4Utils.py:264-398) and the backward reads its half of the
  * concatenated gradient, so neither the cat copy nor the slice copies exist.  residual requires a dense y. */
-int odpl_bn_act_forward_strided(const float* x, const float* residual, int64_t R, int32_t C, const float* gamma, const float* beta,
+/* bf16 != 0: x / residual / y (forward) and x / grad_y / grad_x (backward) are bfloat16 (the activations of a bf16-autocast
+ * network, BASELINE config 5); gamma / beta / statistics / their gradients stay fp32, all arithmetic is fp32 and results are
+ * rounded to bf16 once (after the activation), 8-byte alignment suffices. */
+int odpl_bn_act_forward_strided(const void* x, const void* residual, int32_t bf16, int64_t R, int32_t C, const float* gamma, const float* beta,
                                 float* running_mean, float* running_var, int32_t training, float momentum, float eps,
-                                int32_t act, float* save_mean, float* save_invstd, float* y, int64_t y_row_stride,
+                                int32_t act, float* save_mean, float* save_invstd, void* y, int64_t y_row_stride,
                                 void* workspace, size_t workspace_bytes, int64_t* num_batches_tracked, void* stream);
-int odpl_bn_act_backward_strided(const float* x, const float* grad_y, int64_t gy_row_stride, int64_t R, int32_t C,
+int odpl_bn_act_backward_strided(const void* x, const void* grad_y, int64_t gy_row_stride, int32_t bf16, int64_t R, int32_t C,
                                  const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
-                                 int32_t training, int32_t act, float* grad_x, float* grad_gamma, float* grad_beta,
+                                 int32_t training, int32_t act, void* grad_x, float* grad_gamma, float* grad_beta,
                                  void* workspace, size_t workspace_bytes, void* stream);
 
 /* launch-geometry knobs (process-wide; defaults are the tuned values) */

@@ -17,8 +17,11 @@ def _workspace(dev, need):
 
 
 def fusable(x, bn):
-    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] % 4 == 0 and bn.momentum is not None
-            and bn.affine and bn.track_running_stats and x.is_contiguous(memory_format=torch.channels_last))
+    """Channels-last fp32 activations, or bf16 ones (a bf16-autocast network) when the C++ binding is built; fp32 affine BN."""
+    ok_dtype = x.dtype == torch.float32 or (x.dtype == torch.bfloat16 and _lib.torch_ext() is not None)
+    return (x.is_cuda and ok_dtype and x.dim() == 4 and x.shape[1] % 4 == 0 and bn.momentum is not None
+            and bn.affine and bn.track_running_stats and bn.weight.dtype == torch.float32
+            and x.is_contiguous(memory_format=torch.channels_last))
 
 
 class _BnActFn(torch.autograd.Function):

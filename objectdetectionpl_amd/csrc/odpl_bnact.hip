@@ -44,11 +44,11 @@ __device__ __forceinline__ float act_grad(float z, int act) {
 }
 
 struct BnParams {
-    const float* x; const float* gy; float* y; float* gx;
+    const void* x; const void* gy; void* y; void* gx;  // activations / their gradients: fp32 or bf16 (template BF)
     const float* gamma; const float* beta;
     float* mean; float* invstd;                  // [C] batch statistics (saved for backward)
     float* running_mean; float* running_var;     // [C] or null
-    const float* res;                            // optional residual added after the activation (same layout as y)
+    const void* res;                             // optional residual added after the activation (same layout as y)
     double* part;                                // [nblk][C][2]
     float* dgamma; float* dbeta;                 // [C]
     long long* num_batches_tracked;              // nn.BatchNorm2d buffer, +1 per training forward (or null)
@@ -57,8 +57,29 @@ struct BnParams {
     float eps, momentum;
 };
 
+// Activations are fp32 (a channel quad = one 16-B float4) or bf16 (a quad = 8 B): statistics, affine parameters and all
+// arithmetic are fp32 either way; bf16 results are rounded once (round-to-nearest-even), after the activation.
+template <bool BF>
+__device__ __forceinline__ float4 ld_quad(const void* p, long long qi) {
+    if (!BF) return reinterpret_cast<const float4*>(p)[qi];
+    const uint2 u = reinterpret_cast<const uint2*>(p)[qi];
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ unsigned bf16_rne(float f) {
+    const unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;          // NaN stays NaN (quiet)
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+template <bool BF>
+__device__ __forceinline__ void st_quad(void* p, long long qi, const float4& v) {
+    if (!BF) { reinterpret_cast<float4*>(p)[qi] = v; return; }
+    uint2 u;
+    u.x = bf16_rne(v.x) | (bf16_rne(v.y) << 16); u.y = bf16_rne(v.z) | (bf16_rne(v.w) << 16);
+    reinterpret_cast<uint2*>(p)[qi] = u;
+}
+
 // one pass over a row tile: per-channel sums of (a, b) where (a, b) = f(row, channel-quad)
-template <bool BWD>
+template <bool BWD, bool BF>
 __global__ __launch_bounds__(kT) void bn_reduce_kernel(const BnParams P) {
     extern __shared__ double s_red[];                       // [rows_par][C][2] staged for the cross-row combine
     const int C = P.C, c4n = C >> 2;                        // channel quads
@@ -89,20 +110,18 @@ __global__ __launch_bounds__(kT) void bn_reduce_kernel(const BnParams P) {
                     b[0] += (double)g0 * xh0; b[1] += (double)g1 * xh1; b[2] += (double)g2 * xh2; b[3] += (double)g3 * xh3;
                 }
             };
-            const float4* x4 = reinterpret_cast<const float4*>(P.x);
-            const float4* g4 = reinterpret_cast<const float4*>(P.gy);
             long long r = r0 + tr;
             for (; r + 3LL * rows_par < r1; r += 4LL * rows_par) {
                 float4 v[4], g[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { v[u] = x4[(r + (long long)u * rows_par) * c4n + q]; if (BWD) g[u] = g4[(r + (long long)u * rows_par) * P.gy_rs4 + q]; }
+                for (int u = 0; u < 4; ++u) { v[u] = ld_quad<BF>(P.x, (r + (long long)u * rows_par) * c4n + q); if (BWD) g[u] = ld_quad<BF>(P.gy, (r + (long long)u * rows_par) * P.gy_rs4 + q); }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) body(v[u], g[u]);
             }
             for (; r < r1; r += rows_par) {
-                const float4 v = x4[r * c4n + q];
+                const float4 v = ld_quad<BF>(P.x, r * c4n + q);
                 float4 g = v;
-                if (BWD) g = g4[r * P.gy_rs4 + q];
+                if (BWD) g = ld_quad<BF>(P.gy, r * P.gy_rs4 + q);
                 body(v, g);
             }
         }
@@ -163,6 +182,7 @@ __global__ __launch_bounds__(kT) void bn_bwd_finalize_kernel(const BnParams P) {
     P.dgamma[c] = (float)ss;
 }
 
+template <bool BF>
 __global__ __launch_bounds__(kT) void bn_apply_kernel(const BnParams P) {
     const int c4n = P.C >> 2;
     const long long n4 = P.R * c4n, stride = (long long)gridDim.x * kT;
@@ -172,7 +192,7 @@ __global__ __launch_bounds__(kT) void bn_apply_kernel(const BnParams P) {
     unsigned q = (unsigned)(i % c4n);
     long long r = i / c4n;
     for (; i < n4; i += stride) {
-        const float4 v = reinterpret_cast<const float4*>(P.x)[i];
+        const float4 v = ld_quad<BF>(P.x, i);
         float4 mu, is;
         if (P.mean) { mu = reinterpret_cast<const float4*>(P.mean)[q]; is = reinterpret_cast<const float4*>(P.invstd)[q]; }
         else {                                               // inference: statistics straight from the running buffers
@@ -184,13 +204,14 @@ __global__ __launch_bounds__(kT) void bn_apply_kernel(const BnParams P) {
         float4 o;
         o.x = act_fwd(ga.x * ((v.x - mu.x) * is.x) + be.x, P.act); o.y = act_fwd(ga.y * ((v.y - mu.y) * is.y) + be.y, P.act);
         o.z = act_fwd(ga.z * ((v.z - mu.z) * is.z) + be.z, P.act); o.w = act_fwd(ga.w * ((v.w - mu.w) * is.w) + be.w, P.act);
-        if (P.res) { const float4 r = reinterpret_cast<const float4*>(P.res)[i]; o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
-        reinterpret_cast<float4*>(P.y)[r * P.y_rs4 + q] = o;
+        if (P.res) { const float4 t = ld_quad<BF>(P.res, i); o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
+        st_quad<BF>(P.y, r * P.y_rs4 + q, o);
         q += sq; r += sr;
         if (q >= (unsigned)c4n) { q -= c4n; ++r; }
     }
 }
 
+template <bool BF>
 __global__ __launch_bounds__(kT) void bn_bwd_dx_kernel(const BnParams P) {
     const int c4n = P.C >> 2;
     const long long n4 = P.R * c4n, stride = (long long)gridDim.x * kT;
@@ -201,7 +222,7 @@ __global__ __launch_bounds__(kT) void bn_bwd_dx_kernel(const BnParams P) {
     unsigned q = (unsigned)(i % c4n);
     long long r = i / c4n;
     for (; i < n4; i += stride) {
-        const float4 v = reinterpret_cast<const float4*>(P.x)[i], g = reinterpret_cast<const float4*>(P.gy)[r * P.gy_rs4 + q];
+        const float4 v = ld_quad<BF>(P.x, i), g = ld_quad<BF>(P.gy, r * P.gy_rs4 + q);
         const float4 mu = reinterpret_cast<const float4*>(P.mean)[q], is = reinterpret_cast<const float4*>(P.invstd)[q];
         const float4 ga = reinterpret_cast<const float4*>(P.gamma)[q], be = reinterpret_cast<const float4*>(P.beta)[q];
         const float4 db = reinterpret_cast<const float4*>(P.dbeta)[q], dg = reinterpret_cast<const float4*>(P.dgamma)[q];
@@ -210,7 +231,7 @@ __global__ __launch_bounds__(kT) void bn_bwd_dx_kernel(const BnParams P) {
                      o.f = ga.f * is.f * (gz - db.f * invR - xh * dg.f * invR); }
         ODPL_DX(x) ODPL_DX(y) ODPL_DX(z) ODPL_DX(w)
 #undef ODPL_DX
-        reinterpret_cast<float4*>(P.gx)[i] = o;
+        st_quad<BF>(P.gx, i, o);
         q += sq; r += sr;
         if (q >= (unsigned)c4n) { q -= c4n; ++r; }
     }
@@ -273,13 +294,13 @@ extern "C" int odpl_bn_act_forward_residual(const float* x, const float* residua
                                             float* running_mean, float* running_var, int32_t training, float momentum, float eps,
                                             int32_t act, float* save_mean, float* save_invstd, float* y, void* workspace,
                                             size_t workspace_bytes, int64_t* num_batches_tracked, void* stream_) {
-    return odpl_bn_act_forward_strided(x, residual, R, C, gamma, beta, running_mean, running_var, training, momentum, eps, act,
+    return odpl_bn_act_forward_strided(x, residual, 0, R, C, gamma, beta, running_mean, running_var, training, momentum, eps, act,
                                        save_mean, save_invstd, y, C, workspace, workspace_bytes, num_batches_tracked, stream_);
 }
 
-extern "C" int odpl_bn_act_forward_strided(const float* x, const float* residual, int64_t R, int32_t C, const float* gamma, const float* beta,
+extern "C" int odpl_bn_act_forward_strided(const void* x, const void* residual, int32_t bf16, int64_t R, int32_t C, const float* gamma, const float* beta,
                                            float* running_mean, float* running_var, int32_t training, float momentum, float eps,
-                                           int32_t act, float* save_mean, float* save_invstd, float* y, int64_t y_row_stride,
+                                           int32_t act, float* save_mean, float* save_invstd, void* y, int64_t y_row_stride,
                                            void* workspace, size_t workspace_bytes, int64_t* num_batches_tracked, void* stream_) {
     if (y_row_stride < C || (y_row_stride & 3)) return ODPL_EINVAL;
     if (residual && y_row_stride != C) return ODPL_EINVAL;
@@ -288,7 +309,9 @@ extern "C" int odpl_bn_act_forward_strided(const float* x, const float* residual
     // save_mean / save_invstd may both be NULL in inference (training == 0): the apply pass then reads running_mean / running_var
     if ((!save_mean || !save_invstd) && (training || save_mean || save_invstd || !running_mean || !running_var)) return ODPL_EINVAL;
     if (((uintptr_t)running_mean | (uintptr_t)running_var) & 15) return ODPL_EINVAL;
-    if (act < 0 || act > 3 || (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)save_mean | (uintptr_t)save_invstd | (uintptr_t)residual) & 15)) return ODPL_EINVAL;
+    const uintptr_t amask = bf16 ? 7 : 15;                  // a channel quad is 8 B in bf16, 16 B in fp32
+    if (act < 0 || act > 3 || (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & amask)) return ODPL_EINVAL;
+    if (((uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)save_mean | (uintptr_t)save_invstd) & 15) return ODPL_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
     BnParams P = {};
     P.x = x; P.y = y; P.res = residual; P.gamma = gamma; P.beta = beta; P.mean = save_mean; P.invstd = save_invstd;
@@ -298,14 +321,16 @@ extern "C" int odpl_bn_act_forward_strided(const float* x, const float* residual
     P.num_batches_tracked = (long long*)num_batches_tracked;
     if (training) {
         if (!workspace || workspace_bytes < odpl_bn_act_workspace_bytes(R, C) || ((uintptr_t)workspace & 15)) return ODPL_EINVAL;
-        hipLaunchKernelGGL(bn_reduce_kernel<false>, dim3(nblk), dim3(kT), lds, stream, P);
+        if (bf16) hipLaunchKernelGGL((bn_reduce_kernel<false, true>), dim3(nblk), dim3(kT), lds, stream, P);
+        else hipLaunchKernelGGL((bn_reduce_kernel<false, false>), dim3(nblk), dim3(kT), lds, stream, P);
         ODPL_HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), dim3(kT), 0, stream, P);
         ODPL_HIP_TRY(hipGetLastError());
     }   // eval: the caller filled save_mean / save_invstd from the running statistics
     const long long n4 = R * (C >> 2);
     long long blocks = (n4 + kT - 1) / kT; if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)blocks), dim3(kT), 0, stream, P);
+    if (bf16) hipLaunchKernelGGL(bn_apply_kernel<true>, dim3((unsigned)blocks), dim3(kT), 0, stream, P);
+    else hipLaunchKernelGGL(bn_apply_kernel<false>, dim3((unsigned)blocks), dim3(kT), 0, stream, P);
     ODPL_HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -314,33 +339,36 @@ extern "C" int odpl_bn_act_backward(const float* x, const float* grad_y, int64_t
                                     const float* save_mean, const float* save_invstd, int32_t training, int32_t act,
                                     float* grad_x, float* grad_gamma, float* grad_beta, void* workspace, size_t workspace_bytes,
                                     void* stream_) {
-    return odpl_bn_act_backward_strided(x, grad_y, C, R, C, gamma, beta, save_mean, save_invstd, training, act, grad_x, grad_gamma, grad_beta,
+    return odpl_bn_act_backward_strided(x, grad_y, C, 0, R, C, gamma, beta, save_mean, save_invstd, training, act, grad_x, grad_gamma, grad_beta,
                                         workspace, workspace_bytes, stream_);
 }
 
-extern "C" int odpl_bn_act_backward_strided(const float* x, const float* grad_y, int64_t gy_row_stride, int64_t R, int32_t C,
+extern "C" int odpl_bn_act_backward_strided(const void* x, const void* grad_y, int64_t gy_row_stride, int32_t bf16, int64_t R, int32_t C,
                                             const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
-                                            int32_t training, int32_t act, float* grad_x, float* grad_gamma, float* grad_beta,
+                                            int32_t training, int32_t act, void* grad_x, float* grad_gamma, float* grad_beta,
                                             void* workspace, size_t workspace_bytes, void* stream_) {
     if (gy_row_stride < C || (gy_row_stride & 3)) return ODPL_EINVAL;
     int rpb, nblk; size_t lds;
     if (!x || !grad_y || !grad_x || !gamma || !beta || !save_mean || !save_invstd || !grad_gamma || !grad_beta || !plan(R, C, &rpb, &nblk, &lds))
         return ODPL_EINVAL;
     if (!workspace || workspace_bytes < odpl_bn_act_workspace_bytes(R, C) || act < 0 || act > 3) return ODPL_EINVAL;
-    if (((uintptr_t)x | (uintptr_t)grad_y | (uintptr_t)grad_x | (uintptr_t)grad_gamma | (uintptr_t)grad_beta | (uintptr_t)workspace) & 15) return ODPL_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)grad_y | (uintptr_t)grad_x) & (bf16 ? 7 : 15)) return ODPL_EINVAL;
+    if (((uintptr_t)grad_gamma | (uintptr_t)grad_beta | (uintptr_t)workspace) & 15) return ODPL_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
     BnParams P = {};
     P.x = x; P.gy = grad_y; P.gx = grad_x; P.gamma = gamma; P.beta = beta; P.mean = (float*)save_mean; P.invstd = (float*)save_invstd;
     P.R = R; P.C = C; P.act = act; P.nblk = nblk; P.rows_per_blk = rpb; P.training = training; P.part = (double*)workspace;
     P.y_rs4 = C >> 2; P.gy_rs4 = gy_row_stride >> 2;
     P.dgamma = grad_gamma; P.dbeta = grad_beta;
-    hipLaunchKernelGGL(bn_reduce_kernel<true>, dim3(nblk), dim3(kT), lds, stream, P);
+    if (bf16) hipLaunchKernelGGL((bn_reduce_kernel<true, true>), dim3(nblk), dim3(kT), lds, stream, P);
+    else hipLaunchKernelGGL((bn_reduce_kernel<true, false>), dim3(nblk), dim3(kT), lds, stream, P);
     ODPL_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(kT), 0, stream, P);
     ODPL_HIP_TRY(hipGetLastError());
     const long long n4 = R * (C >> 2);
     long long blocks = (n4 + kT - 1) / kT; if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(bn_bwd_dx_kernel, dim3((unsigned)blocks), dim3(kT), 0, stream, P);
+    if (bf16) hipLaunchKernelGGL(bn_bwd_dx_kernel<true>, dim3((unsigned)blocks), dim3(kT), 0, stream, P);
+    else hipLaunchKernelGGL(bn_bwd_dx_kernel<false>, dim3((unsigned)blocks), dim3(kT), 0, stream, P);
     ODPL_HIP_TRY(hipGetLastError());
     return 0;
 }

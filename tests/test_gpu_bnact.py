@@ -155,3 +155,57 @@ def test_bn_act_inference_path(act):
     xr = x.clone().requires_grad_()
     f(bn(xr)).sum().backward()
     assert torch.allclose(xg.grad, xr.grad, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("act", ["mish", "leaky", "linear"])
+@pytest.mark.parametrize("training", [True, False])
+def test_bn_act_bf16_activations(act, training):
+    """bf16 activations (bf16-autocast network, BASELINE config 5), fp32 parameters and statistics: against the fp32 torch
+    composition evaluated on the same (bf16-valued) inputs.  Outputs / input gradients are rounded to bf16 once: 2^-8 relative."""
+    from objectdetectionpl_amd.LightningFunc.utils.bnact import bn_act, fusable
+    torch.manual_seed(31)
+    N, C, H, W = 4, 64, 20, 20
+    def mk():
+        bn = nn.BatchNorm2d(C).cuda()
+        with torch.no_grad():
+            bn.weight.copy_(torch.rand(C, generator=torch.Generator().manual_seed(1)) + 0.5)
+            bn.bias.copy_(torch.randn(C, generator=torch.Generator().manual_seed(2)) * 0.2)
+            bn.running_mean.copy_(torch.randn(C, generator=torch.Generator().manual_seed(3)) * 0.1)
+            bn.running_var.copy_(torch.rand(C, generator=torch.Generator().manual_seed(4)) + 0.5)
+        return bn.train(training)
+    b1, b2 = mk(), mk()
+    cl = dict(memory_format=torch.channels_last)
+    xb = (torch.randn(N, C, H, W, device="cuda") * 1.5 + 0.2).bfloat16().contiguous(**cl)
+    rb = torch.randn(N, C, H, W, device="cuda").bfloat16().contiguous(**cl)
+    wb = torch.randn(N, C, H, W, device="cuda").bfloat16().contiguous(**cl)
+    x1, r1 = xb.clone().requires_grad_(), rb.clone().requires_grad_()
+    assert fusable(x1, b1)
+    y1 = bn_act(x1, b1, act, r1)
+    assert y1.dtype == torch.bfloat16 and y1.is_contiguous(**cl)
+    x2, r2 = xb.float().requires_grad_(), rb.float().requires_grad_()
+    z = b2(x2)
+    y2 = (F.mish(z) if act == "mish" else (F.leaky_relu(z, 0.1) if act == "leaky" else z)) + r2
+    assert torch.allclose(y1.float(), y2, rtol=1e-2, atol=1e-2)
+    (y1.float() * wb.float()).sum().backward(); (y2 * wb.float()).sum().backward()
+    sc = float(x2.grad.abs().max())
+    assert x1.grad.dtype == torch.bfloat16
+    assert torch.allclose(x1.grad.float(), x2.grad, rtol=2e-2, atol=1e-2 * sc)
+    assert torch.allclose(r1.grad.float(), r2.grad, rtol=1e-2, atol=1e-3)
+    assert b1.weight.grad.dtype == torch.float32
+    assert torch.allclose(b1.weight.grad, b2.weight.grad, rtol=2e-2, atol=2e-2 * float(b2.weight.grad.abs().max()))
+    assert torch.allclose(b1.bias.grad, b2.bias.grad, rtol=2e-2, atol=2e-2 * float(b2.bias.grad.abs().max()))
+    assert torch.allclose(b1.running_mean, b2.running_mean, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(b1.running_var, b2.running_var, rtol=1e-4, atol=1e-5)
+
+
+def test_bn_act_cat_bf16():
+    from objectdetectionpl_amd.LightningFunc.utils.bnact import bn_act_cat
+    torch.manual_seed(33)
+    cl = dict(memory_format=torch.channels_last)
+    bns = [nn.BatchNorm2d(c).cuda().train() for c in (32, 64, 32, 64)]
+    bns[2].load_state_dict(bns[0].state_dict()); bns[3].load_state_dict(bns[1].state_dict())
+    x1 = torch.randn(2, 32, 13, 13, device="cuda").bfloat16().contiguous(**cl)
+    x2 = torch.randn(2, 64, 13, 13, device="cuda").bfloat16().contiguous(**cl)
+    y = bn_act_cat(x1, bns[0], "leaky", x2, bns[1], "leaky")
+    ref = torch.cat((F.leaky_relu(bns[2](x1.float()), 0.1), F.leaky_relu(bns[3](x2.float()), 0.1)), 1)
+    assert y is not None and y.dtype == torch.bfloat16 and torch.allclose(y.float(), ref, rtol=1e-2, atol=1e-2)
