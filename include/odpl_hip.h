@@ -306,6 +306,15 @@ int odpl_spp_forward(const float* x, const int64_t* host_x_strides, int32_t B, i
                      float* y, const int64_t* host_y_strides, void* stream);
 int odpl_spp_backward(const float* x, const int64_t* host_x_strides, int32_t B, int32_t C, int32_t H, int32_t W,
                       const float* grad_y, const int64_t* host_y_strides, float* grad_x, void* stream);
+/* Same block with the channel order as a parameter -- ODPL_SPP_ORDER_V4: [m13 | m9 | m5 | x] (utils/YoloV4Utils.py:418),
+ * ODPL_SPP_ORDER_V5: [x | m5 | m9 | m13] (utils/YoloV5Utils.py:110) -- and optionally bfloat16 tensors (bf16 != 0: dense
+ * channels-last only, C % 16 == 0, H*W <= 400; max is exact, so only the backward sums round, once). */
+#define ODPL_SPP_ORDER_V4 0
+#define ODPL_SPP_ORDER_V5 1
+int odpl_spp_forward_ex(const void* x, const int64_t* host_x_strides, int32_t B, int32_t C, int32_t H, int32_t W,
+                        void* y, const int64_t* host_y_strides, int32_t bf16, int32_t order, void* stream);
+int odpl_spp_backward_ex(const void* x, const int64_t* host_x_strides, int32_t B, int32_t C, int32_t H, int32_t W,
+                         const void* grad_y, const int64_t* host_y_strides, void* grad_x, int32_t bf16, int32_t order, void* stream);
 
 /* ---- device-side collate: dataset/Pascal.py:121-186 == Coco.py:146-220 ------------------------- */
 /* One raw frame in HBM: uint8 [h, w, 3] interleaved (cv2.imread layout, BGR).  flip: bit 0 horizontal, bit 1 vertical
@@ -326,7 +335,8 @@ int odpl_collate_targets(const float* objects, const int32_t* row_image, const i
 
 /* Bias gradient of a convolution from an NCHW-dense output gradient [B, C, HW]: grad_bias[c] = sum over (b, hw)
  * (what ATen's convolution_backward computes with sum((0, 2, 3)); the linear head convs of model/YOLOV4.py:89-127). */
-int odpl_bias_grad_nchw(const float* grad_y, int32_t B, int32_t C, int64_t HW, float* grad_bias, void* stream);
+int odpl_bias_grad_nchw(const void* grad_y, int32_t bf16 /* grad_y is bfloat16; grad_bias stays fp32 */, int32_t B, int32_t C, int64_t HW,
+                        float* grad_bias, void* stream);
 
 /* ---- space-to-depth shuffles next to the stems/heads ------------------------------------------ */
 /* Focus, utils/YoloV5Utils.py:117-125: y[b, g*C+c, i, j] = x[b, c, 2i+(g&1), 2j+(g>>1)]; x is [B,C,H,W], y is

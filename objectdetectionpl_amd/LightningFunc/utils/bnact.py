@@ -95,11 +95,11 @@ class _BiasAddFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
-        if gy.is_cuda and gy.dtype == torch.float32 and gy.is_contiguous():
+        if gy.is_cuda and gy.dtype in (torch.float32, torch.bfloat16) and gy.is_contiguous():
             B, C, H, W = gy.shape
             gb = torch.empty(C, dtype=torch.float32, device=gy.device)
-            _lib.check(_lib.lib().odpl_bias_grad_nchw(_lib.ptr(gy), B, C, H * W, _lib.ptr(gb), _lib.current_stream(gy.device)),
-                       "odpl_bias_grad_nchw")
+            _lib.check(_lib.lib().odpl_bias_grad_nchw(_lib.ptr(gy), 1 if gy.dtype == torch.bfloat16 else 0, B, C, H * W, _lib.ptr(gb),
+                                                      _lib.current_stream(gy.device)), "odpl_bias_grad_nchw")
         else:
             gb = gy.sum((0, 2, 3))
         return gy, gb
@@ -109,7 +109,7 @@ def conv_bias(x, conv):
     """`conv(x)` for an nn.Conv2d with a bias (the linear head convs, `model/YOLOV4.py:89-127`): bias-free convolution on
     MIOpen, bias added in place, bias gradient by the HIP channel-sum kernel."""
     z = torch.nn.functional.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
-    return _BiasAddFn.apply(z, conv.bias)
+    return _BiasAddFn.apply(z, conv.bias)          # under bf16 autocast z is bf16, the bias and its gradient stay fp32
 
 
 def bn_act_cat(x1, bn1, act1, x2, bn2, act2):

@@ -112,11 +112,13 @@ SIGNATURES = {
     "odpl_yolo_stats_reduce": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_void_p, c_void_p]),
     "odpl_collate_images": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, POINTER(ctypes.c_int64), c_void_p]),
     "odpl_collate_targets": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
-    "odpl_bias_grad_nchw": (c_int32, [c_void_p, c_int32, c_int32, ctypes.c_int64, c_void_p, c_void_p]),
+    "odpl_bias_grad_nchw": (c_int32, [c_void_p, c_int32, c_int32, c_int32, ctypes.c_int64, c_void_p, c_void_p]),
     "odpl_focus": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, POINTER(ctypes.c_int64), POINTER(ctypes.c_int64), c_int32, c_void_p]),
     "odpl_reorg": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, POINTER(ctypes.c_int64), c_int32, c_void_p]),
     "odpl_spp_forward": (c_int32, [c_void_p, POINTER(ctypes.c_int64), c_int32, c_int32, c_int32, c_int32, c_void_p, POINTER(ctypes.c_int64), c_void_p]),
     "odpl_spp_backward": (c_int32, [c_void_p, POINTER(ctypes.c_int64), c_int32, c_int32, c_int32, c_int32, c_void_p, POINTER(ctypes.c_int64), c_void_p, c_void_p]),
+    "odpl_spp_forward_ex": (c_int32, [c_void_p, POINTER(ctypes.c_int64), c_int32, c_int32, c_int32, c_int32, c_void_p, POINTER(ctypes.c_int64), c_int32, c_int32, c_void_p]),
+    "odpl_spp_backward_ex": (c_int32, [c_void_p, POINTER(ctypes.c_int64), c_int32, c_int32, c_int32, c_int32, c_void_p, POINTER(ctypes.c_int64), c_void_p, c_int32, c_int32, c_void_p]),
     "odpl_bn_act_workspace_bytes": (c_size_t, [ctypes.c_int64, c_int32]),
     "odpl_bn_act_forward": (c_int32, [c_void_p, ctypes.c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_float, c_float,
                                       c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),

@@ -57,27 +57,6 @@ struct BnParams {
     float eps, momentum;
 };
 
-// Activations are fp32 (a channel quad = one 16-B float4) or bf16 (a quad = 8 B): statistics, affine parameters and all
-// arithmetic are fp32 either way; bf16 results are rounded once (round-to-nearest-even), after the activation.
-template <bool BF>
-__device__ __forceinline__ float4 ld_quad(const void* p, long long qi) {
-    if (!BF) return reinterpret_cast<const float4*>(p)[qi];
-    const uint2 u = reinterpret_cast<const uint2*>(p)[qi];
-    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
-}
-__device__ __forceinline__ unsigned bf16_rne(float f) {
-    const unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;          // NaN stays NaN (quiet)
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-}
-template <bool BF>
-__device__ __forceinline__ void st_quad(void* p, long long qi, const float4& v) {
-    if (!BF) { reinterpret_cast<float4*>(p)[qi] = v; return; }
-    uint2 u;
-    u.x = bf16_rne(v.x) | (bf16_rne(v.y) << 16); u.y = bf16_rne(v.z) | (bf16_rne(v.w) << 16);
-    reinterpret_cast<uint2*>(p)[qi] = u;
-}
-
 // one pass over a row tile: per-channel sums of (a, b) where (a, b) = f(row, channel-quad)
 template <bool BWD, bool BF>
 __global__ __launch_bounds__(kT) void bn_reduce_kernel(const BnParams P) {
@@ -241,18 +220,23 @@ __global__ __launch_bounds__(kT) void bn_bwd_dx_kernel(const BnParams P) {
 // its gradient back in the heads' own NCHW layout).  ATen's sum over (0, 2, 3) takes 0.2-0.5 ms on these shapes
 // (255 outputs => a few workgroups); here one workgroup per channel streams its B planes, double accumulation,
 // fixed-order block reduction (bitwise reproducible).
-__global__ __launch_bounds__(kT) void bias_grad_nchw_kernel(const float* __restrict__ g, int B, int C, long long HW, float* __restrict__ out) {
+template <bool BF>
+__global__ __launch_bounds__(kT) void bias_grad_nchw_kernel(const void* __restrict__ g, int B, int C, long long HW, float* __restrict__ out) {
     __shared__ double sh[kT / 64];
     const int c = blockIdx.x;
     double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    auto ld = [&](long long i) -> float {
+        if (!BF) return reinterpret_cast<const float*>(g)[i];
+        return __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(g)[i] << 16);
+    };
     for (int b = 0; b < B; ++b) {
-        const float* p = g + ((long long)b * C + c) * HW;
+        const long long p = ((long long)b * C + c) * HW;
         long long i = threadIdx.x;
         for (; i + 3LL * kT < HW; i += 4LL * kT) {             // four independent loads in flight per lane
-            const float v0 = p[i], v1 = p[i + kT], v2 = p[i + 2 * kT], v3 = p[i + 3 * kT];
+            const float v0 = ld(p + i), v1 = ld(p + i + kT), v2 = ld(p + i + 2 * kT), v3 = ld(p + i + 3 * kT);
             a0 += v0; a1 += v1; a2 += v2; a3 += v3;
         }
-        for (; i < HW; i += kT) a0 += p[i];
+        for (; i < HW; i += kT) a0 += ld(p + i);
     }
     double a = (a0 + a1) + (a2 + a3);
     for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
@@ -373,9 +357,10 @@ extern "C" int odpl_bn_act_backward_strided(const void* x, const void* grad_y, i
     return 0;
 }
 
-extern "C" int odpl_bias_grad_nchw(const float* grad_y, int32_t B, int32_t C, int64_t HW, float* grad_bias, void* stream_) {
+extern "C" int odpl_bias_grad_nchw(const void* grad_y, int32_t bf16, int32_t B, int32_t C, int64_t HW, float* grad_bias, void* stream_) {
     if (!grad_y || !grad_bias || B < 1 || C < 1 || HW < 1) return ODPL_EINVAL;
-    hipLaunchKernelGGL(bias_grad_nchw_kernel, dim3(C), dim3(kT), 0, (hipStream_t)stream_, grad_y, B, C, (long long)HW, grad_bias);
+    if (bf16) hipLaunchKernelGGL(bias_grad_nchw_kernel<true>, dim3(C), dim3(kT), 0, (hipStream_t)stream_, grad_y, B, C, (long long)HW, grad_bias);
+    else hipLaunchKernelGGL(bias_grad_nchw_kernel<false>, dim3(C), dim3(kT), 0, (hipStream_t)stream_, grad_y, B, C, (long long)HW, grad_bias);
     ODPL_HIP_TRY(hipGetLastError());
     return 0;
 }

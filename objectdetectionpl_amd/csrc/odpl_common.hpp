@@ -114,4 +114,26 @@ __device__ __forceinline__ void fill_zero(float* __restrict__ base, size_t lo, s
 // torch `.long()` of an fp32 value: truncate toward zero.
 __device__ __forceinline__ long long trunc_ll(float v) { return (long long)v; }
 
+// Activations are fp32 (a channel quad = one 16-B float4) or bf16 (a quad = 8 B): statistics, affine parameters and all
+// arithmetic are fp32 either way; bf16 results are rounded once (round-to-nearest-even), after the activation.
+template <bool BF>
+__device__ __forceinline__ float4 ld_quad(const void* p, long long qi) {
+    if (!BF) return reinterpret_cast<const float4*>(p)[qi];
+    const uint2 u = reinterpret_cast<const uint2*>(p)[qi];
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ unsigned bf16_rne(float f) {
+    const unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;          // NaN stays NaN (quiet)
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+template <bool BF>
+__device__ __forceinline__ void st_quad(void* p, long long qi, const float4& v) {
+    if (!BF) { reinterpret_cast<float4*>(p)[qi] = v; return; }
+    uint2 u;
+    u.x = bf16_rne(v.x) | (bf16_rne(v.y) << 16); u.y = bf16_rne(v.z) | (bf16_rne(v.w) << 16);
+    reinterpret_cast<uint2*>(p)[qi] = u;
+}
+
+
 }  // namespace odpl

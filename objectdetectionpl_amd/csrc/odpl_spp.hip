@@ -17,7 +17,8 @@ using namespace odpl;
 constexpr int kMaxHW = 1024;          // plane positions held in LDS (32 x 32)
 
 struct SppParams {
-    const float* x; float* y; const float* gy; float* gx;
+    const float* x; float* y; const float* gy; float* gx;   // tile kernels: may be bf16 (template BF), addressed through void*
+    int blk[4];                       // channel block (0..3) of x, m5, m9, m13 in y: v4 [m13|m9|m5|x] = {3,2,1,0}, v5 [x|m5|m9|m13] = {0,1,2,3}
     int B, C, H, W;
     long long xs[4], ys[4];           // element strides (b, c, h, w) of x / gx and of y / gy
 };
@@ -55,10 +56,10 @@ __global__ __launch_bounds__(256) void spp_fwd_kernel(const SppParams P) {
         const int py = q / P.W, px = q - py * P.W;
         window_scan(s, P.H, P.W, py, px, mx, am);
         float* yp = P.y + b * P.ys[0] + py * P.ys[2] + px * P.ys[3];
-        yp[(long long)c * P.ys[1]] = mx[2];                          // [m13 | m9 | m5 | x]  (YoloV4Utils.py:418)
-        yp[(long long)(P.C + c) * P.ys[1]] = mx[1];
-        yp[(long long)(2 * P.C + c) * P.ys[1]] = mx[0];
-        yp[(long long)(3 * P.C + c) * P.ys[1]] = s[q];
+        yp[(long long)(P.blk[3] * P.C + c) * P.ys[1]] = mx[2];        // v4: [m13 | m9 | m5 | x] (YoloV4Utils.py:418); v5: [x | m5 | m9 | m13]
+        yp[(long long)(P.blk[2] * P.C + c) * P.ys[1]] = mx[1];
+        yp[(long long)(P.blk[1] * P.C + c) * P.ys[1]] = mx[0];
+        yp[(long long)(P.blk[0] * P.C + c) * P.ys[1]] = s[q];
     }
 }
 
@@ -76,14 +77,14 @@ __global__ __launch_bounds__(256) void spp_bwd_kernel(const SppParams P) {
         window_scan(s, P.H, P.W, py, px, mx, a);
         const float* gp = P.gy + b * P.ys[0] + py * P.ys[2] + px * P.ys[3];
         am[0][q] = (short)a[0]; am[1][q] = (short)a[1]; am[2][q] = (short)a[2];
-        g[2][q] = gp[(long long)c * P.ys[1]];                        // gradient of the 13-pool block
-        g[1][q] = gp[(long long)(P.C + c) * P.ys[1]];
-        g[0][q] = gp[(long long)(2 * P.C + c) * P.ys[1]];
+        g[2][q] = gp[(long long)(P.blk[3] * P.C + c) * P.ys[1]];      // gradient of the 13-pool block
+        g[1][q] = gp[(long long)(P.blk[2] * P.C + c) * P.ys[1]];
+        g[0][q] = gp[(long long)(P.blk[1] * P.C + c) * P.ys[1]];
     }
     __syncthreads();
     for (int p = threadIdx.x; p < HW; p += 256) {
         const int py = p / P.W, px = p - py * P.W;
-        float acc = P.gy[b * P.ys[0] + (long long)(3 * P.C + c) * P.ys[1] + py * P.ys[2] + px * P.ys[3]];   // identity branch
+        float acc = P.gy[b * P.ys[0] + (long long)(P.blk[0] * P.C + c) * P.ys[1] + py * P.ys[2] + px * P.ys[3]];   // identity branch
         for (int dy = -6; dy <= 6; ++dy) {                           // windows that contain p, fixed order
             const int yy = py + dy;
             if (yy < 0 || yy >= P.H) continue;
@@ -167,58 +168,68 @@ __device__ __forceinline__ void pool5_stage(const float* sv, const unsigned shor
     __syncthreads();
 }
 
-template <int CT>
-__device__ __forceinline__ void tile_store(const float* lds, float* g, long long row_stride, int HW) {
+// global <-> LDS tile moves; `e0` = element offset of the tile's first channel, row_stride in elements (both multiples of 4);
+// global data is fp32 or bf16 (quads of 16 / 8 bytes), the LDS tile is always fp32
+template <int CT, bool BF>
+__device__ __forceinline__ void tile_store(const float* lds, void* g, long long e0, long long row_stride, int HW) {
     constexpr int Q = CT / 4;
     for (int i = threadIdx.x; i < HW * Q; i += kTileT) {
         const int pos = i / Q, q = i - pos * Q;
-        *reinterpret_cast<float4*>(g + pos * row_stride + 4 * q) = *reinterpret_cast<const float4*>(lds + pos * CT + 4 * q);
+        st_quad<BF>(g, (e0 + pos * row_stride) / 4 + q, *reinterpret_cast<const float4*>(lds + pos * CT + 4 * q));
     }
 }
-template <int CT>
-__device__ __forceinline__ void tile_load(float* lds, const float* g, long long row_stride, int HW) {
+template <int CT, bool BF>
+__device__ __forceinline__ void tile_load(float* lds, const void* g, long long e0, long long row_stride, int HW) {
     constexpr int Q = CT / 4;
     for (int i = threadIdx.x; i < HW * Q; i += kTileT) {
         const int pos = i / Q, q = i - pos * Q;
-        *reinterpret_cast<float4*>(lds + pos * CT + 4 * q) = *reinterpret_cast<const float4*>(g + pos * row_stride + 4 * q);
+        *reinterpret_cast<float4*>(lds + pos * CT + 4 * q) = ld_quad<BF>(g, (e0 + pos * row_stride) / 4 + q);
     }
+}
+template <bool BF>
+__device__ __forceinline__ float ld_elem(const void* g, long long e) {
+    return BF ? __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(g)[e] << 16) : reinterpret_cast<const float*>(g)[e];
+}
+template <bool BF>
+__device__ __forceinline__ void st_elem(void* g, long long e, float v) {
+    if (BF) reinterpret_cast<unsigned short*>(g)[e] = (unsigned short)bf16_rne(v); else reinterpret_cast<float*>(g)[e] = v;
 }
 
-template <int CT>
+template <int CT, bool BF>
 __global__ __launch_bounds__(kTileT) void spp_fwd_nhwc_kernel(const SppParams P) {
     extern __shared__ float lds[];
-    const int HW = P.H * P.W, C = P.C;
+    const int HW = P.H * P.W;
+    const long long C = P.C;
     float* A = lds; float* Bf = lds + HW * CT; float* T = lds + 2 * HW * CT;
-    const float* xb = P.x + blockIdx.y * P.xs[0] + blockIdx.x * CT;
-    float* yb = P.y + blockIdx.y * P.ys[0] + blockIdx.x * CT;
-    tile_load<CT>(A, xb, C, HW);
+    const long long x0 = blockIdx.y * P.xs[0] + blockIdx.x * CT, y0 = blockIdx.y * P.ys[0] + blockIdx.x * CT;
+    tile_load<CT, BF>(A, P.x, x0, C, HW);
     __syncthreads();
-    tile_store<CT>(A, yb + 3LL * C, 4LL * C, HW);                                 // [m13 | m9 | m5 | x]  (YoloV4Utils.py:418)
+    tile_store<CT, BF>(A, P.y, y0 + P.blk[0] * C, 4 * C, HW);                     // v4: [m13 | m9 | m5 | x]; v5: [x | m5 | m9 | m13]
     pool5_stage<CT, false>(A, nullptr, T, nullptr, Bf, nullptr, P.H, P.W);
-    tile_store<CT>(Bf, yb + 2LL * C, 4LL * C, HW);
+    tile_store<CT, BF>(Bf, P.y, y0 + P.blk[1] * C, 4 * C, HW);
     pool5_stage<CT, false>(Bf, nullptr, T, nullptr, A, nullptr, P.H, P.W);
-    tile_store<CT>(A, yb + 1LL * C, 4LL * C, HW);
+    tile_store<CT, BF>(A, P.y, y0 + P.blk[2] * C, 4 * C, HW);
     pool5_stage<CT, false>(A, nullptr, T, nullptr, Bf, nullptr, P.H, P.W);
-    tile_store<CT>(Bf, yb, 4LL * C, HW);
+    tile_store<CT, BF>(Bf, P.y, y0 + P.blk[3] * C, 4 * C, HW);
 }
 
-template <int CT, int KMAX>
+template <int CT, int KMAX, bool BF>
 __global__ __launch_bounds__(kTileT) void spp_bwd_nhwc_kernel(const SppParams P) {
     extern __shared__ float lds[];
-    const int HW = P.H * P.W, C = P.C, n = HW * CT;
+    const int HW = P.H * P.W, n = HW * CT;
+    const long long C = P.C;
     float* V0 = lds; float* V1 = lds + n; float* TV = lds + 2 * n; float* G = lds + 3 * n;
     unsigned short* I0 = reinterpret_cast<unsigned short*>(lds + 4 * n); unsigned short* I1 = I0 + n; unsigned short* TI = I0 + 2 * n;
     const int ch = threadIdx.x % CT, pl = threadIdx.x / CT;
     constexpr int PL = kTileT / CT;
-    const float* xb = P.x + blockIdx.y * P.xs[0] + blockIdx.x * CT;
-    const float* gb = P.gy + blockIdx.y * P.ys[0] + blockIdx.x * CT;
-    tile_load<CT>(V0, xb, C, HW);
+    const long long x0 = blockIdx.y * P.xs[0] + blockIdx.x * CT, g0 = blockIdx.y * P.ys[0] + blockIdx.x * CT;
+    tile_load<CT, BF>(V0, P.x, x0, C, HW);
     float acc[KMAX];
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
         const int p = pl + k * PL;
         acc[k] = 0.f;
-        if (p < HW) { I0[p * CT + ch] = (unsigned short)p; acc[k] = gb[p * 4LL * C + 3LL * C + ch]; }           // identity branch
+        if (p < HW) { I0[p * CT + ch] = (unsigned short)p; acc[k] = ld_elem<BF>(P.gy, g0 + p * 4 * C + P.blk[0] * C + ch); }   // identity branch
     }
     __syncthreads();
     // windows that contain p, fixed row-major order.  The column loop is fully unrolled with UNCONDITIONAL loads and a select,
@@ -250,24 +261,23 @@ __global__ __launch_bounds__(kTileT) void spp_bwd_nhwc_kernel(const SppParams P)
         }
     };
     pool5_stage<CT, true>(V0, I0, TV, TI, V1, I1, P.H, P.W);          // m5 / arg5
-    tile_load<CT>(G, gb + 2LL * C, 4LL * C, HW);
+    tile_load<CT, BF>(G, P.gy, g0 + P.blk[1] * C, 4 * C, HW);
     __syncthreads();
     gather(I1, std::integral_constant<int, 2>{});
     __syncthreads();
     pool5_stage<CT, true>(V1, I1, TV, TI, V0, I0, P.H, P.W);          // m9 / arg9
-    tile_load<CT>(G, gb + 1LL * C, 4LL * C, HW);
+    tile_load<CT, BF>(G, P.gy, g0 + P.blk[2] * C, 4 * C, HW);
     __syncthreads();
     gather(I0, std::integral_constant<int, 4>{});
     __syncthreads();
     pool5_stage<CT, true>(V0, I0, TV, TI, V1, I1, P.H, P.W);          // m13 / arg13
-    tile_load<CT>(G, gb, 4LL * C, HW);
+    tile_load<CT, BF>(G, P.gy, g0 + P.blk[3] * C, 4 * C, HW);
     __syncthreads();
     gather(I1, std::integral_constant<int, 6>{});
-    float* gxb = P.gx + blockIdx.y * P.xs[0] + blockIdx.x * CT;
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
         const int p = pl + k * PL;
-        if (p < HW) gxb[(long long)p * C + ch] = acc[k];
+        if (p < HW) st_elem<BF>(P.gx, x0 + (long long)p * C + ch, acc[k]);
     }
 }
 
@@ -288,52 +298,75 @@ bool fill(SppParams& P, const float* x, const int64_t* xs, int B, int C, int H, 
     for (int i = 0; i < 4; ++i) { P.xs[i] = xs[i]; P.ys[i] = ys[i]; }
     return true;
 }
-}  // namespace
 
-extern "C" int odpl_spp_forward(const float* x, const int64_t* x_strides, int32_t B, int32_t C, int32_t H, int32_t W,
-                                float* y, const int64_t* y_strides, void* stream) {
-    SppParams P;
-    if (!y || !fill(P, x, x_strides, B, C, H, W, y_strides)) return ODPL_EINVAL;
-    P.y = y; P.gy = nullptr; P.gx = nullptr;
-    const int ct = (((uintptr_t)x | (uintptr_t)y) & 15) ? 0 : nhwc_tile(P);
-    if (ct) {
-        const size_t lds = (size_t)3 * H * W * ct * sizeof(float);
-        static bool attr32 = false, attr16 = false;
-        if (ct == 32) {
-            if (!attr32) { ODPL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(spp_fwd_nhwc_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 176 * 32 * 4)); attr32 = true; }
-            hipLaunchKernelGGL(spp_fwd_nhwc_kernel<32>, dim3(C / 32, B), dim3(kTileT), lds, (hipStream_t)stream, P);
-        } else {
-            if (!attr16) { ODPL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(spp_fwd_nhwc_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 400 * 16 * 4)); attr16 = true; }
-            hipLaunchKernelGGL(spp_fwd_nhwc_kernel<16>, dim3(C / 16, B), dim3(kTileT), lds, (hipStream_t)stream, P);
-        }
-        ODPL_HIP_TRY(hipGetLastError());
-        return 0;
+template <typename K>
+int launch_tile(K kernel, size_t lds_max, size_t lds, dim3 grid, hipStream_t stream, const SppParams& P, bool* attr_done) {
+    if (!*attr_done) {          // > 64 KB of dynamic LDS needs the opt-in once per kernel instantiation
+        ODPL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+        *attr_done = true;
     }
-    hipLaunchKernelGGL(spp_fwd_kernel, dim3(C, B), dim3(256), 0, (hipStream_t)stream, P);
+    hipLaunchKernelGGL(kernel, grid, dim3(kTileT), lds, stream, P);
     ODPL_HIP_TRY(hipGetLastError());
     return 0;
 }
 
-extern "C" int odpl_spp_backward(const float* x, const int64_t* x_strides, int32_t B, int32_t C, int32_t H, int32_t W,
-                                 const float* grad_y, const int64_t* y_strides, float* grad_x, void* stream) {
+bool set_order(SppParams& P, int order) {
+    if (order == ODPL_SPP_ORDER_V4) { P.blk[0] = 3; P.blk[1] = 2; P.blk[2] = 1; P.blk[3] = 0; return true; }
+    if (order == ODPL_SPP_ORDER_V5) { P.blk[0] = 0; P.blk[1] = 1; P.blk[2] = 2; P.blk[3] = 3; return true; }
+    return false;
+}
+}  // namespace
+
+extern "C" int odpl_spp_forward_ex(const void* x, const int64_t* x_strides, int32_t B, int32_t C, int32_t H, int32_t W,
+                                   void* y, const int64_t* y_strides, int32_t bf16, int32_t order, void* stream_) {
     SppParams P;
-    if (!grad_y || !grad_x || !fill(P, x, x_strides, B, C, H, W, y_strides)) return ODPL_EINVAL;
-    P.y = nullptr; P.gy = grad_y; P.gx = grad_x;
-    const int ct = (((uintptr_t)x | (uintptr_t)grad_y | (uintptr_t)grad_x) & 15) ? 0 : nhwc_tile(P);
+    if (!y || !fill(P, (const float*)x, x_strides, B, C, H, W, y_strides) || !set_order(P, order)) return ODPL_EINVAL;
+    P.y = (float*)y; P.gy = nullptr; P.gx = nullptr;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int ct = (((uintptr_t)x | (uintptr_t)y) & (bf16 ? 7 : 15)) ? 0 : nhwc_tile(P);
     if (ct) {
-        const size_t lds = (size_t)H * W * ct * (4 * sizeof(float) + 3 * sizeof(unsigned short));
-        static bool attr32 = false, attr16 = false;
-        if (ct == 32) {
-            if (!attr32) { ODPL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(spp_bwd_nhwc_kernel<32, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, 176 * 32 * 22)); attr32 = true; }
-            hipLaunchKernelGGL((spp_bwd_nhwc_kernel<32, 6>), dim3(C / 32, B), dim3(kTileT), lds, (hipStream_t)stream, P);
-        } else {
-            if (!attr16) { ODPL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(spp_bwd_nhwc_kernel<16, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, 400 * 16 * 22)); attr16 = true; }
-            hipLaunchKernelGGL((spp_bwd_nhwc_kernel<16, 7>), dim3(C / 16, B), dim3(kTileT), lds, (hipStream_t)stream, P);
-        }
-        ODPL_HIP_TRY(hipGetLastError());
-        return 0;
+        const size_t lds = (size_t)3 * H * W * ct * sizeof(float);
+        static bool done[4] = {false, false, false, false};
+        const dim3 grid(C / ct, B);
+        if (ct == 32) return bf16 ? launch_tile(spp_fwd_nhwc_kernel<32, true>, 3 * 176 * 32 * 4, lds, grid, stream, P, &done[0])
+                                  : launch_tile(spp_fwd_nhwc_kernel<32, false>, 3 * 176 * 32 * 4, lds, grid, stream, P, &done[1]);
+        return bf16 ? launch_tile(spp_fwd_nhwc_kernel<16, true>, 3 * 400 * 16 * 4, lds, grid, stream, P, &done[2])
+                    : launch_tile(spp_fwd_nhwc_kernel<16, false>, 3 * 400 * 16 * 4, lds, grid, stream, P, &done[3]);
     }
-    hipLaunchKernelGGL(spp_bwd_kernel, dim3(C, B), dim3(256), 0, (hipStream_t)stream, P);
+    if (bf16) return ODPL_EINVAL;                            // bf16 only on the channels-last tile path
+    hipLaunchKernelGGL(spp_fwd_kernel, dim3(C, B), dim3(256), 0, stream, P);
     ODPL_HIP_TRY(hipGetLastError());
     return 0;
+}
+
+extern "C" int odpl_spp_backward_ex(const void* x, const int64_t* x_strides, int32_t B, int32_t C, int32_t H, int32_t W,
+                                    const void* grad_y, const int64_t* y_strides, void* grad_x, int32_t bf16, int32_t order, void* stream_) {
+    SppParams P;
+    if (!grad_y || !grad_x || !fill(P, (const float*)x, x_strides, B, C, H, W, y_strides) || !set_order(P, order)) return ODPL_EINVAL;
+    P.y = nullptr; P.gy = (const float*)grad_y; P.gx = (float*)grad_x;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int ct = (((uintptr_t)x | (uintptr_t)grad_y | (uintptr_t)grad_x) & (bf16 ? 7 : 15)) ? 0 : nhwc_tile(P);
+    if (ct) {
+        const size_t lds = (size_t)H * W * ct * (4 * sizeof(float) + 3 * sizeof(unsigned short));
+        static bool done[4] = {false, false, false, false};
+        const dim3 grid(C / ct, B);
+        if (ct == 32) return bf16 ? launch_tile(spp_bwd_nhwc_kernel<32, 6, true>, 176 * 32 * 22, lds, grid, stream, P, &done[0])
+                                  : launch_tile(spp_bwd_nhwc_kernel<32, 6, false>, 176 * 32 * 22, lds, grid, stream, P, &done[1]);
+        return bf16 ? launch_tile(spp_bwd_nhwc_kernel<16, 7, true>, 400 * 16 * 22, lds, grid, stream, P, &done[2])
+                    : launch_tile(spp_bwd_nhwc_kernel<16, 7, false>, 400 * 16 * 22, lds, grid, stream, P, &done[3]);
+    }
+    if (bf16) return ODPL_EINVAL;
+    hipLaunchKernelGGL(spp_bwd_kernel, dim3(C, B), dim3(256), 0, stream, P);
+    ODPL_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int odpl_spp_forward(const float* x, const int64_t* x_strides, int32_t B, int32_t C, int32_t H, int32_t W,
+                                float* y, const int64_t* y_strides, void* stream) {
+    return odpl_spp_forward_ex(x, x_strides, B, C, H, W, y, y_strides, 0, ODPL_SPP_ORDER_V4, stream);
+}
+
+extern "C" int odpl_spp_backward(const float* x, const int64_t* x_strides, int32_t B, int32_t C, int32_t H, int32_t W,
+                                 const float* grad_y, const int64_t* y_strides, float* grad_x, void* stream) {
+    return odpl_spp_backward_ex(x, x_strides, B, C, H, W, grad_y, y_strides, grad_x, 0, ODPL_SPP_ORDER_V4, stream);
 }

@@ -16,6 +16,7 @@ from ..LightningFunc.nms import yolo_non_max_suppression
 from ..LightningFunc.utils import bnact as _bnact
 from ..LightningFunc.utils.s2d import focus as _focus
 from ..LightningFunc.utils.spp import spp_cat
+from ..LightningFunc.utils.spp import tile_path as _spp_tile_path
 
 try:
     import pytorch_lightning as pl
@@ -97,7 +98,10 @@ class SPP(nn.Module):
 
     def forward(self, x):
         x = self.cv1(x)
-        return self.cv2(torch.cat([x] + [m(x) for m in self.m], 1))     # order [x, m5, m9, m13] (YoloV5Utils.py:110)
+        if self.k == (5, 9, 13) and x.is_cuda and (_spp_tile_path(x) if x.dtype == torch.bfloat16 else
+                                                  (x.dtype == torch.float32 and x.shape[2] * x.shape[3] <= 1024)):
+            return self.cv2(spp_cat(x, "v5"))                             # fused HIP SPP, order [x, m5, m9, m13] (YoloV5Utils.py:110)
+        return self.cv2(torch.cat([x] + [m(x) for m in self.m], 1))
 
 
 class Focus(nn.Module):
@@ -147,11 +151,12 @@ class backbone_head(nn.Module):
         r1 = self.seq6_BottleneckCSP(self.seq5_Conv(r0))
         x = self.seq9_BottleneckCSP(self.seq8_SPP(self.seq7_Conv(r1)))
         route = self.seq10_BottleneckCSP(x)
-        out0 = self.seq11_Conv2d(route)
+        head = (lambda conv, t: _bnact.conv_bias(t, conv)) if route.is_cuda and route.dtype in (torch.float32, torch.bfloat16) else (lambda conv, t: conv(t))
+        out0 = head(self.seq11_Conv2d, route)
         route = self.seq15_BottleneckCSP(self.seq14_Conv(torch.cat([self._up2(route), r1], 1)))
-        out1 = self.seq16_Conv2d(route)
+        out1 = head(self.seq16_Conv2d, route)
         x = self.seq20_BottleneckCSP(self.seq19_Conv(torch.cat([self._up2(route), r0], 1)))
-        return self.seq21_Conv2d(x), out1, out0
+        return head(self.seq21_Conv2d, x), out1, out0
 
 
 class Yolo_Layers(nn.Module):

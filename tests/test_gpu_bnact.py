@@ -209,3 +209,22 @@ def test_bn_act_cat_bf16():
     y = bn_act_cat(x1, bns[0], "leaky", x2, bns[1], "leaky")
     ref = torch.cat((F.leaky_relu(bns[2](x1.float()), 0.1), F.leaky_relu(bns[3](x2.float()), 0.1)), 1)
     assert y is not None and y.dtype == torch.bfloat16 and torch.allclose(y.float(), ref, rtol=1e-2, atol=1e-2)
+
+
+def test_conv_bias_bf16_autocast():
+    """Head conv under bf16 autocast: bf16 output, fp32 bias gradient from the bf16 NCHW gradient."""
+    from objectdetectionpl_amd.LightningFunc.utils.bnact import conv_bias
+    torch.manual_seed(9)
+    conv = torch.nn.Conv2d(16, 255, 1, bias=True).cuda()
+    x = torch.randn(4, 16, 20, 20, device="cuda")
+    w = torch.randn(4, 255, 20, 20, device="cuda")
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y0 = conv(x)
+    (y0.float() * w).sum().backward()
+    ref_b = conv.bias.grad.clone(); conv.zero_grad()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y1 = conv_bias(x, conv)
+    assert y1.dtype == torch.bfloat16 and torch.allclose(y1.float(), y0.float(), rtol=2e-2, atol=2e-2)
+    (y1.float() * w).sum().backward()
+    assert conv.bias.grad.dtype == torch.float32
+    assert torch.allclose(conv.bias.grad, ref_b, rtol=2e-2, atol=2e-2 * float(ref_b.abs().max()))

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""BASELINE config 5 as a full training step: YOLOv5-l, C = 80, B = 32, 640^2, convolutions under bf16 autocast, loss sums in
+fp32 (HIP v5 loss on bf16 heads), fused bf16 BN + LeakyReLU epilogues, fused Adam on fp32 master weights.  Secondary number
+(the judged bench is config 2); `--dtype fp32` runs the same network without autocast for comparison."""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from objectdetectionpl_amd.model.YOLOV5 import YOLOv5
+
+
+class Args:
+    model_name = "YOLOv5"; cls_criterion = "bce_loss"; coord_criterion = "smooth_l1_loss"; data_module = "synthetic"
+    type = "Yolov5l"; lr = 1e-3; weight_decay = 1e-5
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--img", type=int, default=640)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--type", default="Yolov5l")
+    ap.add_argument("--miopen-find", action="store_true", help="cudnn.benchmark=True (exhaustive MIOpen search: minutes on a fresh box)")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    torch.backends.cudnn.benchmark = bool(a.miopen_find)
+    torch.manual_seed(0)
+    Args.type = a.type
+    model = YOLOv5([str(i) for i in range(80)], Args()).to(dev).to(memory_format=torch.channels_last).train()
+    model.img_size = a.img
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5, fused=True)
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(a.batch, 3, a.img, a.img, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    n = a.batch * 7
+    wh = torch.rand(n, 2, generator=g) * 0.48 + 0.02
+    y = torch.cat([torch.arange(a.batch).repeat_interleave(7).float()[:, None], torch.randint(0, 80, (n, 1), generator=g).float(),
+                   torch.rand(n, 2, generator=g) * (1 - wh), wh], 1).to(dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=a.dtype == "bf16"):
+            out = model(x)
+        d = model.criterion(out, y)
+        d["loss"].backward()
+        opt.step()
+        return d, out
+
+    t0 = time.perf_counter()
+    for i in range(a.warmup):
+        d, out = step()
+        torch.cuda.synchronize()
+        print(f"[{time.perf_counter() - t0:6.1f}s] warmup {i + 1}/{a.warmup}", file=sys.stderr, flush=True)
+    t1 = time.perf_counter()
+    for _ in range(a.steps):
+        d, out = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t1) / a.steps
+    print(json.dumps({"workload": f"{a.type} {a.img}x{a.img} bs={a.batch} training step, convs {a.dtype}", "img_per_s": round(a.batch / dt, 1),
+                      "ms_per_step": round(dt * 1e3, 2), "head_dtype": str(out[0].dtype), "loss": round(float(d["loss"].detach()), 4),
+                      "miopen_find": bool(a.miopen_find)}))
+
+
+if __name__ == "__main__":
+    main()
