@@ -136,4 +136,28 @@ __device__ __forceinline__ void st_quad(void* p, long long qi, const float4& v) 
 }
 
 
+// Byte fill as a KERNEL.  hipMemsetAsync is avoided on purpose: captured into a HIP graph it becomes a memset node that does
+// not replay correctly on this stack (ROCm 7.0: state maps came back dirty on every replay after the first -- found by
+// tests/test_gpu_graph.py); a kernel node replays like any other launch, so every entry point stays graph-capturable.
+static __global__ void fill_bytes_kernel(unsigned char* __restrict__ p, unsigned v32, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t head = ((16 - ((uintptr_t)p & 15)) & 15) < n ? ((16 - ((uintptr_t)p & 15)) & 15) : n;    // bytes up to 16-B alignment
+    const size_t n16 = (n - head) / 16;
+    uint4* q = reinterpret_cast<uint4*>(p + head);
+    const uint4 v = make_uint4(v32, v32, v32, v32);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) q[i] = v;
+    const size_t tail0 = head + n16 * 16;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < head + (n - tail0); i += stride) {
+        const size_t j = i < head ? i : tail0 + (i - head);
+        p[j] = (unsigned char)v32;
+    }
+}
+inline hipError_t fill_bytes(void* p, int byte_value, size_t n, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const unsigned b = (unsigned)byte_value & 0xffu, v32 = b | (b << 8) | (b << 16) | (b << 24);
+    size_t blocks = (n / 16 + 255) / 256; if (blocks < 1) blocks = 1; if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(fill_bytes_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (unsigned char*)p, v32, n);
+    return hipGetLastError();
+}
+
 }  // namespace odpl

@@ -216,7 +216,7 @@ inline int next_pow2(int v) { int p = 2; while (p < v) p <<= 1; return p; }
 extern "C" int odpl_batch_statistics(const float* dets, const int32_t* counts, const float* targets, int32_t B, int32_t Kmax,
                                      int32_t nT, float iou_threshold, float* tp, int32_t* status, void* stream) {
     if (!dets || !counts || !tp || !status || B < 1 || Kmax < 1 || nT < 0 || (nT > 0 && !targets)) return ODPL_EINVAL;
-    ODPL_HIP_TRY(hipMemsetAsync(status, 0, sizeof(int), (hipStream_t)stream));
+    ODPL_HIP_TRY(odpl::fill_bytes(status, 0, sizeof(int), (hipStream_t)stream));
     hipLaunchKernelGGL(batch_stats_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, dets, counts, targets, nT, Kmax, iou_threshold, tp, status);
     ODPL_HIP_TRY(hipGetLastError());
     return 0;

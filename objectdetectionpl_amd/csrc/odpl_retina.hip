@@ -294,7 +294,7 @@ extern "C" int odpl_retina_loss(const odpl_retina_loss_desc_t* d, void* workspac
     P.row_tile = (int*)(ws + pl.row_tile); P.tile_pos = (unsigned char*)(ws + pl.tile_pos);
     P.status = (int*)(ws + pl.status); P.part = (float*)(ws + pl.part);
     P.out3 = out3; P.out_counts = out_counts;
-    if (!(d->flags & ODPL_RETINA_STATE_CLEAN)) ODPL_HIP_TRY(hipMemsetAsync(P.status, 0, 256, stream));
+    if (!(d->flags & ODPL_RETINA_STATE_CLEAN)) ODPL_HIP_TRY(odpl::fill_bytes(P.status, 0, 256, stream));
     const dim3 grid(pl.nblk_x, d->B);
     prof_begin(ODPL_PROF_RETINA_ASSIGN, stream);
     hipLaunchKernelGGL(retina_assign_kernel, grid, dim3(kT), 0, stream, P);

@@ -326,7 +326,7 @@ extern "C" int odpl_ssd_loss(const odpl_ssd_loss_desc_t* d, void* workspace, siz
     P.loss = (float*)(ws + pl.loss); P.ann = (int*)(ws + pl.ann); P.flag = (int*)(ws + pl.flag);
     P.best_prior = (int*)(ws + pl.best); P.part = (float*)(ws + pl.part); P.meta = (int*)(ws + pl.meta);
     P.out3 = out3; P.out_counts = out_counts;
-    ODPL_HIP_TRY(hipMemsetAsync(P.meta, 0, 256, stream));
+    ODPL_HIP_TRY(odpl::fill_bytes(P.meta, 0, 256, stream));
     hipLaunchKernelGGL(ssd_image_kernel, dim3(d->B), dim3(kT), 0, stream, P);
     ODPL_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(ssd_finalize_kernel, dim3(1), dim3(64), 0, stream, P);

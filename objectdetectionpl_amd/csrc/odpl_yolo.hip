@@ -509,7 +509,7 @@ extern "C" int odpl_yolo_region_loss(const odpl_yolo_loss_desc_t* d, void* works
         S.fill_blk0 = nblk; nblk += S.fill_nblk;
     }
     (void)any_grad;
-    if (!(d->flags & ODPL_YOLO_STATE_CLEAN)) ODPL_HIP_TRY(hipMemsetAsync(ws, 0xFF, pl.state_bytes_total, stream));
+    if (!(d->flags & ODPL_YOLO_STATE_CLEAN)) ODPL_HIP_TRY(odpl::fill_bytes(ws, 0xFF, pl.state_bytes_total, stream));
     prof_begin(ODPL_PROF_YOLO_ASSIGN, stream);
     hipLaunchKernelGGL(yolo_assign_kernel, dim3(d->nscales), dim3(kAssignThreads), 0, stream, P);
     prof_end(ODPL_PROF_YOLO_ASSIGN, stream);

@@ -94,12 +94,12 @@ extern "C" int odpl_yolo_build_targets(const float* pred_boxes, const float* pre
     if ((long long)B * A * G * G * C > 0x7fffffffLL) return ODPL_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
     const size_t cells = (size_t)B * A * G * G;
-    ODPL_HIP_TRY(hipMemsetAsync(state, 0xFF, cells * sizeof(int), stream));
-    ODPL_HIP_TRY(hipMemsetAsync(obj_mask, 0, cells, stream));
-    ODPL_HIP_TRY(hipMemsetAsync(noobj_mask, 1, cells, stream));
+    ODPL_HIP_TRY(odpl::fill_bytes(state, 0xFF, cells * sizeof(int), stream));
+    ODPL_HIP_TRY(odpl::fill_bytes(obj_mask, 0, cells, stream));
+    ODPL_HIP_TRY(odpl::fill_bytes(noobj_mask, 1, cells, stream));
     float* zf[] = {iou_scores, class_mask, tx, ty, tw, th, tconf};
-    for (float* p : zf) ODPL_HIP_TRY(hipMemsetAsync(p, 0, cells * sizeof(float), stream));
-    ODPL_HIP_TRY(hipMemsetAsync(tcls, 0, cells * C * sizeof(float), stream));
+    for (float* p : zf) ODPL_HIP_TRY(odpl::fill_bytes(p, 0, cells * sizeof(float), stream));
+    ODPL_HIP_TRY(odpl::fill_bytes(tcls, 0, cells * C * sizeof(float), stream));
     BTParams P;
     P.pred_boxes = pred_boxes; P.pred_cls = pred_cls; P.target = target;
     P.B = B; P.A = A; P.G = G; P.C = C; P.nT = nT; P.thr = ignore_thres; P.state = state;

@@ -463,8 +463,8 @@ extern "C" int odpl_yolov5_loss(const odpl_yolov5_loss_desc_t* d, void* workspac
     P.want_grad = want ? 1 : 0;
 
     if (!(d->flags & ODPL_YOLOV5_STATE_CLEAN)) {
-        ODPL_HIP_TRY(hipMemsetAsync(ws + pl.status, 0, 256, stream));
-        ODPL_HIP_TRY(hipMemsetAsync(ws + 256, 0xFF, pl.owner_bytes_total, stream));
+        ODPL_HIP_TRY(odpl::fill_bytes(ws + pl.status, 0, 256, stream));
+        ODPL_HIP_TRY(odpl::fill_bytes(ws + 256, 0xFF, pl.owner_bytes_total, stream));
     }
     hipLaunchKernelGGL(v5_assign_kernel, dim3(d->nl), dim3(kAT), 0, stream, P);
     ODPL_HIP_TRY(hipGetLastError());
