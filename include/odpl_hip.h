@@ -324,6 +324,8 @@ typedef struct {
     int32_t h, w;
     int32_t flip;
     int32_t reserved;
+    const uint8_t* lut;   /* NULL, or device uint8 [3][256]: per-channel point operation applied to the resized uint8 frame (the
+                           * host composes RandomBrightnessContrast / RGBShift -- LUT operations in albumentations -- into it) */
 } odpl_image_t;
 /* x[b] = CHW( flip( resize_linear_u8(image b -> S x S) ) ) / 255, written with the given element strides (b, c, h, w). */
 int odpl_collate_images(const odpl_image_t* host_images, int32_t B, int32_t S, float* x,

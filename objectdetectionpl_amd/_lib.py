@@ -59,7 +59,7 @@ class YoloDecodeDesc(ctypes.Structure):
 
 
 class Image(ctypes.Structure):
-    _fields_ = [("data", c_void_p), ("h", c_int32), ("w", c_int32), ("flip", c_int32), ("reserved", c_int32)]
+    _fields_ = [("data", c_void_p), ("h", c_int32), ("w", c_int32), ("flip", c_int32), ("reserved", c_int32), ("lut", c_void_p)]
 
 
 class YoloV5Layer(ctypes.Structure):

@@ -2,6 +2,8 @@
 // worker, A.Resize(S, S) [cv2.INTER_LINEAR on uint8 HWC BGR] -> HorizontalFlip -> VerticalFlip -> float -> /255 -> CHW,
 // and rewrites the COCO pixel boxes to normalised (img, cls, x, y, w, h) rows (dataset/Pascal.py:121-186).  Here the raw
 // uint8 frames sit in HBM and one launch writes the whole [B, 3, S, S] fp32 batch (any dense strides), a second one the rows.
+// Photometric augmentations that are per-channel point operations on the uint8 frame (RandomBrightnessContrast, RGBShift: both are
+// cv2.LUT calls in albumentations) ride along as ONE composed 3 x 256-byte table per image, looked up after the resize.
 // 8-bit bilinear = OpenCV's fixed-point algorithm (11-bit coefficients, int32 row pass, the >>4 / >>16 / +2 >> 2 vertical pass),
 // bit-exact to oracle/collate.py; see that file for the pinning status (cv2 is absent: "parity unpinned" against cv2 itself).
 // HBM-bound: reads h*w*3 source bytes (4 taps, L2-resident neighbours), writes S*S*3*4 bytes per image.
@@ -13,7 +15,7 @@ using namespace odpl;
 constexpr int kT = 256;
 constexpr int kMaxImg = 32;             // images per launch (kernel-argument block)
 
-struct Img { const unsigned char* data; int h, w, flip, first; };
+struct Img { const unsigned char* data; const unsigned char* lut; int h, w, flip, first; };
 struct CollateParams {
     Img img[kMaxImg];
     int n, S;
@@ -50,6 +52,7 @@ __global__ __launch_bounds__(kT) void collate_images_kernel(const CollateParams 
             const int h1 = r1[x0 * 3 + c] * ax0 + r1[x1 * 3 + c] * ax1;
             int v = (((ay0 * (h0 >> 4)) >> 16) + ((ay1 * (h1 >> 4)) >> 16) + 2) >> 2;
             v = v < 0 ? 0 : (v > 255 ? 255 : v);
+            if (I.lut) v = I.lut[c * 256 + v];               // photometric point operations, composed into one per-channel table by the host
             P.x[b * P.xs[0] + c * P.xs[1] + oy * P.xs[2] + ox * P.xs[3]] = (float)v / 255.0f;
         }
     }
@@ -90,7 +93,7 @@ extern "C" int odpl_collate_images(const odpl_image_t* host_images, int32_t B, i
         for (int k = 0; k < 4; ++k) P.xs[k] = host_x_strides[k];
         for (int k = 0; k < P.n; ++k) {
             const odpl_image_t& im = host_images[i0 + k];
-            P.img[k].data = im.data; P.img[k].h = im.h; P.img[k].w = im.w; P.img[k].flip = im.flip; P.img[k].first = i0 + k;
+            P.img[k].data = im.data; P.img[k].lut = im.lut; P.img[k].h = im.h; P.img[k].w = im.w; P.img[k].flip = im.flip; P.img[k].first = i0 + k;
         }
         hipLaunchKernelGGL(collate_images_kernel, dim3(gx, P.n), dim3(kT), 0, stream, P);
         ODPL_HIP_TRY(hipGetLastError());

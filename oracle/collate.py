@@ -10,8 +10,9 @@ PARITY UNPINNED: `A.Resize` is `cv2.resize(..., interpolation=cv2.INTER_LINEAR)`
 coefficients `saturate_cast<short>(c * 2048)`, horizontal pass into int32, vertical pass
 `(((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2`, pixel centres `(d + 0.5) * scale - 0.5` evaluated
 in double and rounded to float, `scale = 1 / (dst / src)`); the HIP kernel is held bit-exact to THIS restatement.
-The photometric / affine augmentations of the chain (ShiftScaleRotate, RandomBrightnessContrast, RGBShift,
-p = 0.2 each) are not implemented on the device and not restated.
+RandomBrightnessContrast and RGBShift are per-channel cv2.LUT calls in albumentations: the device takes one composed table per
+image (`dataset/collate.photometric_luts` builds it host-side; unpinned like the resize).  ShiftScaleRotate (an affine warp,
+p = 0.2) is not implemented on the device and not restated.
 """
 import numpy as np
 
@@ -45,13 +46,16 @@ def resize_linear_u8(img, S):
     return np.clip(out, 0, 255).astype(np.uint8)
 
 
-def collate(images, objects, S, flips):
+def collate(images, objects, S, flips, luts=None):
     """images: list of uint8 [h, w, 3]; objects: list of float [n_i, 5] = (x, y, w, h, label) in source pixels (COCO);
-    flips: list of ints, bit 0 horizontal, bit 1 vertical.  -> (x f32 [B, 3, S, S], y f32 [nT, 6])."""
+    flips: list of ints, bit 0 horizontal, bit 1 vertical; luts: None or uint8 [B, 3, 256] per-channel tables applied to the
+    resized frame (cv2.LUT semantics: RandomBrightnessContrast / RGBShift).  -> (x f32 [B, 3, S, S], y f32 [nT, 6])."""
     xs, ys = [], []
     for i, (img, obj, fl) in enumerate(zip(images, objects, flips)):
         h, w, _ = img.shape
         r = resize_linear_u8(img, S)
+        if luts is not None:
+            r = np.stack([np.asarray(luts[i][c])[r[..., c]] for c in range(3)], -1)
         if fl & 1:
             r = r[:, ::-1]
         if fl & 2:
