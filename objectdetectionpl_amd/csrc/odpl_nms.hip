@@ -4,20 +4,22 @@
 //     YOLOV2.py:159-222, and YOLOV5.py:157-218 on its reinterpreted memory).  The reference flattens the
 //     RAW heads (no sigmoid, no grid decode), thresholds conf at -0.0151, sorts by conf*max(cls) and loops
 //     {IoU(+1) > thr & same label -> conf-weighted merge into the pivot, drop}.
-//       prep   (N/256 x B WGs)  reads the NCHW heads once (coalesced along the G*G plane; class max/argmax
-//                               per candidate), writes box/conf/cls_conf/label/score as SoA        [HBM read bound]
-//       image  (1 WG / image)   bitonic sort of (score desc, index asc) pairs, gather into sorted SoA, then
-//                               the sequential pivot loop with a block-parallel sweep and wave reductions
-//                               (weighted sums + next pivot = min alive index) per pivot.
+//       prep   (N/64 x B WGs)   reads the NCHW heads once (coalesced along the G*G plane; each wave issues its whole class
+//                               range before the first compare), class max/argmax per candidate, writes box/conf/cls_conf/
+//                               label/score as SoA                                                     [HBM read bound]
+//       image  (1 WG / image)   counts + compacts the valid candidates into LDS, LDS bitonic sort of (score desc, index asc),
+//                               gather into rank order, class histogram/scan, then ONE WAVE PER CLASS runs that class's pivot
+//                               loop (the same-label condition makes the classes independent) with its list in registers;
+//                               rows land at the pivot's rank and a block scan compacts them in rank order.
 //     The pivot is always retired (the reference never terminates when a box's self-IoU <= thr).
 // (2) RetinaNet / SSD greedy top-k NMS -- model/RetinaNet.py:117-178 == SSD.py:249-310.
-//       prep   (An/256 x B WGs)  class rows staged through LDS (coalesced 16-B loads, padded rows), sigmoid-max
-//                               + first argmax per anchor, pass flag (score > class_thresh)
-//       image  (1 WG / image)   stable compaction of the candidates, k-th largest by bisection on the float
-//                               bits (top-k without sorting the candidates), LDS bitonic sort of the <= topk
-//                               survivors, greedy suppression, the reference's output quirks (keep indexes the
-//                               FILTERED list, boxes/labels come from the UNFILTERED arrays; the last single
-//                               box is dropped).
+//       prep   (An/64 x B WGs)  class rows staged through LDS (coalesced 16-B loads, padded rows), sigmoid-max
+//                               + first argmax per anchor, per-tile count of score > class_thresh
+//       image  (1 WG / image)   block scan of the tile counts, barrier-free stable compaction, k-th largest by bisection on
+//                               the float bits with the keys in registers (top-k without sorting the candidates), LDS
+//                               bitonic sort of the <= topk survivors, greedy suppression by one wave, the reference's output
+//                               quirks (keep indexes the FILTERED list, boxes/labels come from the UNFILTERED arrays; the
+//                               last single box is dropped).
 #include <limits.h>
 #include "odpl_common.hpp"
 #include "odpl_boxes_dev.hpp"
@@ -38,10 +40,9 @@ struct YParams {
     int nscales, B, A, no, N, Npad;
     float conf_thres, nms_thres;
     // per image SoA, unsorted then sorted
-    float4* box; float* conf; float* cconf; int* label; float* score;
+    float4* box; float* conf; float* cconf; int* label;
     float4* sbox; float* sconf; float* scconf; int* slabel;
     float* key; unsigned* idx;           // [B*Npad] sort buffers
-    int* nvalid;                          // [B] unused since the image kernel counts for itself (slot kept: workspace layout)
     float* out; int* out_counts;
 };
 
@@ -105,8 +106,6 @@ __global__ __launch_bounds__(kPrepT) void yolo_nms_prep_kernel(const YParams P) 
             P.key[(size_t)b * P.Npad + n] = -INFINITY;
             P.idx[(size_t)b * P.Npad + n] = 0xffffffffu;
         }
-        const unsigned long long m = __ballot(valid);
-        (void)m;                                                 // the image kernel counts the valid candidates itself (no same-address atomics)
     }
 }
 
@@ -401,7 +400,7 @@ __global__ __launch_bounds__(kImgT) void yolo_nms_image_kernel(const YParams P) 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 inline int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
-struct YPlan { size_t nvalid, box, conf, cconf, label, sbox, sconf, scconf, slabel, key, idx, total; int N, Npad; };
+struct YPlan { size_t box, conf, cconf, label, sbox, sconf, scconf, slabel, key, idx, total; int N, Npad; };
 
 bool make_yplan(const odpl_yolo_nms_desc_t* d, YPlan* p) {
     if (!d || d->nscales < 1 || d->nscales > ODPL_MAX_SCALES || d->B < 1 || d->A < 1 || d->no < 6) return false;
@@ -411,7 +410,6 @@ bool make_yplan(const odpl_yolo_nms_desc_t* d, YPlan* p) {
     p->N = (int)N; p->Npad = next_pow2((int)N); if (p->Npad < 2) p->Npad = 2;
     const size_t BN = (size_t)d->B * N, BP = (size_t)d->B * p->Npad;
     size_t off = 0;
-    p->nvalid = off; off += align_up((size_t)d->B * sizeof(int), 256);
     p->box = off;    off += align_up(BN * 16, 256);
     p->conf = off;   off += align_up(BN * 4, 256);
     p->cconf = off;  off += align_up(BN * 4, 256);
@@ -450,10 +448,10 @@ extern "C" int odpl_yolo_nms(const odpl_yolo_nms_desc_t* d, void* workspace, siz
     P.nscales = d->nscales; P.B = d->B; P.A = d->A; P.no = d->no; P.N = pl.N; P.Npad = pl.Npad;
     P.conf_thres = d->conf_thres; P.nms_thres = d->nms_thres;
     P.box = (float4*)(ws + pl.box); P.conf = (float*)(ws + pl.conf); P.cconf = (float*)(ws + pl.cconf);
-    P.label = (int*)(ws + pl.label); P.score = nullptr;
+    P.label = (int*)(ws + pl.label);
     P.sbox = (float4*)(ws + pl.sbox); P.sconf = (float*)(ws + pl.sconf); P.scconf = (float*)(ws + pl.scconf);
     P.slabel = (int*)(ws + pl.slabel); P.key = (float*)(ws + pl.key); P.idx = (unsigned*)(ws + pl.idx);
-    P.nvalid = (int*)(ws + pl.nvalid); P.out = out_dets; P.out_counts = out_counts;
+    P.out = out_dets; P.out_counts = out_counts;
     prof_begin(ODPL_PROF_YOLO_NMS_PREP, stream);
     hipLaunchKernelGGL(yolo_nms_prep_kernel, dim3((pl.Npad + 63) / 64, d->B), dim3(kPrepT), 0, stream, P);
     prof_end(ODPL_PROF_YOLO_NMS_PREP, stream);
