@@ -1,5 +1,5 @@
-// Fused BatchNorm2d (training or eval) + activation (Mish / LeakyReLU(0.1) / identity) for channels-last fp32
-// tensors, forward and backward -- the conv epilogues of LightningFunc/utils/YoloV4Utils.py:208-236
+// Fused BatchNorm2d (training or eval) + activation (Mish / LeakyReLU(0.1) / ReLU / identity) for channels-last fp32 or
+// bf16 tensors, forward and backward -- the conv epilogues of LightningFunc/utils/YoloV4Utils.py:208-236
 // (Conv_Bn_Activation), SURVEY 8f rank 4.  In the profiled YOLOv4 step MIOpen's BN kernels + ATen's Mish kernels
 // make ~5 passes over every conv output in forward and ~7 in backward; this file makes 2 + 2:
 //   stats     per row-tile per-channel (sum, sum of squares) in DOUBLE -> partials            [1 read]
@@ -10,6 +10,10 @@
 //   bwd_dx    gx = gamma * invstd * (gz - dbeta/R - xhat * dgamma/R)                         [2 reads + 1 write]
 // Layout: a channels-last [N,C,H,W] tensor is a row-major [R = N*H*W, C] matrix; lanes run along C with 16-B
 // accesses (C % 4 == 0), so every wave instruction is a coalesced 1-KiB segment.  HBM-bound.
+// Riders on the same passes: the ResBlock skip add (apply: y += residual), column-slice outputs / gradient inputs of a
+// concatenated tensor (row strides: the CSP merges write in place of torch.cat), bf16 activations (template BF: 8-byte
+// quads, fp32 arithmetic, one rounding), inference (statistics derived from the running buffers inside apply), and the
+// per-channel bias gradient of the linear head convs.
 #include "odpl_common.hpp"
 #include "../../include/odpl_hip.h"
 

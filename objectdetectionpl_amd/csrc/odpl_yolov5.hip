@@ -3,7 +3,9 @@
 // (accuracy.py:71-114), forward AND d loss/d p for a unit upstream gradient.
 //
 // Layout: p[i] is [B, na, G, G, no] (channel-LAST, what Yolo_Layers.forward hands the criterion,
-// YOLOV5.py:93-97): a cell's no = 5+nc logits are 4*no contiguous bytes.
+// YOLOV5.py:93-97): a cell's no = 5+nc logits are 4*no contiguous bytes.  Heads and their gradients may be bf16
+// (desc.bf16: BASELINE config 5 trains under bf16 autocast): loads widen to fp32, every sum stays fp32, the gradient
+// stream packs 8 bf16 per 16-B store.
 //
 //   assign (1 WG / layer)  ratio test < 4, 'rect4' neighbour expansion, rows in the reference's order
 //                          [base | x-1 | y-1 | x+1 | y+1] by ballot/popcount compaction; owner map
