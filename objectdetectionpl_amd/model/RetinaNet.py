@@ -131,8 +131,8 @@ class RetinaNet(_Base):
         return nn.Sequential(*layers)
 
     def forward(self, x):
-        if self.iou_boxes is None or self.iou_boxes.device != x.device:
-            self._build_anchors(x.device)
+        if x.is_cuda and (self.iou_boxes is None or self.iou_boxes.device != x.device):
+            self._build_anchors(x.device)          # the anchor table (criterion / NMS side) lives on the HIP device only
         loc, cls = [], []
         for fm in self.fpn(x):
             loc.append(self.loc_head(fm).permute(0, 2, 3, 1).contiguous().view(x.size(0), -1, 4))

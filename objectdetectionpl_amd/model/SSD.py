@@ -110,7 +110,7 @@ class SSD(_Base):
         return torch.rand(self.sample, device=next(self.parameters()).device)
 
     def forward(self, x):
-        if self.iou_boxes is None or self.iou_boxes.device != x.device:
+        if x.is_cuda and (self.iou_boxes is None or self.iou_boxes.device != x.device):
             self._build_priors(x.device)
         B = x.size(0)
         out_cl, out_bbx = [], []

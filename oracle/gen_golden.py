@@ -587,6 +587,96 @@ GROUPS = {
 }
 
 
+# ---- caller models: state_dict manifests + forward fingerprints under a seeded deterministic fill -------------------
+def seeded_fill(model, seed):
+    """Deterministic parameters/buffers from the state_dict KEY ORDER and shapes alone, so that two implementations with
+    the same manifest get the same weights: 4-D conv weights ~ U(-1, 1) / sqrt(fan_in), 1-D `weight` (BN gamma) in
+    [0.75, 1.25], `bias` / `running_mean` in [-0.1, 0.1], `running_var` in [0.75, 1.25], integer buffers untouched."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for k, v in model.state_dict().items():
+            if not v.is_floating_point():
+                continue
+            r = torch.rand(v.shape, generator=g)
+            if v.dim() >= 2:
+                fan_in = v[0].numel()
+                v.copy_((r * 2 - 1) / fan_in ** 0.5)
+            elif k.endswith("running_var") or k.endswith("weight"):
+                v.copy_(r * 0.5 + 0.75)
+            else:
+                v.copy_(r * 0.2 - 0.1)
+
+
+def fingerprint(outs):
+    """Per output tensor: shape, sum, sum of |.|, and 64 evenly strided samples (enough to catch any wiring difference)."""
+    fp = {}
+    for i, t in enumerate(outs):
+        t = t.detach().float().contiguous()
+        flat = t.flatten()
+        step = max(1, flat.numel() // 64)
+        fp[f"out{i}_shape"] = np.array(t.shape, dtype=np.int64)
+        fp[f"out{i}_sum"] = np.array([flat.double().sum().item(), flat.double().abs().sum().item()])
+        fp[f"out{i}_samples"] = npy(flat[::step][:64])
+    return fp
+
+
+MODEL_CASES = {            # name -> (module, class, classes, args overrides, input size)
+    "yolov4": ("model.YOLOV4", "YOLOv4", 80, dict(model_name="YOLOv4"), 64),
+    "yolov2": ("model.YOLOV2", "YOLOv2", 20, dict(model_name="YOLOv2"), 64),
+    "yolov3": ("model.YOLOV3", "YOLOv3", 80, dict(model_name="YOLOv3", coord_criterion="mse_loss"), 64),
+    "yolov5s": ("model.YOLOV5", "YOLOv5", 80, dict(model_name="YOLOv5", type="Yolov5s"), 64),
+    "yolov5l": ("model.YOLOV5", "YOLOv5", 80, dict(model_name="YOLOv5", type="Yolov5l"), 64),
+    "retinanet": ("model.RetinaNet", "RetinaNet", 4, dict(model_name="RetinaNet", cls_criterion="focal_loss"), 64),
+}
+
+
+def model_input(size, batch):
+    return torch.rand(batch, 3, size, size, generator=torch.Generator().manual_seed(77))
+
+
+def group_models(losses, accuracy):
+    """state_dict key/shape manifests (tests/golden/state_dict_*.json) and forward fingerprints (models_forward.npz) of the
+    reference's model classes.  The reference unpickles `dataset/pallete` at class-definition time (a colour table for the
+    drawing helpers); that load is NOT performed -- `pickle.load` is stubbed for the duration of the imports."""
+    import importlib
+    import json
+    import pickle
+    real_load = pickle.load
+    pickle.load = lambda f, *a, **k: [(0, 0, 0)] * 256
+    try:
+        mods = {m: importlib.import_module(m) for m in sorted({c[0] for c in MODEL_CASES.values()})}
+    finally:
+        pickle.load = real_load
+    fps, v5_manifest = {}, {}
+    for name, (mod, cls, nc, over, size) in MODEL_CASES.items():
+        args = _Args(**{**dict(cls_criterion="bce_loss", coord_criterion="smooth_l1_loss", data_module="x"), **over})
+        torch.manual_seed(0)
+        model = getattr(mods[mod], cls)([str(i) for i in range(nc)], args)
+        manifest = {k: list(v.shape) for k, v in model.state_dict().items()}
+        if name.startswith("yolov5"):
+            v5_manifest[over["type"]] = manifest
+        else:
+            with open(os.path.join(OUT, f"state_dict_{name}.json"), "w") as f:
+                json.dump(manifest, f)
+        seeded_fill(model, 1234)
+        with torch.no_grad():
+            model.eval()
+            o = model(model_input(size, 1))
+            for k, v in fingerprint(list(o) if isinstance(o, (list, tuple)) else [o]).items():
+                fps[f"{name}_eval_{k}"] = v
+            model.train()
+            o = model(model_input(size, 2))
+            for k, v in fingerprint(list(o) if isinstance(o, (list, tuple)) else [o]).items():
+                fps[f"{name}_train_{k}"] = v
+        print(name, "ok", len(manifest), "keys")
+    with open(os.path.join(OUT, "state_dict_yolov5.json"), "w") as f:
+        json.dump(v5_manifest, f)
+    save("models_forward", **fps)
+
+
+GROUPS["models"] = group_models
+
+
 def main(argv):
     names = argv or list(GROUPS)
     losses, accuracy = load_reference()
