@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 
 from ..LightningFunc import lightningUtils as _lu
+from ..LightningFunc import optimizer as _opt
 from ..LightningFunc import step as _step
 from ..LightningFunc.losses import configure_loss
 from ..LightningFunc.nms import greedy_non_max_suppression
@@ -135,3 +136,4 @@ class SSD(_Base):
     test_epoch_end = _step.test_epoch_end
     write_Best_model_path = _lu.write_Best_model_path
     read_Best_model_path = _lu.read_Best_model_path
+    configure_optimizers = _opt.configure_optimizers

@@ -8,6 +8,7 @@ import torch
 import torch.nn as nn
 
 from ..LightningFunc import lightningUtils as _lu
+from ..LightningFunc import optimizer as _opt
 from ..LightningFunc import step as _step
 from ..LightningFunc.accuracy import get_yolo_statistics as _get_yolo_statistics
 from ..LightningFunc.losses import configure_loss
@@ -102,4 +103,5 @@ class YOLOv2(_Base):
     test_epoch_end = _step.test_epoch_end
     write_Best_model_path = _lu.write_Best_model_path
     read_Best_model_path = _lu.read_Best_model_path
+    configure_optimizers = _opt.configure_optimizers
     get_yolo_statistics = _get_yolo_statistics

@@ -37,18 +37,21 @@ class Trainer:
             yield i, tuple(t.to(self.device, non_blocking=True) for t in batch)
 
     def _optimizer(self, model):
-        if hasattr(model, "configure_optimizers"):
-            opt = model.configure_optimizers()
-            return opt[0][0] if isinstance(opt, (tuple, list)) and isinstance(opt[0], (tuple, list)) else (opt[0] if isinstance(opt, (tuple, list)) else opt)
+        """-> (optimizer, scheduler or None, monitor).  A model carrying `args.optimizer` uses the reference's factory
+        (`LightningFunc/optimizer.py:configure_optimizers`); otherwise fused Adam on `args.lr` / `args.weight_decay`."""
         a = model.args
-        return torch.optim.Adam(model.parameters(), lr=getattr(a, "lr", 1e-3), weight_decay=getattr(a, "weight_decay", 0.0), fused=True)
+        if hasattr(model, "configure_optimizers") and hasattr(a, "optimizer") and hasattr(a, "lr_scheduler"):
+            cfg = model.configure_optimizers()
+            return cfg["optimizer"], cfg.get("lr_scheduler"), cfg.get("monitor", "val_loss")
+        return (torch.optim.Adam(model.parameters(), lr=getattr(a, "lr", 1e-3), weight_decay=getattr(a, "weight_decay", 0.0), fused=True),
+                None, "val_loss")
 
     def fit(self, model, datamodule):
         model.to(self.device).train()
         if self.world > 1:
             parallel.init_process_group_from_env(self.device)
         net = parallel.wrap_data_parallel(model, self.device) if self.world > 1 else model
-        opt = self._optimizer(model)
+        opt, sched, _monitor = self._optimizer(model)
         history = []
         model.global_step = 0
         for epoch in range(self.max_epochs):
@@ -74,6 +77,11 @@ class Trainer:
                 history.append(("train", epoch, model.training_epoch_end(outs)))
             model.eval()
             vouts = [model.validation_step(b, i) for i, b in self._take(datamodule.val_dataloader(), "val")]
+            if vouts and sched is not None:              # epoch-level scheduler step, the plateau one on val_loss (PL's "monitor")
+                if isinstance(sched, torch.optim.lr_scheduler.ReduceLROnPlateau):
+                    sched.step(float(torch.stack([o["loss"].detach() for o in vouts]).mean()))
+                else:
+                    sched.step()
             if vouts:
                 if self.checkpoint_callback is not None and self.rank == 0:
                     model.checkpoint_callback = self.checkpoint_callback

@@ -54,3 +54,28 @@ def test_ssd_state_dict():
     from objectdetectionpl_amd.model.SSD import SSD
     g = json.load(open(os.path.join(HERE, "golden", "state_dict_ssd.json")))
     _check(SSD([str(i) for i in range(g["num_classes"])], A(model_name="SSD", cls_criterion="ce_loss")), g["state_dict"])
+
+
+def test_configure_optimizers_mirrors_the_reference_choices():
+    """LightningFunc/optimizer.py:6-38: every optimizer / scheduler name of configs/config.yaml, the dict shape, the plateau quirk."""
+    import torch
+    from objectdetectionpl_amd.LightningFunc import optimizer as ref_opt
+    get_lr = ref_opt.get_lr
+
+    class M(torch.nn.Linear):
+        configure_optimizers = ref_opt.configure_optimizers
+
+    for opt, cls in (("Adam", torch.optim.Adam), ("Adagrad", torch.optim.Adagrad), ("RMSprop", torch.optim.RMSprop), ("SGD", torch.optim.SGD)):
+        for sch in ("ReduceLROnPlateau", "StepLR", "MultiStepLR", "ExponentialLR", "CosineAnnealingLR", "LambdaLR", "CyclicLR"):
+            if sch == "CyclicLR" and opt in ("Adam", "Adagrad"):
+                continue                                    # torch's CyclicLR needs a momentum-style optimizer (also in the reference)
+            m = M(4, 2)
+            m.args = A(optimizer=opt, lr_scheduler=sch, lr=1e-3, lr_decay=0, momentum=0.9, weight_decay=1e-5, alpha=0.95)
+            cfg = m.configure_optimizers()
+            assert set(cfg) == {"optimizer", "lr_scheduler", "monitor"} and cfg["monitor"] == "val_loss"
+            assert isinstance(cfg["optimizer"], cls) and type(cfg["lr_scheduler"]).__name__ == sch
+            if sch != "CyclicLR":
+                assert get_lr(cfg["optimizer"]) == 1e-3
+    assert cfg is not None
+    m.args = A(optimizer="Adam", lr_scheduler="ReduceLROnPlateau", lr=1e-3, lr_decay=0, momentum=0.9, weight_decay=1e-5, alpha=0.95)
+    assert m.configure_optimizers()["lr_scheduler"].mode == "max"          # SURVEY appendix B, quirk 4
