@@ -121,6 +121,8 @@ def main():
     ap.add_argument("--bucket-mb", type=int, default=48)
     ap.add_argument("--ddp-impl", default="bucketed", choices=["bucketed", "torch"],
                     help="gradient exchange: own bucketed averager (7 launches/step) or torch DistributedDataParallel")
+    ap.add_argument("--overlap-wgrad", action="store_true",
+                    help="issue the convolutions' weight-gradient kernels on a side stream (LightningFunc/utils/convsplit.py)")
     ap.add_argument("--force-ddp", action="store_true", help="wrap in DDP (RCCL) even at world size 1: exercises the N>1 code path on one GPU")
     ap.add_argument("--stamp", action="store_true", help="diagnostic: in-kernel 100 MHz stamps of yolo_dense_kernel (first start -> last end)")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="libodpl_hip tunable, e.g. yolo_fill_nt=1")
@@ -167,6 +169,9 @@ def main():
     from objectdetectionpl_amd.model.YOLOV4 import YOLOv4
     from objectdetectionpl_amd.parallel import wrap_data_parallel
 
+    if a.overlap_wgrad:
+        from objectdetectionpl_amd.LightningFunc.utils import convsplit
+        convsplit.enabled = True
     for kv in a.tune:
         k, v = kv.split("=")
         _lib.tune_set(k, int(v))

@@ -21,6 +21,7 @@ from ..LightningFunc import step as _step
 from ..LightningFunc.accuracy import get_yolo_statistics as _get_yolo_statistics
 from ..LightningFunc.losses import configure_loss
 from ..LightningFunc.utils import bnact as _bnact
+from ..LightningFunc.utils import convsplit as _cs
 from ..LightningFunc.utils.spp import spp_cat
 
 try:                                    # PL is optional: the reference derives from pl.LightningModule
@@ -52,7 +53,7 @@ class ConvUnit(nn.Module):
         """act(bn(conv(x))) [+ residual]: the skip add of a ResBlock rides on the epilogue's write."""
         if residual is not None:
             if self._act is not None and ConvUnit.fuse_epilogue:
-                z = self.conv[0](x)
+                z = _cs.conv2d(x, self.conv[0])
                 if _bnact.fusable(z, self.conv[1]):
                     return _bnact.bn_act(z, self.conv[1], self._act, residual)
                 for l in list(self.conv)[1:]:
@@ -62,7 +63,7 @@ class ConvUnit(nn.Module):
         if self._plain_bias and ConvUnit.fuse_epilogue and x.is_cuda and x.dtype == torch.float32:
             return _bnact.conv_bias(x, self.conv[0])                 # head conv: bias gradient by the HIP channel sum
         if self._act is not None and ConvUnit.fuse_epilogue:
-            z = self.conv[0](x)
+            z = _cs.conv2d(x, self.conv[0])
             if _bnact.fusable(z, self.conv[1]):
                 return _bnact.bn_act(z, self.conv[1], self._act)     # fused BN + activation (HIP, channels-last)
             x = z
@@ -79,7 +80,7 @@ class ConvUnit(nn.Module):
 def cat_units(u1, x1, u2, x2):
     """torch.cat([u1(x1), u2(x2)], 1) for two conv+BN+activation units: their epilogues write straight into the merged tensor."""
     if ConvUnit.fuse_epilogue and u1._act is not None and u2._act is not None:
-        z1, z2 = u1.conv[0](x1), u2.conv[0](x2)
+        z1, z2 = _cs.conv2d(x1, u1.conv[0]), _cs.conv2d(x2, u2.conv[0])
         if _bnact.fusable(z1, u1.conv[1]) and _bnact.fusable(z2, u2.conv[1]):
             y = _bnact.bn_act_cat(z1, u1.conv[1], u1._act, z2, u2.conv[1], u2._act)
             if y is not None:

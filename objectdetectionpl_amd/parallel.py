@@ -102,6 +102,9 @@ class GradAverager:
             self._launch(b)
 
     def _launch(self, b):
+        if b.flat.is_cuda:
+            from .LightningFunc.utils import convsplit
+            convsplit.join(b.flat.device)                               # weight gradients issued on the side stream (if any)
         torch._foreach_copy_(b.views, [p.grad for p in b.params])      # one multi-tensor kernel per bucket
         for p, v in zip(b.params, b.views):
             p.grad = v                                                  # the optimiser reads the averaged flat buffer
