@@ -2,7 +2,7 @@
 """Golden-vector generator (test infrastructure; runs ONLY in the build container).
 
 Imports the reference's own Python from /root/reference (read-only) under the five
-benign shims listed in SURVEY.md section 8c, feeds it seeded inputs and stores the
+benign shims listed in SURVEY.md section 8c (plus a stub that keeps the pickled colour table from being loaded), feeds it seeded inputs and stores the
 inputs + the reference's outputs as small .npz fixtures under tests/golden/.
 Nothing of the reference's source travels: fixtures are data only.
 
@@ -37,6 +37,8 @@ def load_reference():
     torch.Tensor.cuda = lambda self, *a, **k: self                      # shim 5: no GPU here
     nn.Module.cuda = lambda self, *a, **k: self
     torch.cuda.FloatTensor = torch.FloatTensor
+    import pickle                                                       # shim 6: the model modules unpickle a colour table
+    pickle.load = lambda f, *a, **k: [(0, 0, 0)] * 256                  # (`dataset/pallete`) at class definition: never loaded
     sys.path.insert(0, REF)
     os.chdir(REF)                                                       # class-level open("dataset//pallete")
     from LightningFunc import accuracy, losses
@@ -637,16 +639,10 @@ def model_input(size, batch):
 def group_models(losses, accuracy):
     """state_dict key/shape manifests (tests/golden/state_dict_*.json) and forward fingerprints (models_forward.npz) of the
     reference's model classes.  The reference unpickles `dataset/pallete` at class-definition time (a colour table for the
-    drawing helpers); that load is NOT performed -- `pickle.load` is stubbed for the duration of the imports."""
+    drawing helpers); that load is NOT performed -- `pickle.load` is stubbed in `load_reference` (shim 6)."""
     import importlib
     import json
-    import pickle
-    real_load = pickle.load
-    pickle.load = lambda f, *a, **k: [(0, 0, 0)] * 256
-    try:
-        mods = {m: importlib.import_module(m) for m in sorted({c[0] for c in MODEL_CASES.values()})}
-    finally:
-        pickle.load = real_load
+    mods = {m: importlib.import_module(m) for m in sorted({c[0] for c in MODEL_CASES.values()})}
     fps, v5_manifest = {}, {}
     for name, (mod, cls, nc, over, size) in MODEL_CASES.items():
         args = _Args(**{**dict(cls_criterion="bce_loss", coord_criterion="smooth_l1_loss", data_module="x"), **over})
