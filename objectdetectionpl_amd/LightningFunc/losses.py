@@ -153,6 +153,9 @@ class _RegionLossBase(nn.Module):
         return out7, counts
 
     def _run(self, heads, target, scale_anchors, average):
+        # half-precision heads (a bf16 / fp16 autocast network): the reference computes this loss in fp32, so widen once;
+        # autograd narrows the gradients back (YOLOv5's criterion consumes bf16 heads natively instead)
+        heads = [h.float() if h.dtype in (torch.bfloat16, torch.float16) else h for h in heads]
         loss, metrics, _counts = _RegionLossFn.apply(self, target, scale_anchors, average, *heads)
         vals = (loss,) + tuple(metrics.unbind(0))
         return dict(zip(KEYS, vals))
