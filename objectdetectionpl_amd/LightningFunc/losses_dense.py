@@ -123,9 +123,15 @@ class RetinaNetLoss(nn.Module):
         return out3, counts
 
     def forward(self, outputs, targets):
-        loc_preds, cls_preds = outputs
+        loc_preds, cls_preds = (_widen(t) for t in outputs)
         loss, metrics, _ = _RetinaLossFn.apply(self, targets, loc_preds, cls_preds)
         return {"loss": loss, "Localization": metrics[0], "Classification": metrics[1]}
+
+
+def _widen(t):
+    """Half-precision predictions (an autocast network): the reference computes these losses in fp32 -- widen once, autograd
+    narrows the gradient back."""
+    return t.float() if t.dtype in (torch.bfloat16, torch.float16) else t
 
 
 class _SSDLossFn(torch.autograd.Function):
@@ -214,7 +220,7 @@ class SSDLoss(nn.Module):
         return out3, counts
 
     def forward(self, outputs, targets):
-        predicted_offsets, predicted_classes = outputs
+        predicted_offsets, predicted_classes = (_widen(t) for t in outputs)
         assert predicted_classes.size(0) == predicted_offsets.size(0)
         loss, m, _ = _SSDLossFn.apply(self, targets, predicted_offsets, predicted_classes)
         return {"loss": loss, "Localization": m[0], "Classification": m[1]}
