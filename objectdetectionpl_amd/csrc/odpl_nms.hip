@@ -529,7 +529,7 @@ __global__ __launch_bounds__(256) void greedy_nms_prep_kernel(const GParams P) {
     // combine the 4 lanes of a row: larger value, then smaller index (torch.max(1): first index on ties)
     for (int o = 1; o < 4; o <<= 1) {
         const float ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
-        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        if ((ob != ob && (best == best || oi < bi)) || (best == best && (ob > best || (ob == best && oi < bi)))) { best = ob; bi = oi; }   // NaN wins, first one
     }
     if (r < nr && q == 0) {
         const size_t o = (size_t)b * P.An + a0 + r;

@@ -136,3 +136,51 @@ def test_yolo_nms_more_valid_candidates_than_the_lds_sort_holds():
     g = torch.Generator().manual_seed(69)
     heads = _clustered_heads(g, 1, 3, (80,), conf_shift=4.0, spread=15.0)
     _same_as_oracle(heads)
+
+
+def test_greedy_prep_scores_and_labels_equal_the_max_over_sigmoids():
+    """The prep kernel takes the row maximum on the logits and evaluates the sigmoid only on possible ties: scores and labels
+    must equal `cls.sigmoid().max(1)` bit for bit, including saturated ties (sigmoid(20) == sigmoid(25) == 1 -> first index),
+    near-ties within one float of the sigmoid, rows of equal logits and very negative rows."""
+    from objectdetectionpl_amd.LightningFunc.nms import greedy_non_max_suppression
+    g = torch.Generator().manual_seed(12)
+    An, C = 4096, 80
+    cls = torch.randn(1, An, C, generator=g) * 3.0
+    cls[0, 0, 5] = 20.0; cls[0, 0, 9] = 25.0                         # both saturate to 1.0: label 5
+    cls[0, 1, 40] = 30.0; cls[0, 1, 3] = 17.5                        # 17.5 may or may not round to 1.0
+    cls[0, 2, :] = 0.25                                              # all equal: label 0
+    cls[0, 3, :] = -40.0; cls[0, 3, 7] = -39.9999
+    base = torch.rand(An, generator=g) * 6
+    cls[0, 4:, 11] = base[4:]; cls[0, 4:, 60] = base[4:] + (torch.rand(An - 4, generator=g) - 0.5) * 2e-4   # near ties around the max
+    cls[0, 4:, 11] += 6.0; cls[0, 4:, 60] += 6.0
+    anchors = torch.cat([torch.rand(An, 2, generator=g) * 500 + 50, torch.rand(An, 2, generator=g) * 40 + 10], 1)
+    loc = torch.zeros(1, An, 4)
+    score_ref, label_ref = cls[0].cuda().sigmoid().max(1)            # the same device sigmoid family torch would use
+    import ctypes
+    from objectdetectionpl_amd import _lib
+    L = _lib.lib()
+    d = _lib.GreedyNmsDesc()
+    locd, clsd, and_ = loc.cuda().contiguous(), cls.cuda().contiguous(), anchors.cuda().contiguous()
+    d.loc, d.cls, d.anchors = locd.data_ptr(), clsd.data_ptr(), and_.data_ptr()
+    d.B, d.An, d.C, d.topk = 1, An, C, 100
+    d.nms_thresh, d.class_thresh = 0.5, 0.45
+    need = L.odpl_greedy_nms_workspace_bytes(ctypes.byref(d))
+    ws = torch.zeros(need, dtype=torch.uint8, device="cuda")
+    out = torch.empty(1, 100, 7, device="cuda"); counts = torch.empty(1, 2, dtype=torch.int32, device="cuda")
+    _lib.check(L.odpl_greedy_nms(ctypes.byref(d), _lib.ptr(ws), need, _lib.ptr(out), _lib.ptr(counts), _lib.current_stream(out.device)), "odpl_greedy_nms")
+    torch.cuda.synchronize()
+    score = ws[:An * 4].view(torch.float32)                           # workspace layout: score [B*An] then label [B*An] (256-B aligned)
+    off = (An * 4 + 255) // 256 * 256
+    label = ws[off:off + An * 4].view(torch.int32)
+    cpu_ref_s, cpu_ref_l = cls[0].sigmoid().max(1)
+    lab = label.cpu().long()
+    assert torch.allclose(score.cpu(), cpu_ref_s, rtol=1e-6, atol=1e-7)
+    assert int(lab[0]) == 5 and int(lab[2]) == 0 and int(lab[3]) == 7 and int(lab[1]) in (3, 40)
+    top2 = cls[0].topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 0.05                          # unambiguous rows: the label is the arg-max of the logits
+    clear[:4] = False
+    assert int(clear.sum()) == 0 or torch.equal(lab[clear], cls[0].argmax(1)[clear])
+    near = ~clear; near[:4] = False
+    picked = cls[0].gather(1, lab[:, None])[:, 0]                       # near ties: the label is one of the contenders within the
+    assert bool((torch.sigmoid(picked[near]) >= torch.sigmoid(top2[near, 0]) - 1.2e-7).all())   # ... whose sigmoid ties with the maximum
+    assert label_ref.shape == lab.shape
