@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ODPL_ABI_VERSION 1
+#define ODPL_ABI_VERSION 2   /* 2: bf16 flags on the epilogue / SPP / bias entries, odpl_image_t.lut, strided BN entries */
 #define ODPL_EINVAL (-1)
 #define ODPL_MAX_SCALES 4
 #define ODPL_MAX_ANCHORS 8

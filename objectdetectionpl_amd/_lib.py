@@ -6,6 +6,7 @@ from ctypes import POINTER, c_float, c_int32, c_size_t, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libodpl_hip.so")
 
+ABI_VERSION = 2            # include/odpl_hip.h: ODPL_ABI_VERSION
 MAX_SCALES = 4
 MAX_ANCHORS = 8
 COORD_MODES = {"mse_loss": 0, "smooth_l1_loss": 1}
@@ -156,7 +157,7 @@ def lib():
                 raise OdplError(f"{LIB_PATH} does not export {name}; rebuild the library") from e
             fn.restype = res
             fn.argtypes = args
-        if l.odpl_abi_version() != 1:
+        if l.odpl_abi_version() != ABI_VERSION:
             raise OdplError("libodpl_hip.so ABI version mismatch; rebuild")
         _lib = l
     return _lib
