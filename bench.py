@@ -22,8 +22,9 @@ if REPO not in sys.path:
 # MIOpen ships no gfx950 find-db / kernel-db in this image, so the exhaustive solver search over the ~300 conv
 # problems of YOLOv4 costs ~220 s on a fresh box.  The search RESULTS (text find-db + compiled-kernel cache,
 # produced by tools/build_miopen_db.sh) live under miopen_db/; each rank works on a private copy so that eight
-# processes never contend for one sqlite file.  A missing or stale db only costs start-up time.
+# processes never contend for one sqlite file (removed again at exit).  A missing or stale db only costs start-up time.
 def _stage_miopen_db():
+    import atexit
     import shutil
     import tempfile
     src = os.path.join(REPO, "miopen_db")
@@ -34,18 +35,80 @@ def _stage_miopen_db():
         os.makedirs(os.path.join(dst, "cache"), exist_ok=True)
         os.environ.setdefault("MIOPEN_USER_DB_PATH", dst)
         os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", os.path.join(dst, "cache"))
+        atexit.register(shutil.rmtree, dst, ignore_errors=True)
     except OSError:
         pass
 
 
-_stage_miopen_db()
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
-import torch
-import torch.distributed as dist
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` started by hand (no torchrun): the reference's multi-GPU entry is ONE process start
+    (run.py:109-115 with configs/config.yaml:58-61 `gpus: -1`; PL spawns one process per GPU).  This parent never touches
+    the GPU (no torch import, no HIP call): it starts one child per GPU with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*
+    set as torchrun would, relays rank 0's single JSON line, and exits non-zero if any rank does."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MASTER_ADDR"] = "127.0.0.1"
+    env["MASTER_PORT"] = str(_free_port())
+    env["WORLD_SIZE"] = env["LOCAL_WORLD_SIZE"] = str(n)
+    env["ODPL_BENCH_CHILD"] = "1"
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        # rank 0's stdout is the JSON channel; the other ranks' stdout goes to our stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rc = 0
+    try:
+        while True:                             # a rank that dies takes the job down: its peers would wait in a collective
+            codes = [p.poll() for p in procs]
+            if all(c is not None for c in codes) or any(c not in (None, 0) for c in codes):
+                break
+            time.sleep(0.1)
+    finally:
+        for p in procs:                         # exactly the PIDs started above
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    reader.join(timeout=10)
+    out0 = b"".join(c for c in chunks if c)
+    for r, p in enumerate(procs):
+        if p.returncode != 0:
+            print(f"[bench launcher] rank {r} exited with code {p.returncode}", file=sys.stderr, flush=True)
+            rc = rc or (p.returncode if p.returncode and p.returncode > 0 else 1)
+    lines = [l for l in out0.decode(errors="replace").splitlines() if l.strip()]
+    if rc == 0 and len(lines) != 1:
+        print(f"[bench launcher] rank 0 printed {len(lines)} lines, expected exactly one", file=sys.stderr, flush=True)
+        rc = 1
+    if rc == 0:
+        sys.stdout.write(lines[0] + "\n")
+        sys.stdout.flush()
+    return rc
+
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 V4_ANCHORS = [[12, 16], [19, 36], [40, 28], [36, 75], [76, 55], [72, 146], [142, 110], [192, 243], [459, 401]]
 V4_MASKS = [[0, 1, 2], [3, 4, 5], [6, 7, 8]]
+GPU_BOX_CPU_SHARE = 16          # host threads one GPU's worth of a node may use (the box exposes every core of the host)
+
+torch = None                    # imported by main() in the rank processes only: the launcher parent never loads it
+dist = None
 
 
 class Args:
@@ -71,16 +134,36 @@ def synthetic_batch(seed, B, C, img, device):
     return x.to(device), y.to(device)
 
 
-def cpu_baseline(B_sample, C, img, steps):
-    """The reference's CPU path restated: same network on torch-CPU + the oracle loss, timed on the host."""
-    from oracle import yolo as oracle_yolo
-    from objectdetectionpl_amd.model.YOLOV4 import YOLOv4
-    cores = os.cpu_count() or 1
+def allotted_cores():
+    """(threads to use, what bounded them): the affinity mask, a cgroup-v2 CPU quota if one is set, and one GPU's share
+    of the node (GPU_BOX_CPU_SHARE) -- the bench runs beside seven other GPUs' worth of work on a full node."""
+    n, why = os.cpu_count() or 1, "os.cpu_count"
     try:
-        cores = len(os.sched_getaffinity(0))
+        a = len(os.sched_getaffinity(0))
+        if a < n:
+            n, why = a, "sched_getaffinity"
     except Exception:  # noqa: BLE001
         pass
-    cores = min(cores, 16)      # one GPU's share of the host (the box exposes all 256 cores)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            q = max(1, int(int(quota) / int(period)))
+            if q < n:
+                n, why = q, "cgroup cpu.max"
+    except Exception:  # noqa: BLE001
+        pass
+    if n > GPU_BOX_CPU_SHARE:
+        n, why = GPU_BOX_CPU_SHARE, f"one GPU's share of the node ({GPU_BOX_CPU_SHARE} of {os.cpu_count()} visible cores)"
+    return n, why
+
+
+def cpu_baseline(B_sample, C, img, steps, warmup=1):
+    """The reference's CPU path restated: same network on torch-CPU + the oracle loss + Adam, timed on the host
+    (same seeds and shapes as config 2; a BOUNDED sample so the default run stays within minutes)."""
+    from oracle import yolo as oracle_yolo
+    from objectdetectionpl_amd.model.YOLOV4 import YOLOv4
+    cores, why = allotted_cores()
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     model = YOLOv4([str(i) for i in range(C)], Args()).train()
@@ -97,14 +180,50 @@ def cpu_baseline(B_sample, C, img, steps):
         opt.step()
         return t1 - t0
 
+    for _ in range(warmup):
+        step()
     t0 = time.perf_counter()
     loss_s = 0.0
     for _ in range(steps):
         loss_s += step()
     dt = time.perf_counter() - t0
     return {"value": round(B_sample * steps / dt, 3), "unit": "img/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} training step(s) of bs={B_sample} (same net on torch-CPU fp32, oracle loss, Adam), "
-                      f"{dt:.1f} s; oracle loss forward alone {1e3 * loss_s / steps:.0f} ms/step"}
+            "sample": f"{warmup} warm-up + {steps} timed training step(s) of bs={B_sample} (same net on torch-CPU fp32, oracle loss, "
+                      f"Adam), {dt:.1f} s on {cores} threads (bounded by {why}); oracle loss forward alone "
+                      f"{1e3 * loss_s / steps:.0f} ms/step"}
+
+
+def rocprof_row(kernel):
+    """Average duration of `kernel` in the committed `rocprofv3 --kernel-trace --stats` summary of this command
+    (profiles/r02_rocprof_stats_bench.csv), so the live event timing and the profiler's figure sit side by side."""
+    import csv
+    for name in ("r02_rocprof_stats_bench.csv", "r01_rocprof_stats_yolo.csv"):
+        try:
+            with open(os.path.join(REPO, "profiles", name)) as f:
+                for row in csv.DictReader(f):
+                    if row.get("Name", "").startswith(kernel):
+                        return {"file": "profiles/" + name, "avg_us": round(float(row["AverageNs"]) / 1e3, 2), "calls": int(row["Calls"])}
+        except Exception:  # noqa: BLE001
+            continue
+    return None
+
+
+def dryrun_rank(json_fd):
+    """ODPL_BENCH_DRYRUN=1 (tests/test_bench_launcher.py, no GPU): the rank processes only rendezvous over gloo, sum their
+    ranks and rank 0 prints one line -- exercises the launcher / env plumbing / exit-code relay without a device."""
+    import torch.distributed as d
+    import torch as t
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    if os.environ.get("ODPL_BENCH_DRYRUN_FAIL_RANK") == str(rank):
+        sys.exit(7)
+    d.init_process_group("gloo")
+    v = t.tensor([float(1 + rank)])
+    d.all_reduce(v)
+    d.barrier()
+    if rank == 0:
+        os.write(json_fd, (json.dumps({"dryrun": True, "n_gpus": world, "seed_sum": float(v.item()),
+                                       "master": os.environ["MASTER_ADDR"] + ":" + os.environ["MASTER_PORT"]}) + "\n").encode())
+    d.destroy_process_group()
 
 
 def main():
@@ -116,8 +235,8 @@ def main():
     ap.add_argument("--classes", type=int, default=80)
     ap.add_argument("--img", type=int, default=416)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-batch", type=int, default=8)
-    ap.add_argument("--cpu-sample-steps", type=int, default=4)
+    ap.add_argument("--cpu-sample-batch", type=int, default=16)
+    ap.add_argument("--cpu-sample-steps", type=int, default=3)
     ap.add_argument("--bucket-mb", type=int, default=48)
     ap.add_argument("--ddp-impl", default="bucketed", choices=["bucketed", "torch"],
                     help="gradient exchange: own bucketed averager (7 launches/step) or torch DistributedDataParallel")
@@ -132,18 +251,29 @@ def main():
     ap.add_argument("--no-channels-last", dest="channels_last", action="store_false", help="NCHW memory format for the network")
     a = ap.parse_args()
 
-    t_start = time.perf_counter()
-    # stdout carries exactly ONE line (the JSON): libraries that print banners there (RCCL's version block, MIOpen) are sent
-    # to stderr by pointing fd 1 at fd 2 for the duration of the run; the result is written to the saved descriptor.
-    sys.stdout.flush()
-    json_fd = os.dup(1)
-    os.dup2(2, 1)
+    # ---- launcher: `python bench.py --gpus N` without torchrun -> this process only starts the N ranks -------------------
+    if a.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus > 1 and world != a.gpus:
-        sys.exit(f"--gpus {a.gpus} needs `python -m torch.distributed.run --nproc-per-node {a.gpus} bench.py ...` "
-                 f"(WORLD_SIZE={world})")
+        sys.exit(f"--gpus {a.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus {a.gpus}` or "
+                 f"`python -m torch.distributed.run --nproc-per-node {a.gpus} bench.py --gpus {a.gpus} ...`")
+    t_start = time.perf_counter()
+    # stdout carries exactly ONE line (the JSON): libraries that print banners there (RCCL's version block, gloo, MIOpen) are
+    # sent to stderr by pointing fd 1 at fd 2 for the duration of the run; the result is written to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    if os.environ.get("ODPL_BENCH_DRYRUN") == "1":
+        return dryrun_rank(json_fd)
+
+    global torch, dist
+    _stage_miopen_db()
+    import torch as _torch
+    import torch.distributed as _dist
+    torch, dist = _torch, _dist
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
     # REHEARSAL ONLY: ODPL_BENCH_BACKEND=gloo lets several ranks share one GPU (RCCL refuses duplicate devices) so that the
@@ -151,6 +281,9 @@ def main():
     backend = os.environ.get("ODPL_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local_rank %= max(torch.cuda.device_count(), 1)
+    elif local_rank >= torch.cuda.device_count():
+        sys.exit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible "
+                 f"(RCCL needs one device per rank; ODPL_BENCH_BACKEND=gloo rehearses the control flow on fewer)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_ddp = world > 1 or a.force_ddp
@@ -183,7 +316,7 @@ def main():
     crit = model.criterion
     net = wrap_data_parallel(model, dev, bucket_mb=a.bucket_mb, impl=a.ddp_impl) if use_ddp else model
     opt = torch.optim.Adam(model.parameters(), lr=Args.lr, weight_decay=Args.weight_decay, fused=bool(a.fused_adam))
-    x, y = synthetic_batch(1 + rank, a.batch, a.classes, a.img, dev)
+    x, y = synthetic_batch(1 + rank, a.batch, a.classes, a.img, dev)       # rank r draws from seed 1 + r
     if a.channels_last:
         x = x.contiguous(memory_format=torch.channels_last)
 
@@ -209,7 +342,9 @@ def main():
         torch.cuda.synchronize()
         log(f"warmup step {i + 1}/{a.warmup} done")     # the first step includes MIOpen solver selection / kernel builds
     fence()
-    _lib.profile_enable("yolo_dense", True)
+    PROF = ("yolo_dense", "yolo_assign", "yolo_obj", "yolo_finalize")
+    for k in PROF:
+        _lib.profile_enable(k, True)
     stamps = []
     if a.stamp:
         sbuf = torch.zeros(2 * 8192, dtype=torch.int64, device=dev)
@@ -225,8 +360,11 @@ def main():
             stamps.append(float(v[:, 1].max() - v[:, 0].min()) / 100.0)      # us: first workgroup start -> last end
     fence()
     dt = time.perf_counter() - t0
-    _lib.profile_enable("yolo_dense", False)
-    dense_ms, dense_raw_ms = _lib.profile_collect("yolo_dense")
+    prof = {}
+    for k in PROF:
+        _lib.profile_enable(k, False)
+        prof[k] = _lib.profile_collect(k)
+    dense_ms, dense_raw_ms = prof["yolo_dense"]
     loss_val = float(d["loss"].item())
 
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -260,16 +398,19 @@ def main():
         # as-built algorithmic bytes of yolo_dense_kernel per launch (DESIGN.md "Kernels"): write every gradient
         # element once + read the confidence row and the int32 state map once + reset the state map
         alg_bytes = 4 * cells * CH + 4 * cells + 4 * cells + 4 * cells
-        traffic = None
+        traffic, traffic_src = None, None
         try:        # PMC counters cannot be collected from inside this process: committed rocprofv3 --pmc passes
             with open(os.path.join(REPO, "profiles", "pmc_traffic.json")) as f:
                 pmc = json.load(f)
             if pmc["workload"] == {"batch": a.batch, "classes": a.classes, "img": a.img}:
                 traffic = pmc["yolo_dense_kernel"]["hbm_bytes"]
+                traffic_src = "committed PMC pass (" + pmc.get("source", "profiles/pmc_traffic.json") + "), not measured in this run"
         except Exception:  # noqa: BLE001
             pass
         avg_ms = sum(dense_ms) / max(len(dense_ms), 1)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if dense_ms else None
+        rp = rocprof_row("yolo_dense_kernel")
+        launches_us = {k: round(1e3 * sum(v[0]) / max(len(v[0]), 1), 2) for k, v in prof.items()}
         res = {
             "metric": "images/sec training step (YOLOv4 416x416, bs=16/GPU)",
             "value": round(a.batch * world * a.steps / dt, 2), "unit": "img/s",
@@ -278,14 +419,19 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"YOLOv4 COCO-synthetic {a.img}x{a.img} bs={a.batch}/GPU training step "
-                                   f"(fwd + HIP region loss + bwd + Adam), {a.classes} classes, 7 targets/img",
+                                   f"(fwd + HIP region loss + bwd + Adam), {a.classes} classes, 7 targets/img, rank r seeded 1+r",
                        "global_batch": a.batch * world, "parallelism": f"dp{world}", "loss_last": round(loss_val, 4)},
             "roofline": {"kernel": "yolo_dense_kernel", "bound": "hbm",
                          "achieved": None if achieved is None else round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "avg_kernel_us": round(avg_ms * 1e3, 2),
                          "avg_event_pair_us_uncorrected": round(1e3 * sum(dense_raw_ms) / max(len(dense_raw_ms), 1), 2),
+                         "rocprof_avg_kernel_us": None if rp is None else rp["avg_us"],
+                         "rocprof_frac": None if rp is None else round(alg_bytes / (rp["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                         "rocprof_source": None if rp is None else rp["file"],
                          "launches": len(dense_ms),
+                         "loss_launches_us": launches_us, "loss_launches_sum_us": round(sum(launches_us.values()), 2),
                          **({"in_kernel_stamp_us": round(sorted(stamps)[len(stamps) // 2], 2)} if stamps else {}),
                          "algorithmic_bytes": alg_bytes, "survey_8d_bytes": 2 * 4 * cells * CH},
         }

@@ -1,0 +1,28 @@
+"""`python bench.py --gpus 2` on a one-GPU box: the launcher starts two ranks that share the device (gloo instead of RCCL,
+which refuses duplicate devices -- ODPL_BENCH_BACKEND=gloo is a rehearsal switch, the judged runs use RCCL), each runs the
+real training step on its own seed (1 + rank), and rank 0's one JSON line carries the N > 1 fields."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_self_launches_two_ranks():
+    env = dict(os.environ, ODPL_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 32 and d["config"]["parallelism"] == "dp2"
+    assert d["value"] > 0 and d["scaling"] == "weak"
+    assert d["allreduce"]["bytes"] == 4 * 64363101 and d["allreduce"]["bus_GBps"] > 0       # 64.363 M parameters
+    assert d["roofline"]["launches"] == 2
