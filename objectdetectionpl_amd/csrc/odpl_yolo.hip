@@ -126,6 +126,10 @@ __global__ __launch_bounds__(kAssignThreads) void yolo_assign_kernel(const Param
             if (!(wrap_idx(b, B) & wrap_idx(gj, G) & wrap_idx(gi, G))) continue;
             const int cell = (((int)b * A + d.best) * G + (int)gj) * G + (int)gi;
             const int w = __hip_atomic_load(&S.state[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1;
+            if ((unsigned)w >= (unsigned)nT) {                            // impossible on a clean map (the owner is a row of THIS call):
+                atomicOr(&s_flags, 8);                                    // the STATE_CLEAN promise was broken -- flag it, index nothing
+                continue;
+            }
             if (w == t) {                                                 // last writer in row order wins
                 S.tcell[t] = cell;
                 if (t < kAssignRankCap) s_cell[t] = cell;
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(kAssignThreads) void yolo_assign_kernel(const Param
         S.counts[1] = B * A * S.G2 - L;         // nNoobj
         S.counts[2] = g1;
         S.counts[3] = g2;
-        S.counts[4] = st;
+        S.counts[4] = st | ((s_flags & 8) ? 2 : 0);     // status: bit0 index below -size (the reference raises), bit1 dirty state map
         S.counts[5] = S.counts[6] = S.counts[7] = 0;
     }
 }
@@ -265,7 +269,7 @@ __global__ __launch_bounds__(kObjThreads) void yolo_obj_kernel(const Params P) {
     const int t = blockIdx.x, tid = threadIdx.x, CH = P.CH, C = P.C, G2 = S.G2;
     float* part = S.obj_part + (size_t)t * 8;
     const int cell = S.tcell[t];
-    if (cell < 0) { if (tid < 8) part[tid] = 0.f; return; }
+    if (cell < 0 || cell >= P.B * S.A * G2) { if (tid < 8) part[tid] = 0.f; return; }
     const int plane = cell / G2, s = cell - plane * G2, a = plane % S.A;
     const size_t base = (size_t)plane * CH * G2 + s;
     const float* __restrict__ zp = S.head + base;

@@ -271,9 +271,11 @@ __global__ __launch_bounds__(kDT) void v5_dense_kernel(const VParams P) {
     const unsigned c_lo = e0 <= 4 ? 0u : (unsigned)((e0 - 4 + no - 1) / no);
     const int n_loc = e1 >= 5 ? (int)((e1 - 5) / no) - (int)c_lo + 1 : 0;        // cells with e0 <= no*c+4 < e1
     float acc = 0.f;
+    const int nrows_now = S.nrows[0];                         // rows the assign kernel of THIS call produced
     for (int i = tid; i < n_loc; i += kDT) {                  // one pass at no = 85 fp32 (<= 194 cells per chunk)
         const unsigned c = c_lo + i;
-        const int ow = S.owner[c];
+        int ow = S.owner[c];
+        if (ow >= nrows_now) { atomicOr(P.status, 4); S.owner[c] = -1; ow = -1; }   // a dirty map (broken STATE_CLEAN promise) never indexes the row arrays
         const float tobj = ow >= 0 ? fmaxf(S.row_iou[ow], 0.0f) : 0.0f;         // losses.py:123 (gr = 1)
         float l, dx;
         focal_bce(ld_head(S.p, (size_t)c * no + 4, BF16), tobj, l, dx);
