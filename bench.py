@@ -6,7 +6,7 @@ assignment, 7 loss terms and d loss/d head) + backward + Adam, on one synthetic 
 resident in HBM.  N>1: one process per GPU (torchrun), DDP over RCCL/xGMI, weak scaling.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying
-  roofline     : the dense kernel of the loss (yolo_dense_kernel), timed with HIP events on its launch stream
+  roofline     : the dominant kernel of the loss path, timed with HIP events on its launch stream
   cpu_baseline : the same training step on the host cores with the CPU oracle as the loss (rank 0, N=1 only)
 """
 import argparse
@@ -243,7 +243,7 @@ def main():
     ap.add_argument("--overlap-wgrad", action="store_true",
                     help="issue the convolutions' weight-gradient kernels on a side stream (LightningFunc/utils/convsplit.py)")
     ap.add_argument("--force-ddp", action="store_true", help="wrap in DDP (RCCL) even at world size 1: exercises the N>1 code path on one GPU")
-    ap.add_argument("--stamp", action="store_true", help="diagnostic: in-kernel 100 MHz stamps of yolo_dense_kernel (first start -> last end)")
+    ap.add_argument("--stamp", action="store_true", help="diagnostic: in-kernel 100 MHz stamps of yolo_expand_kernel (first start -> last end)")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="libodpl_hip tunable, e.g. yolo_fill_nt=1")
     ap.add_argument("--no-miopen-find", dest="miopen_find", action="store_false",
                     help="torch.backends.cudnn.benchmark=False (MIOpen immediate mode instead of the find-db solvers)")
@@ -342,7 +342,7 @@ def main():
         torch.cuda.synchronize()
         log(f"warmup step {i + 1}/{a.warmup} done")     # the first step includes MIOpen solver selection / kernel builds
     fence()
-    PROF = ("yolo_dense", "yolo_assign", "yolo_obj", "yolo_finalize")
+    PROF = ("yolo_expand", "yolo_assign", "yolo_loss", "yolo_finalize")
     for k in PROF:
         _lib.profile_enable(k, True)
     stamps = []
@@ -364,7 +364,7 @@ def main():
     for k in PROF:
         _lib.profile_enable(k, False)
         prof[k] = _lib.profile_collect(k)
-    dense_ms, dense_raw_ms = prof["yolo_dense"]
+    dense_ms, dense_raw_ms = prof["yolo_expand"]
     loss_val = float(d["loss"].item())
 
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -395,21 +395,21 @@ def main():
     if rank == 0:
         CH = 5 + a.classes
         cells = sum(a.batch * 3 * G * G for G in (a.img // 8, a.img // 16, a.img // 32))
-        # as-built algorithmic bytes of yolo_dense_kernel per launch (DESIGN.md "Kernels"): write every gradient
-        # element once + read the confidence row and the int32 state map once + reset the state map
-        alg_bytes = 4 * cells * CH + 4 * cells + 4 * cells + 4 * cells
+        # as-built algorithmic bytes of yolo_expand_kernel per launch (DESIGN.md "Kernels"): write every gradient
+        # element once + read the compact confidence gradient once
+        alg_bytes = 4 * cells * CH + 4 * cells
         traffic, traffic_src = None, None
         try:        # PMC counters cannot be collected from inside this process: committed rocprofv3 --pmc passes
             with open(os.path.join(REPO, "profiles", "pmc_traffic.json")) as f:
                 pmc = json.load(f)
             if pmc["workload"] == {"batch": a.batch, "classes": a.classes, "img": a.img}:
-                traffic = pmc["yolo_dense_kernel"]["hbm_bytes"]
+                traffic = pmc["yolo_expand_kernel"]["hbm_bytes"]
                 traffic_src = "committed PMC pass (" + pmc.get("source", "profiles/pmc_traffic.json") + "), not measured in this run"
         except Exception:  # noqa: BLE001
             pass
         avg_ms = sum(dense_ms) / max(len(dense_ms), 1)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if dense_ms else None
-        rp = rocprof_row("yolo_dense_kernel")
+        rp = rocprof_row("yolo_expand_kernel")
         launches_us = {k: round(1e3 * sum(v[0]) / max(len(v[0]), 1), 2) for k, v in prof.items()}
         res = {
             "metric": "images/sec training step (YOLOv4 416x416, bs=16/GPU)",
@@ -421,7 +421,7 @@ def main():
             "config": {"workload": f"YOLOv4 COCO-synthetic {a.img}x{a.img} bs={a.batch}/GPU training step "
                                    f"(fwd + HIP region loss + bwd + Adam), {a.classes} classes, 7 targets/img, rank r seeded 1+r",
                        "global_batch": a.batch * world, "parallelism": f"dp{world}", "loss_last": round(loss_val, 4)},
-            "roofline": {"kernel": "yolo_dense_kernel", "bound": "hbm",
+            "roofline": {"kernel": "yolo_expand_kernel", "bound": "hbm",
                          "achieved": None if achieved is None else round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_source": traffic_src,

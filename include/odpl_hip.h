@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ODPL_ABI_VERSION 2   /* 2: bf16 flags on the epilogue / SPP / bias entries, odpl_image_t.lut, strided BN entries */
+#define ODPL_ABI_VERSION 3   /* 3: memory-format strides + compact (structured) gradients on the YOLO losses, head-conv backward from them */
 #define ODPL_EINVAL (-1)
 #define ODPL_MAX_SCALES 4
 #define ODPL_MAX_ANCHORS 8
@@ -42,13 +42,21 @@ int odpl_abi_version(void);
 
 /* ---- YOLO v2/v3/v4 region loss: losses.py:475-905 + accuracy.py:305-380 ------------------ */
 
+/* memory formats of a [B, A*(5+C), G, G] head tensor (and of its gradient) */
+#define ODPL_LAYOUT_PLANAR 0        /* NCHW: element (b,a,c,s) at ((b*A + a)*(5+C) + c)*G*G + s */
+#define ODPL_LAYOUT_INTERLEAVED 1   /* channels-last: element (b,a,c,s) at ((b*G*G + s)*A + a)*(5+C) + c */
+
 typedef struct {
-    const float* head;              /* [B, A*(5+C), G, G] raw head tensor, NCHW as the conv wrote it */
-    float* grad;                    /* d loss / d head, same shape; NULL = forward only (validation) */
+    const float* head;              /* [B, A*(5+C), G, G] raw head tensor, in the memory format the producing conv wrote */
+    float* grad;                    /* d loss / d head, same shape AND strides; NULL = forward only (validation) */
     int32_t G;                      /* grid size */
     int32_t A;                      /* anchors of this scale (<= ODPL_MAX_ANCHORS) */
     float anchor_w[ODPL_MAX_ANCHORS];   /* scaled anchors, grid units: f32(double(aw)/double(img/G)), */
     float anchor_h[ODPL_MAX_ANCHORS];   /* the host table of losses.py:499-503 */
+    int64_t stride[4];              /* element strides (b, c, y, x) of head and grad as a dense tensor: NCHW-contiguous or
+                                     * channels-last (torch.channels_last); all zero = NCHW-contiguous.  Anything else is
+                                     * ODPL_EINVAL (the reference copies to [B,A,G,G,5+C] first, losses.py:517-522; here no
+                                     * copy is made for either format) */
 } odpl_yolo_scale_t;
 
 typedef struct {
@@ -68,24 +76,60 @@ typedef struct {
 } odpl_yolo_loss_desc_t;
 
 /* flags.  STATE_CLEAN: the caller promises that the last use of this workspace was a successful
- * odpl_yolo_region_loss call with the same B, A, G per scale (the call leaves its cell-state maps,
- * which sit first in the workspace, reset); the initial memset is then skipped. */
+ * odpl_yolo_region_loss[_forward] call with the same B, A, G and memory format per scale (the call leaves its cell-state
+ * maps, which sit first in the workspace, reset); the initial fill is then skipped.  A broken promise is detected where it
+ * would index out of bounds (status bit 1 of out_counts[.][4]) and never faults, but the losses of that call are garbage. */
 #define ODPL_YOLO_STATE_CLEAN 1
 
-/* Bytes of scratch `odpl_yolo_region_loss` needs for this descriptor (host-side arithmetic only). */
+/* Bytes of scratch `odpl_yolo_region_loss` needs for this descriptor (host-side arithmetic only).  Includes the compact
+ * gradient area when any scale has a `grad` pointer. */
 size_t odpl_yolo_region_loss_workspace_bytes(const odpl_yolo_loss_desc_t* desc);
 
 /*
  * Replaces MultiScaleRegionLoss_v4.forward (losses.py:583-634), MultiScaleRegionLoss_v3.forward
  * (744-795) and RegionLoss_v2.forward (830-905) INCLUDING their autograd backward:
  * target assignment (accuracy.py:305-380), the seven loss terms, and d loss/d head for a unit
- * upstream gradient, in one pass over the head tensors.
+ * upstream gradient, in one call (= odpl_yolo_region_loss_forward + _backward below).
  *   out7        [7]  loss, Localization, Size, Conf, Classification, Conf_obj, Conf_noobj
  *   out_scales  [nscales*7] the per-scale 7-tuples before accumulation (may be NULL)
  *   out_counts  [nscales*8] int32: nObj, nNoobj, guard1_tripped, guard2_tripped, status, 0,0,0 (may be NULL)
+ *               status bit 0: an index below -size (the reference raises IndexError), bit 1: dirty state map
  */
 int odpl_yolo_region_loss(const odpl_yolo_loss_desc_t* desc, void* workspace, size_t workspace_bytes,
                           float* out7, float* out_scales, int32_t* out_counts, void* stream);
+
+/*
+ * The same, split the way autograd calls it.  Given the assignment every loss term is local to a cell and all terms but
+ * the confidence BCE live on the <= nT obj cells (losses.py:557-564), so d loss/d head is STRUCTURED: one value per cell
+ * (its confidence logit), 4+C values on each obj cell, zeros elsewhere.  forward leaves it in that compact form in
+ * `compact` (odpl_yolo_region_loss_compact_bytes; NULL: no gradient wanted -- validation_step, step.py:43-50):
+ *     per scale: gconf f32 [cells] in the head's cell order, gobj f32 [nT, 5+C] (slot 4 unused), tcell int32 [nT] (-1: the
+ *     target owns no cell).
+ * backward expands it into scale[i].grad (the head's memory format), multiplied by *upstream (device scalar, NULL = 1):
+ * the dense tensor a generic producer's backward expects.  `workspace` only needs odpl_yolo_region_loss_workspace_bytes of
+ * the same descriptor with every grad NULL.  A 1x1-convolution producer skips backward altogether: odpl_head_conv_backward
+ * consumes the compact form (odpl_yolo_compact_view) and the dense tensor is never written.
+ */
+size_t odpl_yolo_region_loss_compact_bytes(const odpl_yolo_loss_desc_t* desc);
+int odpl_yolo_region_loss_forward(const odpl_yolo_loss_desc_t* desc, void* workspace, size_t workspace_bytes,
+                                  void* compact, size_t compact_bytes, float* out7, float* out_scales,
+                                  int32_t* out_counts, void* stream);
+int odpl_yolo_region_loss_backward(const odpl_yolo_loss_desc_t* desc, const void* compact, size_t compact_bytes,
+                                   const float* upstream, void* stream);
+
+/* A structured output gradient of a detection head [B, A*no, G, G] (HOST struct holding DEVICE pointers):
+ *   dense     f32 [B*A*G2]: gradient of channel a*no + dense_ch of every cell, in the layout's cell order
+ *             (planar: (b*A + a)*G2 + s; interleaved: (b*G2 + s)*A + a)
+ *   rows      f32 [n_rows, no]: gradient of the `no` channels of anchor a at one cell (slot dense_ch is ignored: it is in `dense`)
+ *   row_cell  int32 [n_rows]: that cell (same order as `dense`), or -1 = no row */
+typedef struct {
+    const float* dense;
+    const float* rows;
+    const int32_t* row_cell;
+    int32_t n_rows, B, G2, A, no, dense_ch, layout;
+} odpl_sparse_grad_t;
+/* the compact gradient of scale `scale` as left by odpl_yolo_region_loss_forward (host-side pointer arithmetic only) */
+int odpl_yolo_compact_view(const odpl_yolo_loss_desc_t* desc, const void* compact, int32_t scale, odpl_sparse_grad_t* out);
 
 /*
  * autograd glue: grad[i] *= *scale unless *scale == 1.0f (decided on the device, no host sync).
@@ -398,16 +442,16 @@ int odpl_bn_act_backward_strided(const void* x, const void* grad_y, int64_t gy_r
 #define ODPL_TUNE_RETINA_FILL_NT 2
 int odpl_tune_set(int32_t key, int32_t value);
 
-/* diagnostic: when non-NULL, every workgroup w of yolo_dense_kernel stores its start / end reading of the
+/* diagnostic: when non-NULL, every workgroup w of yolo_expand_kernel stores its start / end reading of the
  * constant 100 MHz counter into dev_u64[2w], dev_u64[2w+1] (buffer >= 2 * grid entries); NULL disables it. */
 int odpl_debug_set_stamp_buffer(void* dev_u64);
 
 /* ---- in-library kernel timing (bench.py roofline leg) ------------------------------------------
  * HIP events recorded on the launch stream immediately around the named kernel of every later call.
  * No counterpart in the reference (it has no benchmark); host_ms is a HOST buffer.               */
-#define ODPL_PROF_YOLO_DENSE 0
+#define ODPL_PROF_YOLO_EXPAND 0      /* yolo_expand_kernel: the dense gradient stream of the generic backward */
 #define ODPL_PROF_YOLO_ASSIGN 1
-#define ODPL_PROF_YOLO_OBJ 2
+#define ODPL_PROF_YOLO_LOSS 2        /* yolo_loss_kernel: confidence blocks + obj-cell blocks */
 #define ODPL_PROF_YOLO_FINALIZE 3
 #define ODPL_PROF_RETINA_ASSIGN 4
 #define ODPL_PROF_RETINA_MAIN 5

@@ -40,17 +40,29 @@ def _anchor_table(anchors, img_dim, grid):
     return [(ctypes.c_float(aw / stride).value, ctypes.c_float(ah / stride).value) for aw, ah in anchors]
 
 
+def _memory_format(h):
+    """-> (tensor to hand to the library, element strides (b, c, y, x)).  NCHW-contiguous and channels-last tensors are
+    consumed in place (the producing convolution's own format); anything else is copied to NCHW once."""
+    if h.is_contiguous():
+        return h, (0, 0, 0, 0)
+    if h.dim() == 4 and h.is_contiguous(memory_format=torch.channels_last):
+        return h, tuple(h.stride())
+    return h.contiguous(), (0, 0, 0, 0)
+
+
 class _RegionLossFn(torch.autograd.Function):
-    """loss (differentiable) + the six metric scalars; the gradient of `loss` w.r.t. every head was
-    written by the same launch sequence that produced the scalars."""
+    """loss (differentiable) + the six metric scalars.  forward leaves d loss / d head in the library's compact form
+    (one value per cell + 4+C values per obj cell); backward expands it into dense tensors in the heads' own memory
+    format, scaled by the upstream gradient on the device -- one launch, no host sync."""
 
     @staticmethod
     def forward(ctx, owner, target, scale_anchors, average, *heads):
         need_grad = any(ctx.needs_input_grad[4:])
-        heads_c = [h if h.is_contiguous() else h.contiguous() for h in heads]
-        grads = [torch.empty_like(h) for h in heads_c] if need_grad else [None] * len(heads_c)
-        out7, counts = owner._launch(heads_c, grads, target, scale_anchors, average)
-        ctx.grads = grads
+        pairs = [_memory_format(h) for h in heads]
+        d, keep = owner._describe([p[0] for p in pairs], [p[1] for p in pairs], target, scale_anchors, average)
+        out7, counts, compact = owner._forward(d, pairs[0][0].device, need_grad)
+        ctx.desc, ctx.keep, ctx.compact = d, keep, compact
+        ctx.like = [p[0] for p in pairs] if need_grad else None
         ctx.used = False
         loss = out7[0]
         metrics = out7[1:]
@@ -63,14 +75,15 @@ class _RegionLossFn(torch.autograd.Function):
             raise RuntimeError("the fused region loss frees its gradient buffers after the first backward "
                                "(call backward once per forward)")
         ctx.used = True
-        grads = ctx.grads
-        ctx.grads = None
-        g = g_loss.contiguous().float()
-        L = _lib.lib()
-        for gr in grads:
-            if gr is not None:
-                _lib.check(L.odpl_scale_inplace_if_not_one(_lib.ptr(gr), gr.numel(), _lib.ptr(g),
-                                                           _lib.current_stream(gr.device)), "odpl_scale_inplace_if_not_one")
+        d, compact, like = ctx.desc, ctx.compact, ctx.like
+        ctx.desc = ctx.compact = ctx.like = ctx.keep = None
+        grads = [torch.empty_like(h) if need else None for h, need in zip(like, ctx.needs_input_grad[4:])]    # preserves the strides
+        for i, g in enumerate(grads):
+            d.scale[i].grad = g.data_ptr() if g is not None else None
+        up = g_loss.contiguous().float()
+        dev = like[0].device
+        _lib.check(_lib.lib().odpl_yolo_region_loss_backward(ctypes.byref(d), _lib.ptr(compact), compact.numel(), _lib.ptr(up),
+                                                             _lib.current_stream(dev)), "odpl_yolo_region_loss_backward")
         return (None, None, None, None) + tuple(grads)
 
 
@@ -91,14 +104,12 @@ class _RegionLossBase(nn.Module):
         self._cls_name = _criterion_name(cls_criterion, _lib.CLS_MODES)
         self._coord_name = _criterion_name(coord_criterion, _lib.COORD_MODES)
         self._ws = None
-        self._ws_clean_key = None        # (device, shapes) for which the workspace's state maps are known clean
+        self._ws_clean_key = None        # (device, stream, shapes, formats) for which the workspace's state maps are known clean
         self.last_counts = None          # int32 [nscales, 8] on device: nObj, nNoobj, guard1, guard2, status
 
-    # -- one C-ABI call -------------------------------------------------------------------------
-    def _launch(self, heads, grads, target, scale_anchors, average):
+    # -- descriptor ---------------------------------------------------------------------------------
+    def _describe(self, heads, strides, target, scale_anchors, average):
         _lib.require_cuda(target, *heads)
-        L = _lib.lib()
-        dev = heads[0].device
         C = self.num_classes
         d = _lib.YoloLossDesc()
         d.B = heads[0].shape[0]
@@ -119,7 +130,7 @@ class _RegionLossBase(nn.Module):
         d.obj_scale = self.obj_scale
         d.noobj_scale = self.noobj_scale
         d.target = tgt.data_ptr() if d.nT else None
-        for i, (h, g, anc) in enumerate(zip(heads, grads, scale_anchors)):
+        for i, (h, st, anc) in enumerate(zip(heads, strides, scale_anchors)):
             A = len(anc)
             if h.dtype != torch.float32:
                 raise TypeError("head tensors must be fp32 (the reference computes the loss in fp32)")
@@ -129,28 +140,46 @@ class _RegionLossBase(nn.Module):
                 raise ValueError(f"at most {_lib.MAX_ANCHORS} anchors per scale")
             s = d.scale[i]
             s.head = h.data_ptr()
-            s.grad = g.data_ptr() if g is not None else None
+            s.grad = None
             s.G = h.shape[2]
             s.A = A
+            for k in range(4):
+                s.stride[k] = st[k]
             for a, (aw, ah) in enumerate(_anchor_table(anc, self.img_dim, s.G)):
                 s.anchor_w[a] = aw
                 s.anchor_h[a] = ah
-        need = L.odpl_yolo_region_loss_workspace_bytes(ctypes.byref(d))
+        return d, (tgt, heads)
+
+    # -- forward: one C-ABI call ----------------------------------------------------------------------
+    def _forward(self, d, dev, need_grad):
+        L = _lib.lib()
+        need = L.odpl_yolo_region_loss_workspace_bytes(ctypes.byref(d))          # every grad is NULL: workspace without the compact area
         if need == 0:
             raise OdplError("odpl_yolo_region_loss_workspace_bytes rejected the descriptor")
         if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
             self._ws = torch.empty(int(need * 1.25) + 4096, dtype=torch.uint8, device=dev)
             self._ws_clean_key = None
-        key = (dev, torch.cuda.current_stream(dev).cuda_stream, d.B, tuple((s.G, s.A) for s in d.scale[:d.nscales]))
-        d.flags = _lib.YOLO_STATE_CLEAN if self._ws_clean_key == key else 0
-        self._ws_clean_key = None        # stays None if the call below raises
+        key = (dev, torch.cuda.current_stream(dev).cuda_stream, d.B,
+               tuple((s.G, s.A, tuple(s.stride)) for s in d.scale[:d.nscales]))
+        # under stream capture the kernels are only RECORDED: the workspace is not cleaned by this call, and the graph must
+        # carry its own fill so that every replay starts from a clean map -- never claim STATE_CLEAN there, and leave the
+        # eager bookkeeping as it was
+        capturing = torch.cuda.is_current_stream_capturing()
+        d.flags = _lib.YOLO_STATE_CLEAN if (self._ws_clean_key == key and not capturing) else 0
+        if not capturing:
+            self._ws_clean_key = None    # stays None if the call below raises
+        compact = None
+        if need_grad:
+            compact = torch.empty(L.odpl_yolo_region_loss_compact_bytes(ctypes.byref(d)), dtype=torch.uint8, device=dev)
         out7 = torch.empty(7, dtype=torch.float32, device=dev)
         counts = torch.empty(d.nscales, 8, dtype=torch.int32, device=dev)
-        _lib.check(L.odpl_yolo_region_loss(ctypes.byref(d), _lib.ptr(self._ws), self._ws.numel(), _lib.ptr(out7),
-                                           None, _lib.ptr(counts), _lib.current_stream(dev)), "odpl_yolo_region_loss")
-        self._ws_clean_key = key         # the dense kernel reset every cell it read
+        _lib.check(L.odpl_yolo_region_loss_forward(ctypes.byref(d), _lib.ptr(self._ws), self._ws.numel(), _lib.ptr(compact),
+                                                   0 if compact is None else compact.numel(), _lib.ptr(out7), None, _lib.ptr(counts),
+                                                   _lib.current_stream(dev)), "odpl_yolo_region_loss_forward")
+        if not capturing:
+            self._ws_clean_key = key     # the conf blocks reset every cell they read
         self.last_counts = counts
-        return out7, counts
+        return out7, counts, compact
 
     def _run(self, heads, target, scale_anchors, average):
         # half-precision heads (a bf16 / fp16 autocast network): the reference computes this loss in fp32, so widen once;

@@ -6,7 +6,8 @@ from ctypes import POINTER, c_float, c_int32, c_size_t, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libodpl_hip.so")
 
-ABI_VERSION = 2            # include/odpl_hip.h: ODPL_ABI_VERSION
+ABI_VERSION = 3            # include/odpl_hip.h: ODPL_ABI_VERSION
+LAYOUT_PLANAR, LAYOUT_INTERLEAVED = 0, 1
 MAX_SCALES = 4
 MAX_ANCHORS = 8
 COORD_MODES = {"mse_loss": 0, "smooth_l1_loss": 1}
@@ -20,7 +21,13 @@ class OdplError(RuntimeError):
 
 class YoloScale(ctypes.Structure):
     _fields_ = [("head", c_void_p), ("grad", c_void_p), ("G", c_int32), ("A", c_int32),
-                ("anchor_w", c_float * MAX_ANCHORS), ("anchor_h", c_float * MAX_ANCHORS)]
+                ("anchor_w", c_float * MAX_ANCHORS), ("anchor_h", c_float * MAX_ANCHORS), ("stride", ctypes.c_int64 * 4)]
+
+
+class SparseGrad(ctypes.Structure):
+    """odpl_sparse_grad_t: a structured head gradient (host struct, device pointers)."""
+    _fields_ = [("dense", c_void_p), ("rows", c_void_p), ("row_cell", c_void_p),
+                ("n_rows", c_int32), ("B", c_int32), ("G2", c_int32), ("A", c_int32), ("no", c_int32), ("dense_ch", c_int32), ("layout", c_int32)]
 
 
 class YoloLossDesc(ctypes.Structure):
@@ -87,6 +94,10 @@ SIGNATURES = {
     "odpl_abi_version": (c_int32, []),
     "odpl_yolo_region_loss_workspace_bytes": (c_size_t, [POINTER(YoloLossDesc)]),
     "odpl_yolo_region_loss": (c_int32, [POINTER(YoloLossDesc), c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "odpl_yolo_region_loss_compact_bytes": (c_size_t, [POINTER(YoloLossDesc)]),
+    "odpl_yolo_region_loss_forward": (c_int32, [POINTER(YoloLossDesc), c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "odpl_yolo_region_loss_backward": (c_int32, [POINTER(YoloLossDesc), c_void_p, c_size_t, c_void_p, c_void_p]),
+    "odpl_yolo_compact_view": (c_int32, [POINTER(YoloLossDesc), c_void_p, c_int32, POINTER(SparseGrad)]),
     "odpl_scale_inplace_if_not_one": (c_int32, [c_void_p, c_size_t, c_void_p, c_void_p]),
     "odpl_retina_loss_workspace_bytes": (c_size_t, [POINTER(RetinaLossDesc)]),
     "odpl_retina_loss": (c_int32, [POINTER(RetinaLossDesc), c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
@@ -196,7 +207,7 @@ def tune_set(name, value):
     check(lib().odpl_tune_set(TUNE_KEYS[name], int(value)), "odpl_tune_set")
 
 
-PROF_IDS = {"yolo_dense": 0, "yolo_assign": 1, "yolo_obj": 2, "yolo_finalize": 3, "retina_assign": 4, "retina_main": 5,
+PROF_IDS = {"yolo_expand": 0, "yolo_assign": 1, "yolo_loss": 2, "yolo_finalize": 3, "retina_assign": 4, "retina_main": 5,
             "yolo_nms_prep": 6, "yolo_nms_image": 7, "greedy_nms_prep": 8, "greedy_nms_image": 9, "yolo_decode": 10, "yolov5_dense": 11}
 
 

@@ -1,21 +1,28 @@
 // YOLO v2/v3/v4 region loss for MI355X (gfx950): target assignment + the seven loss terms +
 // d loss / d head, replacing losses.py:475-905 and accuracy.py:305-380 of the reference.
 //
-// Data layout in HBM.  The head tensor stays exactly as the 1x1 conv wrote it: [B, A*(5+C), G, G]
-// = R rows of G*G contiguous floats, row q = (b*A + a)*(5+C) + c.  The reference's
-// permute(0,1,3,4,2).contiguous() copy (losses.py:517-522) is never made.
+// Data layout in HBM.  The head tensor is consumed exactly as the producing convolution wrote it, in either memory
+// format of a [B, A*(5+C), G, G] tensor, and the gradient goes back in the same format:
+//   planar      (NCHW)           element (b,a,c,s) at ((b*A + a)*(5+C) + c)*G2 + s      cell index (b*A + a)*G2 + s
+//   interleaved (channels-last)  element (b,a,c,s) at ((b*G2 + s)*A + a)*(5+C) + c      cell index (b*G2 + s)*A + a
+// The reference's view().permute(0,1,3,4,2).contiguous() copy (losses.py:517-522) is never made.
 //
-// What the loss touches.  Given the assignment, every term is local to a cell, and all terms but the
-// confidence BCE live on the nObj <= nT "obj" cells only (losses.py:557-564).  So per call:
-//   assign   (1 workgroup / scale)  targets -> int32 cell-state map {-1 noobj, 0 ignored, t+1 obj},
-//                                   per-winner records (tx,ty,tw,th, class bitset, raster rank), counts
-//   dense    (one launch, all scales) "conf" blocks read the confidence row of every (b,a) plane + the
-//                                   state map and write its gradient; "fill" blocks stream zeros into the
-//                                   other 4+C rows of the gradient.  HBM-write bound: this is the kernel
-//                                   the roofline figure is quoted on.
-//   obj      (1 workgroup / target) gathers the 5+C logits of each obj cell (stride G*G), writes their
-//                                   gradients over the zeros, partial sums for x,y,w,h,cls and "Size"
-//   finalize (1 workgroup)          fixed-order reduction -> the reference's 7 scalars per scale and total
+// What the loss touches.  Given the assignment, every term is local to a cell, and all terms but the confidence BCE live
+// on the nObj <= nT "obj" cells only (losses.py:557-564).  The gradient is therefore STRUCTURED: one dense value per cell
+// (its confidence logit) + 4+C values on each obj cell + zeros.  forward produces it in that compact form:
+//   assign   (1 workgroup / scale)   targets -> int32 cell-state map {-1 noobj, 0 ignored, t+1 obj owner}, per-winner
+//                                    records (tx,ty,tw,th, class bitset, raster rank), exact integer nObj / nNoobj
+//   loss     (one launch)            "conf" blocks: confidence logit + state of every cell -> BCE(obj / noobj x100) partial
+//                                    sums, gconf[cell] = d loss/d logit, state reset; "obj" blocks (1 / target / scale):
+//                                    the 5+C logits of an obj cell -> x,y,w,h,cls terms, gobj[t][5+C], "Size" metric
+//   finalize (1 workgroup)           fixed-order reduction -> the reference's 7 scalars per scale and total
+// backward consumes the compact gradient:
+//   expand   (one launch)            the dense tensor autograd hands to a generic producer: zeros streamed with 16-B
+//                                    non-temporal stores, gconf in the confidence slots, gobj on the obj cells, all scaled by
+//                                    the upstream scalar read on the device.  HBM-write bound; the kernel the generic path's
+//                                    roofline figure is quoted on.
+//   (or odpl_headgrad.hip)           when the producer is a 1x1 convolution the dense tensor is never materialised: the
+//                                    convolution's backward is computed from the compact form directly.
 // No atomics on floats anywhere: results are bitwise reproducible run to run.
 #include <hip/hip_bf16.h>
 #include "odpl_common.hpp"
@@ -28,36 +35,40 @@ using namespace odpl;
 
 constexpr int kAssignThreads = 256;
 constexpr int kAssignRankCap = 4096;    // winners' cells staged in LDS for the raster-rank pass
-constexpr int kDenseThreads = 256;
-constexpr int kObjThreads = 128;
+constexpr int kConfThreads = 256;
+constexpr int kObjThreads = 128;        // obj blocks use the first 128 threads of a loss-kernel workgroup
+constexpr int kExpandThreads = 256;
 
 // tunables (odpl_tune_set): defaults chosen on MI355X, see DESIGN.md "Kernels"
-int g_fill_f4_per_block = 2048;         // float4 stores per fill block (x16 B)
+int g_fill_f4_per_block = 2048;         // float4 stores per expand block (x16 B)
 unsigned long long* g_stamp = nullptr;
-int g_fill_nt = 1;                      // 1: non-temporal stores for the zero fill (in-step: 11.4 vs 12.1 us)
-
+int g_fill_nt = 1;                      // 1: non-temporal stores for the zero stream (in-step: 11.4 vs 12.1 us)
 
 struct Scale {
     const float* head;
-    float* grad;
-    int* state;          // [B*A*G2]
+    float* grad;         // expand destination
+    int* state;          // [cells]  (persistent workspace; kept at -1 between calls: the conf blocks reset what they read)
     float* rec;          // [nT*4]   tx,ty,tw,th of target t (meaningful for winners)
-    int* tcell;          // [nT]     linear cell (b,a,j,i) if target t owns its cell, else -1
+    int* tcell;          // [nT]     linear cell (layout order) if target t owns its cell, else -1
     int* trank;          // [nT]     raster rank of the cell among obj cells (winners)
     unsigned* bits;      // [nT*W]   class bitset of the winner's cell (multi-hot on shared cells)
     int* counts;         // [8]
     float* conf_part;    // [conf_nblk*2]  (sum obj BCE, sum noobj BCE)
     float* obj_part;     // [nT*8]   lx, ly, lw, lh, lcls, size, -, -
-    int G, G2, A;
+    float* gconf;        // [cells]  compact gradient of the confidence logits (NULL: forward only)
+    float* gobj;         // [nT*CH]  compact gradient of each winner's cell (slot 4 unused)
+    int G, G2, A, layout, cells;
     int conf_blk0, conf_blk_per_row, conf_nblk, conf_vec;
-    int fill_blk0, fill_nblk, rows_per_fill_blk;
+    int obj_blk0;
+    int exp_blk0, exp_nblk, rows_per_exp_blk;
+    unsigned long long inv_ch;           // ceil(2^40 / CH): e / CH for e < 2^31 by one 64-bit multiply
     float aw[ODPL_MAX_ANCHORS], ah[ODPL_MAX_ANCHORS];
 };
-// state map encoding: kept at -1 ("clean") between calls: the dense kernel resets every cell it reads
 
 struct Params {
     Scale s[ODPL_MAX_SCALES];
     const float* target;
+    const float* upstream;       // device scalar d L / d loss, or NULL (= 1)
     int nscales, B, C, CH, nT, W;
     int coord_sl1, cls_mode, average, fill_nt;
     float ignore_thres, obj_scale, noobj_scale, inv_S;
@@ -66,6 +77,10 @@ struct Params {
     int* out_counts;
     unsigned long long* stamp;   // diagnostic only (odpl_debug_set_stamp_buffer): [2*wg] start, [2*wg+1] end, 100 MHz ticks
 };
+
+__device__ __forceinline__ int cell_index(const Scale& S, int b, int a, int j, int i) {
+    return S.layout == ODPL_LAYOUT_PLANAR ? ((b * S.A + a) * S.G + j) * S.G + i : ((b * S.G + j) * S.G + i) * S.A + a;
+}
 
 __global__ __launch_bounds__(kAssignThreads) void yolo_assign_kernel(const Params P) {
     const Scale& S = P.s[blockIdx.x];
@@ -97,6 +112,7 @@ __global__ __launch_bounds__(kAssignThreads) void yolo_assign_kernel(const Param
     __syncthreads();
     flags = s_flags;
     const int g1 = flags & 1 ? 1 : 0, g2 = (flags & 3) ? 1 : 0, st = flags & 4 ? 1 : 0;
+    __syncthreads();                                                      // everyone has read s_flags before bit 3 may be set below
 
     int left = 0, became = 0;
     for (int t = tid; t < nT; t += kAssignThreads) {
@@ -106,13 +122,13 @@ __global__ __launch_bounds__(kAssignThreads) void yolo_assign_kernel(const Param
         const bool ok = wrap_idx(b, B) & wrap_idx(gj, G) & wrap_idx(gi, G);
         if (!ok) continue;
         if (!g1) {                                                        // accuracy.py:344-346
-            const int cell = (((int)b * A + d.best) * G + (int)gj) * G + (int)gi;
+            const int cell = cell_index(S, (int)b, d.best, (int)gj, (int)gi);
             const int old = atomicMax(&S.state[cell], t + 1);
             left += (old == -1); became += (old < 1);
         }
         if (upper_ok) {                                                   // accuracy.py:349-358
             for (int a = 0; a < A; ++a) if ((d.over >> a) & 1u) {
-                const int cell = (((int)b * A + a) * G + (int)gj) * G + (int)gi;
+                const int cell = cell_index(S, (int)b, a, (int)gj, (int)gi);
                 const int old = atomicMax(&S.state[cell], 0);
                 left += (old == -1);
             }
@@ -124,7 +140,7 @@ __global__ __launch_bounds__(kAssignThreads) void yolo_assign_kernel(const Param
             const TDec d = dec(t);
             long long b = d.b, gj = d.gj, gi = d.gi, lab = d.lab;
             if (!(wrap_idx(b, B) & wrap_idx(gj, G) & wrap_idx(gi, G))) continue;
-            const int cell = (((int)b * A + d.best) * G + (int)gj) * G + (int)gi;
+            const int cell = cell_index(S, (int)b, d.best, (int)gj, (int)gi);
             const int w = __hip_atomic_load(&S.state[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1;
             if ((unsigned)w >= (unsigned)nT) {                            // impossible on a clean map (the owner is a row of THIS call):
                 atomicOr(&s_flags, 8);                                    // the STATE_CLEAN promise was broken -- flag it, index nothing
@@ -146,14 +162,21 @@ __global__ __launch_bounds__(kAssignThreads) void yolo_assign_kernel(const Param
         }
     }
     __syncthreads();
-    // raster rank of every obj cell (order of pred_boxes[..., 2:4][obj_mask], losses.py:568)
+    // raster rank of every obj cell (order of pred_boxes[..., 2:4][obj_mask], losses.py:568: (b, a, j, i) ascending); the
+    // interleaved cell index orders (b, j, i, a), so ranks compare the planar key there
+    auto raster_key = [&](int c) {
+        if (S.layout == ODPL_LAYOUT_PLANAR) return c;
+        const int a = c % A, bs = c / A, b = bs / S.G2, s = bs - b * S.G2;
+        return (b * A + a) * S.G2 + s;
+    };
     for (int t = tid; t < nT; t += kAssignThreads) {
         const int c = t < kAssignRankCap ? s_cell[t] : S.tcell[t];
         if (c < 0) continue;
+        const int kc = raster_key(c);
         int r = 0;
         const int nl = nT < kAssignRankCap ? nT : kAssignRankCap;
-        for (int u = 0; u < nl; ++u) { const int cu = s_cell[u]; r += (cu >= 0) & (cu < c); }
-        for (int u = kAssignRankCap; u < nT; ++u) { const int cu = S.tcell[u]; r += (cu >= 0) & (cu < c); }
+        for (int u = 0; u < nl; ++u) { const int cu = s_cell[u]; r += (cu >= 0) && (raster_key(cu) < kc); }
+        for (int u = kAssignRankCap; u < nT; ++u) { const int cu = S.tcell[u]; r += (cu >= 0) && (raster_key(cu) < kc); }
         S.trank[t] = r;
     }
     // counts
@@ -173,7 +196,7 @@ __global__ __launch_bounds__(kAssignThreads) void yolo_assign_kernel(const Param
 }
 
 // ------------------------------------------------------------------------------------------------
-// dense kernel: confidence rows + zero fill of the rest of the gradient
+// loss kernel: confidence term of every cell ("conf" blocks) + the other terms on the obj cells ("obj" blocks)
 
 __device__ __forceinline__ void conf_cell(float z, int st, float w_obj, float w_noobj, float& g, float& lo, float& ln) {
     const float p = sigmoidf_(z);
@@ -195,31 +218,18 @@ __device__ __forceinline__ void stamp_end(const Params& P) {
     if (P.stamp) { __syncthreads(); if (threadIdx.x == 0) { __builtin_amdgcn_s_waitcnt(0); P.stamp[2 * blockIdx.x + 1] = (unsigned long long)wall_clock64(); } }
 }
 
-__global__ __launch_bounds__(kDenseThreads) void yolo_dense_kernel(const Params P) {
-    __shared__ float sh[2 * (kDenseThreads / 64)];
-    const int bid = blockIdx.x, tid = threadIdx.x;
-    stamp_begin(P);
-    int si = 0;
-    bool is_conf = false;
-    for (int i = 0; i < P.nscales; ++i) {
-        const Scale& T = P.s[i];
-        if (bid >= T.conf_blk0 && bid < T.conf_blk0 + T.conf_nblk) { si = i; is_conf = true; }
-        if (bid >= T.fill_blk0 && bid < T.fill_blk0 + T.fill_nblk) { si = i; is_conf = false; }
-    }
-    const Scale& S = P.s[si];
-    const int G2 = S.G2, CH = P.CH;
-    if (is_conf) {
-        const int local = bid - S.conf_blk0;
+__device__ __forceinline__ void conf_block(const Params& P, const Scale& S, int local, float* sh) {
+    const int tid = threadIdx.x, G2 = S.G2, CH = P.CH;
+    const float w_obj = P.obj_scale * P.inv_S / (float)S.counts[0];
+    const float w_noobj = P.noobj_scale * P.inv_S / (float)S.counts[1];
+    float acc[2] = {0.f, 0.f};
+    if (S.layout == ODPL_LAYOUT_PLANAR) {
         const int plane = local / S.conf_blk_per_row, part = local - plane * S.conf_blk_per_row;
-        const size_t rowoff = ((size_t)plane * CH + 4) * G2;
-        const float* __restrict__ z = S.head + rowoff;
-        float* __restrict__ g = S.grad ? S.grad + rowoff : nullptr;
+        const float* __restrict__ z = S.head + ((size_t)plane * CH + 4) * G2;
+        float* __restrict__ g = S.gconf ? S.gconf + (size_t)plane * G2 : nullptr;
         int* __restrict__ st = S.state + (size_t)plane * G2;
-        const float w_obj = P.obj_scale * P.inv_S / (float)S.counts[0];
-        const float w_noobj = P.noobj_scale * P.inv_S / (float)S.counts[1];
-        float acc[2] = {0.f, 0.f};
         if (S.conf_vec) {
-            const int i4 = part * kDenseThreads + tid;
+            const int i4 = part * kConfThreads + tid;
             if (i4 < G2 / 4) {
                 const float4 zv = reinterpret_cast<const float4*>(z)[i4];
                 const int4 sv = reinterpret_cast<const int4*>(st)[i4];
@@ -232,7 +242,7 @@ __global__ __launch_bounds__(kDenseThreads) void yolo_dense_kernel(const Params 
                 reinterpret_cast<int4*>(st)[i4] = make_int4(-1, -1, -1, -1);      // leave the map clean for the next call
             }
         } else {
-            const int i = part * kDenseThreads + tid;
+            const int i = part * kConfThreads + tid;
             if (i < G2) {
                 float gv;
                 conf_cell(z[i], st[i], w_obj, w_noobj, gv, acc[0], acc[1]);
@@ -240,40 +250,38 @@ __global__ __launch_bounds__(kDenseThreads) void yolo_dense_kernel(const Params 
                 st[i] = -1;
             }
         }
-        block_sum<2>(acc, sh);
-        if (tid == 0) { S.conf_part[local * 2] = acc[0]; S.conf_part[local * 2 + 1] = acc[1]; }
     } else {
-        // rows [r0, r1) of this scale, skipping the confidence row (c == 4) of every plane
-        const int R = P.B * S.A * CH;
-        int r0 = (bid - S.fill_blk0) * S.rows_per_fill_blk;
-        int r1 = r0 + S.rows_per_fill_blk; if (r1 > R) r1 = R;
-        int cur = r0;
-        while (cur < r1) {
-            int c = cur % CH;
-            int next_conf = cur + ((4 - c) % CH + CH) % CH;     // first row >= cur with c == 4
-            int seg_end = next_conf < r1 ? next_conf : r1;
-            if (seg_end > cur) { if (P.fill_nt) fill_zero<true, kDenseThreads>(S.grad, (size_t)cur * G2, (size_t)seg_end * G2); else fill_zero<false, kDenseThreads>(S.grad, (size_t)cur * G2, (size_t)seg_end * G2); }
-            cur = seg_end + (next_conf < r1 ? 1 : 0);
+        // interleaved: thread = cell; the logit sits CH floats from its neighbour's (one memory request per cell), the
+        // state map and gconf are compact and coalesced
+        const int c = local * kConfThreads + tid;
+        if (c < S.cells) {
+            float gv;
+            conf_cell(S.head[(size_t)c * CH + 4], S.state[c], w_obj, w_noobj, gv, acc[0], acc[1]);
+            if (S.gconf) S.gconf[c] = gv;
+            S.state[c] = -1;
         }
     }
-    stamp_end(P);
+    block_sum<2>(acc, sh);
+    if (tid == 0) { S.conf_part[local * 2] = acc[0]; S.conf_part[local * 2 + 1] = acc[1]; }
 }
 
-// ------------------------------------------------------------------------------------------------
-// obj kernel: one workgroup per target that owns an obj cell
-
-__global__ __launch_bounds__(kObjThreads) void yolo_obj_kernel(const Params P) {
-    __shared__ float sh[8 * (kObjThreads / 64)];
-    __shared__ float sh_bc[2];
-    const Scale& S = P.s[blockIdx.y];
-    const int t = blockIdx.x, tid = threadIdx.x, CH = P.CH, C = P.C, G2 = S.G2;
+__device__ __forceinline__ void obj_block(const Params& P, const Scale& S, int t, float* sh, float* sh_bc) {
+    // one workgroup per target that may own an obj cell; the first kObjThreads threads work, all join the barriers
+    const int tid = threadIdx.x, CH = P.CH, C = P.C, G2 = S.G2;
+    const bool act = tid < kObjThreads;
     float* part = S.obj_part + (size_t)t * 8;
     const int cell = S.tcell[t];
-    if (cell < 0 || cell >= P.B * S.A * G2) { if (tid < 8) part[tid] = 0.f; return; }
-    const int plane = cell / G2, s = cell - plane * G2, a = plane % S.A;
-    const size_t base = (size_t)plane * CH * G2 + s;
+    if (cell < 0 || cell >= S.cells) { if (tid < 8) part[tid] = 0.f; return; }       // uniform per block
+    size_t base, cs;
+    int a;
+    if (S.layout == ODPL_LAYOUT_PLANAR) {
+        const int plane = cell / G2, s = cell - plane * G2;
+        a = plane % S.A; base = (size_t)plane * CH * G2 + s; cs = (size_t)G2;
+    } else {
+        a = cell % S.A; base = (size_t)cell * CH; cs = 1;
+    }
     const float* __restrict__ zp = S.head + base;
-    float* __restrict__ gp = S.grad ? S.grad + base : nullptr;
+    float* __restrict__ go = S.gobj ? S.gobj + (size_t)t * CH : nullptr;
     const int nObj = S.counts[0];
     const float w = P.inv_S / (float)nObj;                 // mean over nObj, then the 1/len(output)
     const float* r = S.rec + (size_t)t * 4;
@@ -285,8 +293,8 @@ __global__ __launch_bounds__(kObjThreads) void yolo_obj_kernel(const Params P) {
     float lse = 0.f, tsum = 0.f;
     if (P.cls_mode == ODPL_CLS_CE) {
         float m = -INFINITY, ts = 0.f;
-        for (int k = tid; k < C; k += kObjThreads) {
-            m = fmaxf(m, sigmoidf_(zp[(size_t)(5 + k) * G2]));
+        if (act) for (int k = tid; k < C; k += kObjThreads) {
+            m = fmaxf(m, sigmoidf_(zp[(size_t)(5 + k) * cs]));
             ts += (float)((bits[k >> 5] >> (k & 31)) & 1u);
         }
         m = wave_max(m);
@@ -295,15 +303,15 @@ __global__ __launch_bounds__(kObjThreads) void yolo_obj_kernel(const Params P) {
         m = sh[0]; for (int i = 1; i < kObjThreads / 64; ++i) m = fmaxf(m, sh[i]);
         __syncthreads();
         float e[2] = {0.f, ts};
-        for (int k = tid; k < C; k += kObjThreads) e[0] += expf(sigmoidf_(zp[(size_t)(5 + k) * G2]) - m);
+        if (act) for (int k = tid; k < C; k += kObjThreads) e[0] += expf(sigmoidf_(zp[(size_t)(5 + k) * cs]) - m);
         block_sum<2>(e, sh);
         if (tid == 0) { sh_bc[0] = m + logf(e[0]); sh_bc[1] = e[1]; }
         __syncthreads();
         lse = sh_bc[0]; tsum = sh_bc[1];
     }
-    for (int c = tid; c < CH; c += kObjThreads) {
-        if (c == 4) continue;                              // confidence: dense kernel
-        const float z = zp[(size_t)c * G2];
+    if (act) for (int c = tid; c < CH; c += kObjThreads) {
+        if (c == 4) { if (go) go[4] = 0.f; continue; }     // confidence: conf blocks (gconf)
+        const float z = zp[(size_t)c * cs];
         float g;
         if (c < 2) {                                       // losses.py:557-558
             const float p = sigmoidf_(z), d = p - r[c];
@@ -326,13 +334,13 @@ __global__ __launch_bounds__(kObjThreads) void yolo_obj_kernel(const Params P) {
                 g = bce_grad_logit(p, tk, w / (float)C);
             }
         }
-        if (gp) gp[(size_t)c * G2] = g;
+        if (go) go[c] = g;
     }
     // "Size" metric (losses.py:568-573): obj cells in raster order vs target COLUMNS 3:5 of row `rank`
     if (tid == 0) {
         const int k = nObj < P.nT ? nObj : P.nT, rk = S.trank[t];
         if (rk < k) {
-            const float pw = expf(zp[(size_t)2 * G2]) * S.aw[a], ph = expf(zp[(size_t)3 * G2]) * S.ah[a];
+            const float pw = expf(zp[(size_t)2 * cs]) * S.aw[a], ph = expf(zp[(size_t)3 * cs]) * S.ah[a];
             const float* yr = P.target + (size_t)rk * 6;
             const float d0 = sqrtf(fabsf(pw) + 1e-32f) - sqrtf(fabsf(yr[3]) + 1e-32f);
             const float d1 = sqrtf(fabsf(ph) + 1e-32f) - sqrtf(fabsf(yr[4]) + 1e-32f);
@@ -344,6 +352,22 @@ __global__ __launch_bounds__(kObjThreads) void yolo_obj_kernel(const Params P) {
         for (int i = 0; i < 6; ++i) part[i] = acc[i];
         part[6] = part[7] = 0.f;
     }
+}
+
+__global__ __launch_bounds__(kConfThreads) void yolo_loss_kernel(const Params P) {
+    __shared__ float sh[8 * (kConfThreads / 64)];
+    __shared__ float sh_bc[2];
+    const int bid = blockIdx.x;
+    int si = 0;
+    bool is_conf = true;
+    for (int i = 0; i < P.nscales; ++i) {
+        const Scale& T = P.s[i];
+        if (bid >= T.conf_blk0 && bid < T.conf_blk0 + T.conf_nblk) { si = i; is_conf = true; }
+        if (bid >= T.obj_blk0 && bid < T.obj_blk0 + P.nT) { si = i; is_conf = false; }
+    }
+    const Scale& S = P.s[si];
+    if (is_conf) conf_block(P, S, bid - S.conf_blk0, sh);
+    else obj_block(P, S, bid - S.obj_blk0, sh, sh_bc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -398,6 +422,103 @@ __global__ __launch_bounds__(64 * ODPL_MAX_SCALES) void yolo_finalize_kernel(con
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// expand: compact gradient -> the dense d loss / d head tensor in the head's own memory format
+
+template <bool NT>
+__device__ __forceinline__ void st4(v4f* p, const v4f& v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; }
+
+template <bool NT>
+__device__ __forceinline__ void expand_block(const Params& P, const Scale& S, int local) {
+    const int tid = threadIdx.x, G2 = S.G2, CH = P.CH;
+    const float f = P.upstream ? *P.upstream : 1.0f;
+    if (S.layout == ODPL_LAYOUT_PLANAR) {
+        // rows [r0, r1) of this scale; row q = plane*CH + c holds G2 floats: zeros, or gconf for c == 4
+        const int R = P.B * S.A * CH;
+        const int r0 = local * S.rows_per_exp_blk;
+        int r1 = r0 + S.rows_per_exp_blk; if (r1 > R) r1 = R;
+        int cur = r0;
+        while (cur < r1) {
+            const int c = cur % CH;
+            const int next_conf = cur + ((4 - c) % CH + CH) % CH;     // first row >= cur with c == 4
+            const int seg_end = next_conf < r1 ? next_conf : r1;
+            if (seg_end > cur) fill_zero<NT, kExpandThreads>(S.grad, (size_t)cur * G2, (size_t)seg_end * G2);
+            if (next_conf < r1) {
+                const float* __restrict__ src = S.gconf + (size_t)(next_conf / CH) * G2;
+                float* __restrict__ dst = S.grad + (size_t)next_conf * G2;
+                if (S.conf_vec) {
+                    for (int i4 = tid; i4 < G2 / 4; i4 += kExpandThreads) {
+                        float4 v = reinterpret_cast<const float4*>(src)[i4];
+                        v.x *= f; v.y *= f; v.z *= f; v.w *= f;
+                        reinterpret_cast<float4*>(dst)[i4] = v;
+                    }
+                } else {
+                    for (int i = tid; i < G2; i += kExpandThreads) dst[i] = src[i] * f;
+                }
+            }
+            cur = seg_end + (next_conf < r1 ? 1 : 0);
+        }
+        if (P.nT == 0) return;
+        __syncthreads();                                              // the block's own stores are complete: patch the obj cells
+        const int p_lo = r0 / CH, p_hi = (r1 - 1) / CH;               // planes this block touches
+        for (int t = tid; t < P.nT; t += kExpandThreads) {
+            const int cell = S.tcell[t];
+            if (cell < 0 || cell >= S.cells) continue;
+            const int plane = cell / G2, s = cell - plane * G2;
+            if (plane < p_lo || plane > p_hi) continue;
+            const float* go = S.gobj + (size_t)t * CH;
+            const int q0 = plane * CH;
+            const int c0 = r0 > q0 ? r0 - q0 : 0, c1 = (r1 - q0) < CH ? (r1 - q0) : CH;
+            for (int c = c0; c < c1; ++c) if (c != 4) S.grad[(size_t)(q0 + c) * G2 + s] = go[c] * f;
+        }
+    } else {
+        // interleaved: a linear chunk of the [cells*CH] array; element e = cell*CH + c, confidence slots at c == 4
+        const size_t total = (size_t)S.cells * CH, totalq = total / 4;
+        const size_t chunk = (size_t)S.rows_per_exp_blk;              // float4 per block
+        const size_t q0 = (size_t)local * chunk;
+        const bool last = q0 + chunk >= totalq;
+        const size_t q1 = last ? totalq : q0 + chunk;
+        const size_t e0 = q0 * 4, e1 = last ? total : q1 * 4;         // the last chunk also owns the < 4 tail elements
+        v4f* g4 = reinterpret_cast<v4f*>(S.grad);
+        for (size_t q = q0 + tid; q < q1; q += kExpandThreads) {
+            const unsigned e = (unsigned)(q * 4);
+            const unsigned c = (unsigned)(((unsigned long long)e * S.inv_ch) >> 40);     // cell of the quad's first element
+            const unsigned r = e - c * (unsigned)CH;                                      // its channel
+            v4f o = {0.f, 0.f, 0.f, 0.f};
+            if (r >= 1u && r <= 4u) o[4 - r] = S.gconf[c] * f;        // the quad holds cell c's confidence slot (a quad that spills
+                                                                      // into cell c+1 reaches at most its channel 2)
+            st4<NT>(g4 + q, o);
+        }
+        if (last) for (size_t e = totalq * 4 + tid; e < total; e += kExpandThreads) {
+            const size_t c = e / CH;
+            S.grad[e] = (e - c * CH == 4) ? S.gconf[c] * f : 0.f;
+        }
+        if (P.nT == 0) return;
+        __syncthreads();
+        for (int t = tid; t < P.nT; t += kExpandThreads) {
+            const int cell = S.tcell[t];
+            if (cell < 0 || cell >= S.cells) continue;
+            const size_t b0 = (size_t)cell * CH;
+            if (b0 + CH <= e0 || b0 >= e1) continue;
+            const float* go = S.gobj + (size_t)t * CH;
+            for (int c = 0; c < CH; ++c) {
+                const size_t e = b0 + c;
+                if (c != 4 && e >= e0 && e < e1) S.grad[e] = go[c] * f;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kExpandThreads) void yolo_expand_kernel(const Params P) {
+    const int bid = blockIdx.x;
+    stamp_begin(P);
+    int si = 0;
+    for (int i = 0; i < P.nscales; ++i) if (bid >= P.s[i].exp_blk0 && bid < P.s[i].exp_blk0 + P.s[i].exp_nblk) si = i;
+    const Scale& S = P.s[si];
+    if (P.fill_nt) expand_block<true>(P, S, bid - S.exp_blk0); else expand_block<false>(P, S, bid - S.exp_blk0);
+    stamp_end(P);
+}
+
 __global__ void scale_if_not_one_kernel(float* __restrict__ g, size_t n, const float* __restrict__ s) {
     const float f = *s;
     if (f == 1.0f) return;
@@ -420,51 +541,171 @@ __global__ void scale_if_not_one_bf16_kernel(__hip_bfloat16* __restrict__ g, siz
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct Plan {
-    size_t state_off[ODPL_MAX_SCALES], rec_off[ODPL_MAX_SCALES], tcell_off[ODPL_MAX_SCALES],
-        trank_off[ODPL_MAX_SCALES], bits_off[ODPL_MAX_SCALES], counts_off[ODPL_MAX_SCALES],
-        confp_off[ODPL_MAX_SCALES], objp_off[ODPL_MAX_SCALES];
-    size_t state_bytes_total, total;
+    // persistent + per-call scratch workspace
+    size_t state_off[ODPL_MAX_SCALES], rec_off[ODPL_MAX_SCALES], trank_off[ODPL_MAX_SCALES], bits_off[ODPL_MAX_SCALES],
+        counts_off[ODPL_MAX_SCALES], confp_off[ODPL_MAX_SCALES], objp_off[ODPL_MAX_SCALES], tcell_ws_off[ODPL_MAX_SCALES];
+    size_t state_bytes_total, ws_total;
+    // compact gradient buffer (survives until backward)
+    size_t gconf_off[ODPL_MAX_SCALES], gobj_off[ODPL_MAX_SCALES], tcell_off[ODPL_MAX_SCALES], compact_total;
+    int layout[ODPL_MAX_SCALES], cells[ODPL_MAX_SCALES];
     int conf_blk_per_row[ODPL_MAX_SCALES], conf_nblk[ODPL_MAX_SCALES], conf_vec[ODPL_MAX_SCALES];
-    int fill_nblk[ODPL_MAX_SCALES], rows_per_fill_blk[ODPL_MAX_SCALES];
+    int exp_nblk[ODPL_MAX_SCALES], rows_per_exp_blk[ODPL_MAX_SCALES];
     int W;
 };
+
+// memory format of one scale from its element strides (b, c, y, x); all zero = NCHW contiguous
+int classify_layout(const odpl_yolo_scale_t& s, int B, int CH) {
+    const long long G = s.G, ACH = (long long)s.A * CH;
+    const int64_t* t = s.stride;
+    if (t[0] == 0 && t[1] == 0 && t[2] == 0 && t[3] == 0) return ODPL_LAYOUT_PLANAR;
+    const bool b_ok = B == 1 || t[0] == ACH * G * G;
+    if (b_ok && t[1] == G * G && (G == 1 || (t[2] == G && t[3] == 1))) return ODPL_LAYOUT_PLANAR;
+    if (b_ok && t[1] == 1 && (G == 1 || (t[2] == G * ACH && t[3] == ACH))) return ODPL_LAYOUT_INTERLEAVED;
+    return -1;
+}
 
 bool make_plan(const odpl_yolo_loss_desc_t* d, Plan* p) {
     if (!d || d->nscales < 1 || d->nscales > ODPL_MAX_SCALES || d->B < 1 || d->C < 1 || d->nT < 0) return false;
     const int CH = 5 + d->C;
     p->W = (d->C + 31) / 32;
     size_t off = 0;
-    // all state maps first, contiguous: one memset(0xFF) resets them
+    // all state maps first, contiguous: one fill(0xFF) resets them
     for (int i = 0; i < d->nscales; ++i) {
         const odpl_yolo_scale_t& s = d->scale[i];
         if (s.G < 1 || s.A < 1 || s.A > ODPL_MAX_ANCHORS || !s.head) return false;
         if ((long long)d->B * s.A * CH * s.G * s.G > 0x7fffffffLL) return false;
+        p->layout[i] = classify_layout(s, d->B, CH);
+        if (p->layout[i] < 0) return false;
+        p->cells[i] = d->B * s.A * s.G * s.G;
         p->state_off[i] = off;
-        off += align_up((size_t)d->B * s.A * s.G * s.G * sizeof(int), 256);
+        off += align_up((size_t)p->cells[i] * sizeof(int), 256);
     }
     p->state_bytes_total = off;
     const size_t nT = (size_t)(d->nT > 0 ? d->nT : 1);
+    size_t coff = 0;
     for (int i = 0; i < d->nscales; ++i) {
         const odpl_yolo_scale_t& s = d->scale[i];
         const int G2 = s.G * s.G;
-        p->conf_vec[i] = (G2 % 4 == 0) ? 1 : 0;
-        const int units = p->conf_vec[i] ? G2 / 4 : G2;
-        p->conf_blk_per_row[i] = (units + kDenseThreads - 1) / kDenseThreads;
-        p->conf_nblk[i] = d->B * s.A * p->conf_blk_per_row[i];
-        int rows = (g_fill_f4_per_block * 4 + G2 - 1) / G2; if (rows < 1) rows = 1;
-        p->rows_per_fill_blk[i] = rows;
-        const int R = d->B * s.A * CH;
-        p->fill_nblk[i] = s.grad ? (R + rows - 1) / rows : 0;
-        p->rec_off[i] = off;    off += align_up(nT * 4 * sizeof(float), 256);
-        p->tcell_off[i] = off;  off += align_up(nT * sizeof(int), 256);
-        p->trank_off[i] = off;  off += align_up(nT * sizeof(int), 256);
-        p->bits_off[i] = off;   off += align_up(nT * p->W * sizeof(unsigned), 256);
-        p->counts_off[i] = off; off += 256;
-        p->confp_off[i] = off;  off += align_up((size_t)p->conf_nblk[i] * 2 * sizeof(float), 256);
-        p->objp_off[i] = off;   off += align_up(nT * 8 * sizeof(float), 256);
+        if (p->layout[i] == ODPL_LAYOUT_PLANAR) {
+            p->conf_vec[i] = (G2 % 4 == 0) ? 1 : 0;
+            const int units = p->conf_vec[i] ? G2 / 4 : G2;
+            p->conf_blk_per_row[i] = (units + kConfThreads - 1) / kConfThreads;
+            p->conf_nblk[i] = d->B * s.A * p->conf_blk_per_row[i];
+            int rows = (g_fill_f4_per_block * 4 + G2 - 1) / G2; if (rows < 1) rows = 1;
+            p->rows_per_exp_blk[i] = rows;
+            const int R = d->B * s.A * CH;
+            p->exp_nblk[i] = (R + rows - 1) / rows;
+        } else {
+            p->conf_vec[i] = 0;
+            p->conf_blk_per_row[i] = 1;
+            p->conf_nblk[i] = (p->cells[i] + kConfThreads - 1) / kConfThreads;
+            p->rows_per_exp_blk[i] = g_fill_f4_per_block;                   // float4 per block
+            const size_t totalq = (size_t)p->cells[i] * CH / 4;
+            p->exp_nblk[i] = (int)((totalq + g_fill_f4_per_block - 1) / g_fill_f4_per_block);
+            if (p->exp_nblk[i] < 1) p->exp_nblk[i] = 1;
+        }
+        p->rec_off[i] = off;      off += align_up(nT * 4 * sizeof(float), 256);
+        p->tcell_ws_off[i] = off; off += align_up(nT * sizeof(int), 256);
+        p->trank_off[i] = off;    off += align_up(nT * sizeof(int), 256);
+        p->bits_off[i] = off;     off += align_up(nT * p->W * sizeof(unsigned), 256);
+        p->counts_off[i] = off;   off += 256;
+        p->confp_off[i] = off;    off += align_up((size_t)p->conf_nblk[i] * 2 * sizeof(float), 256);
+        p->objp_off[i] = off;     off += align_up(nT * 8 * sizeof(float), 256);
+        p->gconf_off[i] = coff;   coff += align_up((size_t)p->cells[i] * sizeof(float), 256);
+        p->gobj_off[i] = coff;    coff += align_up(nT * CH * sizeof(float), 256);
+        p->tcell_off[i] = coff;   coff += align_up(nT * sizeof(int), 256);
     }
-    p->total = off;
+    p->ws_total = off;
+    p->compact_total = coff;
     return true;
+}
+
+bool any_grad(const odpl_yolo_loss_desc_t* d) {
+    for (int i = 0; i < d->nscales; ++i) if (d->scale[i].grad) return true;
+    return false;
+}
+
+// fills the kernel parameter block; `ws` is NULL in backward, `compact` is NULL in a forward-only call
+int make_params(const odpl_yolo_loss_desc_t* d, const Plan& pl, char* ws, char* compact, Params* out) {
+    Params& P = *out;
+    P.target = d->target; P.upstream = nullptr;
+    P.nscales = d->nscales; P.B = d->B; P.C = d->C; P.CH = 5 + d->C; P.nT = d->nT; P.W = pl.W;
+    P.coord_sl1 = d->coord_mode == ODPL_COORD_SMOOTH_L1; P.cls_mode = d->cls_mode; P.average = d->average;
+    P.ignore_thres = d->ignore_thres; P.obj_scale = d->obj_scale; P.noobj_scale = d->noobj_scale;
+    P.inv_S = d->average ? 1.0f / (float)d->nscales : 1.0f;
+    P.fill_nt = g_fill_nt;
+    P.stamp = g_stamp;
+    P.out7 = nullptr; P.out_scales = nullptr; P.out_counts = nullptr;
+    for (int i = 0; i < d->nscales; ++i) {
+        const odpl_yolo_scale_t& s = d->scale[i];
+        Scale& S = P.s[i];
+        if (((uintptr_t)s.head & 15) != 0 || ((uintptr_t)s.grad & 15) != 0) return ODPL_EINVAL;
+        S.head = s.head; S.grad = s.grad; S.G = s.G; S.G2 = s.G * s.G; S.A = s.A; S.layout = pl.layout[i]; S.cells = pl.cells[i];
+        S.inv_ch = ((1ull << 40) + (unsigned long long)P.CH - 1ull) / (unsigned long long)P.CH;
+        if (ws) {
+            S.state = (int*)(ws + pl.state_off[i]); S.rec = (float*)(ws + pl.rec_off[i]);
+            S.trank = (int*)(ws + pl.trank_off[i]); S.bits = (unsigned*)(ws + pl.bits_off[i]);
+            S.counts = (int*)(ws + pl.counts_off[i]);
+            S.conf_part = (float*)(ws + pl.confp_off[i]); S.obj_part = (float*)(ws + pl.objp_off[i]);
+        } else {
+            S.state = nullptr; S.rec = nullptr; S.trank = nullptr; S.bits = nullptr; S.counts = nullptr; S.conf_part = nullptr; S.obj_part = nullptr;
+        }
+        if (compact) {
+            S.gconf = (float*)(compact + pl.gconf_off[i]); S.gobj = (float*)(compact + pl.gobj_off[i]);
+            S.tcell = (int*)(compact + pl.tcell_off[i]);
+        } else {
+            S.gconf = nullptr; S.gobj = nullptr; S.tcell = ws ? (int*)(ws + pl.tcell_ws_off[i]) : nullptr;
+        }
+        for (int a = 0; a < ODPL_MAX_ANCHORS; ++a) { S.aw[a] = s.anchor_w[a]; S.ah[a] = s.anchor_h[a]; }
+        S.conf_blk_per_row = pl.conf_blk_per_row[i]; S.conf_nblk = pl.conf_nblk[i]; S.conf_vec = pl.conf_vec[i];
+        S.exp_nblk = pl.exp_nblk[i]; S.rows_per_exp_blk = pl.rows_per_exp_blk[i];
+        S.conf_blk0 = S.obj_blk0 = S.exp_blk0 = 0;
+    }
+    return 0;
+}
+
+int run_forward(const odpl_yolo_loss_desc_t* d, const Plan& pl, void* workspace, void* compact, float* out7, float* out_scales,
+                int32_t* out_counts, hipStream_t stream) {
+    Params P;
+    const int rc = make_params(d, pl, (char*)workspace, (char*)compact, &P);
+    if (rc) return rc;
+    P.out7 = out7; P.out_scales = out_scales; P.out_counts = out_counts;
+    int nblk = 0;
+    for (int i = 0; i < d->nscales; ++i) { P.s[i].conf_blk0 = nblk; nblk += P.s[i].conf_nblk; }     // confidence blocks first
+    for (int i = 0; i < d->nscales; ++i) { P.s[i].obj_blk0 = nblk; nblk += d->nT; }
+    if (!(d->flags & ODPL_YOLO_STATE_CLEAN)) ODPL_HIP_TRY(odpl::fill_bytes(workspace, 0xFF, pl.state_bytes_total, stream));
+    prof_begin(ODPL_PROF_YOLO_ASSIGN, stream);
+    hipLaunchKernelGGL(yolo_assign_kernel, dim3(d->nscales), dim3(kAssignThreads), 0, stream, P);
+    prof_end(ODPL_PROF_YOLO_ASSIGN, stream);
+    ODPL_HIP_TRY(hipGetLastError());
+    prof_begin(ODPL_PROF_YOLO_LOSS, stream);
+    hipLaunchKernelGGL(yolo_loss_kernel, dim3(nblk), dim3(kConfThreads), 0, stream, P);
+    prof_end(ODPL_PROF_YOLO_LOSS, stream);
+    ODPL_HIP_TRY(hipGetLastError());
+    prof_begin(ODPL_PROF_YOLO_FINALIZE, stream);
+    hipLaunchKernelGGL(yolo_finalize_kernel, dim3(1), dim3(64 * ODPL_MAX_SCALES), 0, stream, P);
+    prof_end(ODPL_PROF_YOLO_FINALIZE, stream);
+    ODPL_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int run_backward(const odpl_yolo_loss_desc_t* d, const Plan& pl, const void* compact, const float* upstream, hipStream_t stream) {
+    Params P;
+    const int rc = make_params(d, pl, nullptr, (char*)compact, &P);
+    if (rc) return rc;
+    P.upstream = upstream;
+    int nblk = 0;
+    for (int i = 0; i < d->nscales; ++i) {
+        P.s[i].exp_blk0 = nblk;
+        if (!d->scale[i].grad) P.s[i].exp_nblk = 0;
+        nblk += P.s[i].exp_nblk;
+    }
+    if (nblk == 0) return 0;
+    prof_begin(ODPL_PROF_YOLO_EXPAND, stream);
+    hipLaunchKernelGGL(yolo_expand_kernel, dim3(nblk), dim3(kExpandThreads), 0, stream, P);
+    prof_end(ODPL_PROF_YOLO_EXPAND, stream);
+    ODPL_HIP_TRY(hipGetLastError());
+    return 0;
 }
 }  // namespace
 
@@ -472,66 +713,59 @@ extern "C" int odpl_abi_version(void) { return ODPL_ABI_VERSION; }
 
 extern "C" size_t odpl_yolo_region_loss_workspace_bytes(const odpl_yolo_loss_desc_t* desc) {
     Plan p;
-    return make_plan(desc, &p) ? p.total : 0;
+    if (!make_plan(desc, &p)) return 0;
+    return p.ws_total + (any_grad(desc) ? p.compact_total : 0);      // the one-call entry keeps the compact form in the workspace
+}
+
+extern "C" size_t odpl_yolo_region_loss_compact_bytes(const odpl_yolo_loss_desc_t* desc) {
+    Plan p;
+    return make_plan(desc, &p) ? p.compact_total : 0;
+}
+
+extern "C" int odpl_yolo_region_loss_forward(const odpl_yolo_loss_desc_t* d, void* workspace, size_t workspace_bytes,
+                                             void* compact, size_t compact_bytes, float* out7, float* out_scales,
+                                             int32_t* out_counts, void* stream) {
+    Plan pl;
+    if (!make_plan(d, &pl) || !workspace || workspace_bytes < pl.ws_total || !out7) return ODPL_EINVAL;
+    if (compact && compact_bytes < pl.compact_total) return ODPL_EINVAL;
+    if (d->nT > 0 && !d->target) return ODPL_EINVAL;
+    if (((uintptr_t)workspace & 15) != 0 || ((uintptr_t)compact & 15) != 0) return ODPL_EINVAL;
+    return run_forward(d, pl, workspace, compact, out7, out_scales, out_counts, (hipStream_t)stream);
+}
+
+extern "C" int odpl_yolo_region_loss_backward(const odpl_yolo_loss_desc_t* d, const void* compact, size_t compact_bytes,
+                                              const float* upstream, void* stream) {
+    Plan pl;
+    if (!make_plan(d, &pl) || !compact || compact_bytes < pl.compact_total || ((uintptr_t)compact & 15) != 0) return ODPL_EINVAL;
+    return run_backward(d, pl, compact, upstream, (hipStream_t)stream);
 }
 
 extern "C" int odpl_yolo_region_loss(const odpl_yolo_loss_desc_t* d, void* workspace, size_t workspace_bytes,
                                      float* out7, float* out_scales, int32_t* out_counts, void* stream_) {
     Plan pl;
-    if (!make_plan(d, &pl) || !workspace || workspace_bytes < pl.total || !out7) return ODPL_EINVAL;
+    if (!make_plan(d, &pl) || !workspace || !out7) return ODPL_EINVAL;
+    const bool grads = any_grad(d);
+    if (workspace_bytes < pl.ws_total + (grads ? pl.compact_total : 0)) return ODPL_EINVAL;
     if (d->nT > 0 && !d->target) return ODPL_EINVAL;
     if (((uintptr_t)workspace & 15) != 0) return ODPL_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
-    char* ws = (char*)workspace;
-    Params P;
-    P.target = d->target; P.nscales = d->nscales; P.B = d->B; P.C = d->C; P.CH = 5 + d->C; P.nT = d->nT; P.W = pl.W;
-    P.coord_sl1 = d->coord_mode == ODPL_COORD_SMOOTH_L1; P.cls_mode = d->cls_mode; P.average = d->average;
-    P.ignore_thres = d->ignore_thres; P.obj_scale = d->obj_scale; P.noobj_scale = d->noobj_scale;
-    P.inv_S = d->average ? 1.0f / (float)d->nscales : 1.0f;
-    P.fill_nt = g_fill_nt;
-    P.stamp = g_stamp;
-    P.out7 = out7; P.out_scales = out_scales; P.out_counts = out_counts;
-    int nblk = 0;
-    bool any_grad = false;
-    for (int i = 0; i < d->nscales; ++i) {          // confidence blocks first: latency-bound, start early
-        const odpl_yolo_scale_t& s = d->scale[i];
-        Scale& S = P.s[i];
-        if (((uintptr_t)s.head & 15) != 0 || ((uintptr_t)s.grad & 15) != 0) return ODPL_EINVAL;
-        S.head = s.head; S.grad = s.grad; S.G = s.G; S.G2 = s.G * s.G; S.A = s.A;
-        S.state = (int*)(ws + pl.state_off[i]); S.rec = (float*)(ws + pl.rec_off[i]);
-        S.tcell = (int*)(ws + pl.tcell_off[i]); S.trank = (int*)(ws + pl.trank_off[i]);
-        S.bits = (unsigned*)(ws + pl.bits_off[i]); S.counts = (int*)(ws + pl.counts_off[i]);
-        S.conf_part = (float*)(ws + pl.confp_off[i]); S.obj_part = (float*)(ws + pl.objp_off[i]);
-        for (int a = 0; a < ODPL_MAX_ANCHORS; ++a) { S.aw[a] = s.anchor_w[a]; S.ah[a] = s.anchor_h[a]; }
-        S.conf_blk_per_row = pl.conf_blk_per_row[i]; S.conf_nblk = pl.conf_nblk[i]; S.conf_vec = pl.conf_vec[i];
-        S.conf_blk0 = nblk; nblk += S.conf_nblk;
-        any_grad |= s.grad != nullptr;
-    }
-    for (int i = 0; i < d->nscales; ++i) {
-        Scale& S = P.s[i];
-        S.fill_nblk = pl.fill_nblk[i]; S.rows_per_fill_blk = pl.rows_per_fill_blk[i];
-        S.fill_blk0 = nblk; nblk += S.fill_nblk;
-    }
-    (void)any_grad;
-    if (!(d->flags & ODPL_YOLO_STATE_CLEAN)) ODPL_HIP_TRY(odpl::fill_bytes(ws, 0xFF, pl.state_bytes_total, stream));
-    prof_begin(ODPL_PROF_YOLO_ASSIGN, stream);
-    hipLaunchKernelGGL(yolo_assign_kernel, dim3(d->nscales), dim3(kAssignThreads), 0, stream, P);
-    prof_end(ODPL_PROF_YOLO_ASSIGN, stream);
-    ODPL_HIP_TRY(hipGetLastError());
-    prof_begin(ODPL_PROF_YOLO_DENSE, stream);
-    hipLaunchKernelGGL(yolo_dense_kernel, dim3(nblk), dim3(kDenseThreads), 0, stream, P);
-    prof_end(ODPL_PROF_YOLO_DENSE, stream);
-    ODPL_HIP_TRY(hipGetLastError());
-    if (d->nT > 0) {
-        prof_begin(ODPL_PROF_YOLO_OBJ, stream);
-        hipLaunchKernelGGL(yolo_obj_kernel, dim3(d->nT, d->nscales), dim3(kObjThreads), 0, stream, P);
-        prof_end(ODPL_PROF_YOLO_OBJ, stream);
-        ODPL_HIP_TRY(hipGetLastError());
-    }
-    prof_begin(ODPL_PROF_YOLO_FINALIZE, stream);
-    hipLaunchKernelGGL(yolo_finalize_kernel, dim3(1), dim3(64 * ODPL_MAX_SCALES), 0, stream, P);
-    prof_end(ODPL_PROF_YOLO_FINALIZE, stream);
-    ODPL_HIP_TRY(hipGetLastError());
+    char* compact = grads ? (char*)workspace + pl.ws_total : nullptr;            // every offset is a multiple of 256
+    const int rc = run_forward(d, pl, workspace, compact, out7, out_scales, out_counts, stream);
+    if (rc || !grads) return rc;
+    return run_backward(d, pl, compact, nullptr, stream);
+}
+
+extern "C" int odpl_yolo_compact_view(const odpl_yolo_loss_desc_t* d, const void* compact, int32_t scale, odpl_sparse_grad_t* out) {
+    Plan pl;
+    if (!make_plan(d, &pl) || !compact || !out || scale < 0 || scale >= d->nscales) return ODPL_EINVAL;
+    const char* c = (const char*)compact;
+    out->dense = (const float*)(c + pl.gconf_off[scale]);
+    out->rows = (const float*)(c + pl.gobj_off[scale]);
+    out->row_cell = (const int32_t*)(c + pl.tcell_off[scale]);
+    out->n_rows = d->nT;
+    out->B = d->B; out->G2 = d->scale[scale].G * d->scale[scale].G; out->A = d->scale[scale].A; out->no = 5 + d->C;
+    out->dense_ch = 4;
+    out->layout = pl.layout[scale];
     return 0;
 }
 

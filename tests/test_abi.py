@@ -21,13 +21,16 @@ def test_header_symbols_exported_and_bound():
     for n in names:
         assert hasattr(raw, n), f"{n} declared in odpl_hip.h but not exported"
     assert sorted(_lib.SIGNATURES) == names, (set(names) ^ set(_lib.SIGNATURES))
-    assert _lib.lib().odpl_abi_version() == _lib.ABI_VERSION == 2
+    assert _lib.lib().odpl_abi_version() == _lib.ABI_VERSION == 3
 
 
 def test_struct_layout_matches_header():
     from objectdetectionpl_amd import _lib
-    # odpl_yolo_scale_t: 2 pointers + 2 int32 + 2*8 floats
-    assert ctypes.sizeof(_lib.YoloScale) == 8 + 8 + 4 + 4 + 4 * 16
+    # odpl_yolo_scale_t: 2 pointers + 2 int32 + 2*8 floats + 4 int64 strides
+    assert ctypes.sizeof(_lib.YoloScale) == 8 + 8 + 4 + 4 + 4 * 16 + 8 * 4
+    assert _lib.YoloScale.stride.offset == 88
+    # odpl_sparse_grad_t: 3 pointers + 7 int32 (+pad)
+    assert ctypes.sizeof(_lib.SparseGrad) == 56
     # odpl_yolo_loss_desc_t: 8 int32 + 3 float (+pad) + pointer + 4 scales
     assert _lib.YoloLossDesc.target.offset == 48
     assert ctypes.sizeof(_lib.YoloLossDesc) == 56 + 4 * ctypes.sizeof(_lib.YoloScale)
@@ -41,6 +44,20 @@ def test_workspace_query_is_host_only():
         d.scale[i].G, d.scale[i].A, d.scale[i].head = G, 3, 0x1000
     n = _lib.lib().odpl_yolo_region_loss_workspace_bytes(ctypes.byref(d))
     assert 16 * 3 * (52 * 52 + 26 * 26 + 13 * 13) * 4 < n < 4 << 20
+    # the compact (structured) gradient: one float per cell + nT rows of 5+C + nT cells, per scale
+    c = _lib.lib().odpl_yolo_region_loss_compact_bytes(ctypes.byref(d))
+    assert 16 * 3 * (52 * 52 + 26 * 26 + 13 * 13) * 4 + 3 * 112 * 85 * 4 <= c < 1 << 20
+    # with a gradient requested the one-call entry keeps the compact form in its workspace
+    d.scale[0].grad = 0x2000
+    assert _lib.lib().odpl_yolo_region_loss_workspace_bytes(ctypes.byref(d)) == n + c
+    # channels-last strides are accepted, arbitrary ones are not
+    for i, G in enumerate((52, 26, 13)):
+        for k, v in enumerate((255 * G * G, 1, 255 * G, 255)):
+            d.scale[i].stride[k] = v
+    assert _lib.lib().odpl_yolo_region_loss_workspace_bytes(ctypes.byref(d)) > 0
+    d.scale[1].stride[3] = 7
+    assert _lib.lib().odpl_yolo_region_loss_workspace_bytes(ctypes.byref(d)) == 0
+    d.scale[1].stride[3] = 255
     d.nscales = 9
     assert _lib.lib().odpl_yolo_region_loss_workspace_bytes(ctypes.byref(d)) == 0
 
@@ -50,6 +67,9 @@ def test_bad_arguments_return_einval_without_touching_the_gpu():
     L = _lib.lib()
     d = _lib.YoloLossDesc()
     assert L.odpl_yolo_region_loss(ctypes.byref(d), None, 0, None, None, None, None) == -1
+    assert L.odpl_yolo_region_loss_forward(ctypes.byref(d), None, 0, None, 0, None, None, None, None) == -1
+    assert L.odpl_yolo_region_loss_backward(ctypes.byref(d), None, 0, None, None) == -1
+    assert L.odpl_yolo_compact_view(ctypes.byref(d), None, 0, None) == -1
     assert L.odpl_scale_inplace_if_not_one(None, 4, None, None) == -1
     assert L.odpl_profile_enable(99, 1) == -1
     assert L.odpl_tune_set(99, 1) == -1

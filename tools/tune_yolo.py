@@ -26,7 +26,7 @@ def main():
     tgt = torch.cat([torch.arange(B).repeat_interleave(7).float()[:, None], torch.randint(0, C, (n, 1), generator=g).float(),
                      torch.rand(n, 2, generator=g) * (1 - wh), wh], 1).to(dev)
     crit = MultiScaleRegionLoss_v4(A9, M, "bce_loss", "smooth_l1_loss", "bce_loss", C, 416)
-    names = ("yolo_assign", "yolo_dense", "yolo_obj", "yolo_finalize")
+    names = ("yolo_assign", "yolo_loss", "yolo_finalize", "yolo_expand")
     N = int(os.environ.get("N", "100"))
     settings = list(itertools.product([512, 1024, 2048, 4096, 8192, 16384], [0, 1]))
     cold = os.environ.get("COLD", "1") == "1"
