@@ -249,6 +249,10 @@ def main():
                     help="torch.backends.cudnn.benchmark=False (MIOpen immediate mode instead of the find-db solvers)")
     ap.add_argument("--no-fused-adam", dest="fused_adam", action="store_false", help="foreach Adam instead of the fused one")
     ap.add_argument("--no-channels-last", dest="channels_last", action="store_false", help="NCHW memory format for the network")
+    ap.add_argument("--no-head-gemm", dest="head_gemm", action="store_false",
+                    help="A/B: head 1x1 convolutions on MIOpen (channels-last heads) instead of utils/headconv.py")
+    ap.add_argument("--no-fused-head-backward", dest="fused_head", action="store_false",
+                    help="A/B: the criterion hands autograd the dense d loss/d head instead of running the head convolutions' backward itself")
     a = ap.parse_args()
 
     # ---- launcher: `python bench.py --gpus N` without torchrun -> this process only starts the N ranks -------------------
@@ -309,6 +313,10 @@ def main():
         k, v = kv.split("=")
         _lib.tune_set(k, int(v))
     torch.backends.cudnn.benchmark = bool(a.miopen_find)
+    from objectdetectionpl_amd.LightningFunc.losses import _RegionLossBase
+    from objectdetectionpl_amd.LightningFunc.utils.headconv import HeadConv2d
+    HeadConv2d.enabled = bool(a.head_gemm)
+    _RegionLossBase.fuse_head_backward = bool(a.fused_head)
     torch.manual_seed(0)
     model = YOLOv4([str(i) for i in range(a.classes)], Args()).to(dev).train()
     if a.channels_last:
@@ -342,7 +350,7 @@ def main():
         torch.cuda.synchronize()
         log(f"warmup step {i + 1}/{a.warmup} done")     # the first step includes MIOpen solver selection / kernel builds
     fence()
-    PROF = ("yolo_expand", "yolo_assign", "yolo_loss", "yolo_finalize")
+    PROF = ("yolo_assign", "yolo_loss", "yolo_finalize", "yolo_expand", "yolo_patch", "headgrad_stream", "headgrad_finish")
     for k in PROF:
         _lib.profile_enable(k, True)
     stamps = []
@@ -364,7 +372,9 @@ def main():
     for k in PROF:
         _lib.profile_enable(k, False)
         prof[k] = _lib.profile_collect(k)
-    dense_ms, dense_raw_ms = prof["yolo_expand"]
+    fused = len(prof["headgrad_stream"][0]) > 0        # the criterion ran the head convolutions' backward itself
+    roof_key = "headgrad_stream" if fused else "yolo_expand"
+    dense_ms, dense_raw_ms = prof[roof_key]
     loss_val = float(d["loss"].item())
 
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -395,22 +405,29 @@ def main():
     if rank == 0:
         CH = 5 + a.classes
         cells = sum(a.batch * 3 * G * G for G in (a.img // 8, a.img // 16, a.img // 32))
-        # as-built algorithmic bytes of yolo_expand_kernel per launch (DESIGN.md "Kernels"): write every gradient
-        # element once + read the compact confidence gradient once
-        alg_bytes = 4 * cells * CH + 4 * cells
+        head_cin = {a.img // 8: 256, a.img // 16: 512, a.img // 32: 1024}          # inputs of conv2 / conv10 / conv18 (model/YOLOV4.py:89-127)
+        if fused:
+            # headgrad_stream_kernel, one launch for the three heads: read X once (dW of the confidence
+            # channels), write dX once, read the compact confidence gradient; fp32
+            alg_bytes = sum(2 * 4 * a.batch * G * G * c for G, c in head_cin.items()) + 4 * cells
+            roof_kernel = "headgrad_stream_kernel"
+        else:
+            # yolo_expand_kernel: write every element of the dense d loss/d head once + read the compact confidence gradient
+            alg_bytes = 4 * cells * CH + 4 * cells
+            roof_kernel = "yolo_expand_kernel"
         traffic, traffic_src = None, None
         try:        # PMC counters cannot be collected from inside this process: committed rocprofv3 --pmc passes
             with open(os.path.join(REPO, "profiles", "pmc_traffic.json")) as f:
                 pmc = json.load(f)
             if pmc["workload"] == {"batch": a.batch, "classes": a.classes, "img": a.img}:
-                traffic = pmc["yolo_expand_kernel"]["hbm_bytes"]
+                traffic = pmc[roof_kernel]["hbm_bytes"]
                 traffic_src = "committed PMC pass (" + pmc.get("source", "profiles/pmc_traffic.json") + "), not measured in this run"
         except Exception:  # noqa: BLE001
             pass
         avg_ms = sum(dense_ms) / max(len(dense_ms), 1)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if dense_ms else None
-        rp = rocprof_row("yolo_expand_kernel")
-        launches_us = {k: round(1e3 * sum(v[0]) / max(len(v[0]), 1), 2) for k, v in prof.items()}
+        rp = rocprof_row(roof_kernel)
+        launches_us = {k: round(1e3 * sum(v[0]) / len(v[0]), 2) for k, v in prof.items() if v[0]}
         res = {
             "metric": "images/sec training step (YOLOv4 416x416, bs=16/GPU)",
             "value": round(a.batch * world * a.steps / dt, 2), "unit": "img/s",
@@ -421,7 +438,7 @@ def main():
             "config": {"workload": f"YOLOv4 COCO-synthetic {a.img}x{a.img} bs={a.batch}/GPU training step "
                                    f"(fwd + HIP region loss + bwd + Adam), {a.classes} classes, 7 targets/img, rank r seeded 1+r",
                        "global_batch": a.batch * world, "parallelism": f"dp{world}", "loss_last": round(loss_val, 4)},
-            "roofline": {"kernel": "yolo_expand_kernel", "bound": "hbm",
+            "roofline": {"kernel": roof_kernel, "bound": "hbm",
                          "achieved": None if achieved is None else round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_source": traffic_src,
@@ -431,7 +448,11 @@ def main():
                          "rocprof_frac": None if rp is None else round(alg_bytes / (rp["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                          "rocprof_source": None if rp is None else rp["file"],
                          "launches": len(dense_ms),
-                         "loss_launches_us": launches_us, "loss_launches_sum_us": round(sum(launches_us.values()), 2),
+                         "loss_launches_us": launches_us,
+                         "loss_launches_sum_us": round(sum(v for k, v in launches_us.items() if k.startswith("yolo_")), 2),
+                         "head_backward_launches_sum_us": round(sum(v for k, v in launches_us.items() if k.startswith("headgrad_")), 2),
+                         "replaces": ("MIOpen backward of the three head convolutions + the dense 57.9 MB d loss/d head stream "
+                                      "(0.89 ms + 11 us, tools/probe_headconv.py)") if fused else None,
                          **({"in_kernel_stamp_us": round(sorted(stamps)[len(stamps) // 2], 2)} if stamps else {}),
                          "algorithmic_bytes": alg_bytes, "survey_8d_bytes": 2 * 4 * cells * CH},
         }

@@ -131,6 +131,35 @@ typedef struct {
 /* the compact gradient of scale `scale` as left by odpl_yolo_region_loss_forward (host-side pointer arithmetic only) */
 int odpl_yolo_compact_view(const odpl_yolo_loss_desc_t* desc, const void* compact, int32_t scale, odpl_sparse_grad_t* out);
 
+/* ---- backward of a head's 1x1 convolution from a structured gradient -------------------------------------------
+ * The linear head convolutions (model/YOLOV4.py:89-127 conv2/conv10/conv18, YOLOV3 / YOLOV2 heads, YOLOV5.py:93-97
+ * Detect.m: Conv2d(Cin, A*no, 1) with bias) feed the criterion directly.  Their backward from an odpl_sparse_grad_t:
+ *     dX[n,:]  = sum_a dense[n,a] * W[a*no+dc,:] + sum_{rows t at n} sum_{c != dc} rows[t,c] * W[a_t*no+c,:]
+ *     dW[ch,:] = sum_n (d loss/d head)[n,ch] * X[n,:]        db[ch] = sum_n (d loss/d head)[n,ch]
+ * (what aten::convolution_backward computes from the dense tensor -- the implicit autograd of model/YOLOV4.py:216-218 --
+ * without ever writing that tensor).  X: the convolution's input as [N = B*G2, Cin] row-major (a dense channels-last
+ * [B, Cin, G, G] tensor), fp32 or bf16; W: [A*no, Cin] fp32.  Every output is fully written (not accumulated). */
+typedef struct {
+    const void* x;                  /* [N, Cin] */
+    const float* w;                 /* [A*no, Cin] */
+    void* grad_x;                   /* [N, Cin], dtype of x; NULL = not wanted */
+    float* grad_w;                  /* [A*no, Cin]; NULL = not wanted */
+    float* grad_b;                  /* [A*no]; NULL = not wanted */
+    const float* upstream;          /* device scalar multiplied into every gradient; NULL = 1 */
+    int32_t Cin;                    /* % 4 == 0 (% 8 for bf16) */
+    int32_t bf16;                   /* x / grad_x are bfloat16 */
+} odpl_head_conv_t;
+size_t odpl_head_conv_backward_workspace_bytes(const odpl_head_conv_t* head, const odpl_sparse_grad_t* grad);
+int odpl_head_conv_backward(const odpl_head_conv_t* head, const odpl_sparse_grad_t* grad, void* workspace,
+                            size_t workspace_bytes, void* stream);
+/* All heads of a model in ONE pair of launches (same A and dtype on every head, n <= ODPL_MAX_SCALES, at most 4096 rows per
+ * head); `heads` / `grads` are host arrays. */
+size_t odpl_head_conv_backward_multi_workspace_bytes(int32_t n, const odpl_head_conv_t* heads, const odpl_sparse_grad_t* grads);
+int odpl_head_conv_backward_multi(int32_t n, const odpl_head_conv_t* heads, const odpl_sparse_grad_t* grads, void* workspace,
+                                  size_t workspace_bytes, void* stream);
+/* launch geometry of the streaming kernel: rows of X per workgroup (default 64) */
+int odpl_head_conv_tune(int32_t rows_per_tile);
+
 /*
  * autograd glue: grad[i] *= *scale unless *scale == 1.0f (decided on the device, no host sync).
  * Used by the backward of the fused loss, whose gradient was produced for a unit upstream gradient.
@@ -461,6 +490,9 @@ int odpl_debug_set_stamp_buffer(void* dev_u64);
 #define ODPL_PROF_GREEDY_NMS_IMAGE 9
 #define ODPL_PROF_YOLO_DECODE 10
 #define ODPL_PROF_YOLOV5_DENSE 11
+#define ODPL_PROF_HEADGRAD_STREAM 12  /* headgrad_stream_kernel: X read + dX write of the fused head backward */
+#define ODPL_PROF_HEADGRAD_FINISH 13
+#define ODPL_PROF_YOLO_PATCH 14
 #define ODPL_PROF_NUM_KERNELS 16
 int odpl_profile_enable(int32_t kernel_id, int32_t on);
 /* Synchronises the recorded events, writes up to max_n durations (ms) and returns how many launches

@@ -14,6 +14,7 @@ import torch.nn as nn
 
 from .. import _lib
 from .._lib import OdplError
+from .utils.headconv import fusable_source
 
 KEYS = ("loss", "Localization", "Size", "Conf", "Classification", "Conf_obj", "Conf_noobj")
 
@@ -87,6 +88,47 @@ class _RegionLossFn(torch.autograd.Function):
         return (None, None, None, None) + tuple(grads)
 
 
+class _RegionLossHeadFn(torch.autograd.Function):
+    """The same loss when every head is the output of `utils.headconv.head_conv`: differentiable inputs are the head
+    convolutions' (x, weight, bias), not the head tensors.  backward runs each convolution's backward from the compact
+    gradient (`odpl_head_conv_backward`): the dense d loss/d head tensors are never materialised."""
+
+    @staticmethod
+    def forward(ctx, owner, target, scale_anchors, average, n, *args):
+        heads, srcs = args[:n], args[n:]
+        xs, ws, bs = srcs[0::3], srcs[1::3], srcs[2::3]
+        d, keep = owner._describe(list(heads), [(0, 0, 0, 0)] * n, target, scale_anchors, average)
+        out7, counts, compact = owner._forward(d, heads[0].device, True)
+        ctx.desc, ctx.keep, ctx.compact, ctx.n = d, keep, compact, n
+        ctx.srcs = (xs, ws, bs)
+        ctx.used = False
+        loss = out7[0]
+        metrics = out7[1:]
+        ctx.mark_non_differentiable(metrics, counts)
+        return loss, metrics, counts
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_metrics, _g_counts):
+        from .utils.headconv import head_conv_backward
+        if ctx.used:
+            raise RuntimeError("the fused region loss frees its gradient buffers after the first backward "
+                               "(call backward once per forward)")
+        ctx.used = True
+        d, compact, n = ctx.desc, ctx.compact, ctx.n
+        xs, ws, bs = ctx.srcs
+        ctx.desc = ctx.compact = ctx.srcs = ctx.keep = None
+        up = g_loss.contiguous().float()
+        L = _lib.lib()
+        need_all = ctx.needs_input_grad[5 + n:]
+        sparses = []
+        for i in range(n):
+            sg = _lib.SparseGrad()
+            _lib.check(L.odpl_yolo_compact_view(ctypes.byref(d), _lib.ptr(compact), i, ctypes.byref(sg)), "odpl_yolo_compact_view")
+            sparses.append(sg)
+        out = head_conv_backward(sparses, xs, ws, bs, up, [need_all[3 * i:3 * i + 3] for i in range(n)])
+        return (None, None, None, None, None) + (None,) * n + tuple(out)
+
+
 class _RegionLossBase(nn.Module):
     """Shared host logic of the v2/v3/v4 region losses."""
 
@@ -106,6 +148,9 @@ class _RegionLossBase(nn.Module):
         self._ws = None
         self._ws_clean_key = None        # (device, stream, shapes, formats) for which the workspace's state maps are known clean
         self.last_counts = None          # int32 [nscales, 8] on device: nObj, nNoobj, guard1, guard2, status
+
+    # class switch: False = always hand autograd the dense d loss/d head (the head convolutions then run their own backward)
+    fuse_head_backward = True
 
     # -- descriptor ---------------------------------------------------------------------------------
     def _describe(self, heads, strides, target, scale_anchors, average):
@@ -184,8 +229,14 @@ class _RegionLossBase(nn.Module):
     def _run(self, heads, target, scale_anchors, average):
         # half-precision heads (a bf16 / fp16 autocast network): the reference computes this loss in fp32, so widen once;
         # autograd narrows the gradients back (YOLOv5's criterion consumes bf16 heads natively instead)
-        heads = [h.float() if h.dtype in (torch.bfloat16, torch.float16) else h for h in heads]
-        loss, metrics, _counts = _RegionLossFn.apply(self, target, scale_anchors, average, *heads)
+        srcs = [fusable_source(h) for h in heads] if self.fuse_head_backward else [None]
+        if all(s is not None for s in srcs) and all(h.dtype == torch.float32 and h.is_contiguous() for h in heads):
+            flat = [t for s in srcs for t in s]
+            loss, metrics, _counts = _RegionLossHeadFn.apply(self, target, scale_anchors, average, len(heads),
+                                                             *[h.detach() for h in heads], *flat)
+        else:
+            heads = [h.float() if h.dtype in (torch.bfloat16, torch.float16) else h for h in heads]
+            loss, metrics, _counts = _RegionLossFn.apply(self, target, scale_anchors, average, *heads)
         vals = (loss,) + tuple(metrics.unbind(0))
         return dict(zip(KEYS, vals))
 

@@ -30,6 +30,12 @@ class SparseGrad(ctypes.Structure):
                 ("n_rows", c_int32), ("B", c_int32), ("G2", c_int32), ("A", c_int32), ("no", c_int32), ("dense_ch", c_int32), ("layout", c_int32)]
 
 
+class HeadConv(ctypes.Structure):
+    """odpl_head_conv_t"""
+    _fields_ = [("x", c_void_p), ("w", c_void_p), ("grad_x", c_void_p), ("grad_w", c_void_p), ("grad_b", c_void_p),
+                ("upstream", c_void_p), ("Cin", c_int32), ("bf16", c_int32)]
+
+
 class YoloLossDesc(ctypes.Structure):
     _fields_ = [("B", c_int32), ("C", c_int32), ("nT", c_int32), ("nscales", c_int32),
                 ("coord_mode", c_int32), ("cls_mode", c_int32), ("average", c_int32), ("flags", c_int32),
@@ -98,6 +104,11 @@ SIGNATURES = {
     "odpl_yolo_region_loss_forward": (c_int32, [POINTER(YoloLossDesc), c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
     "odpl_yolo_region_loss_backward": (c_int32, [POINTER(YoloLossDesc), c_void_p, c_size_t, c_void_p, c_void_p]),
     "odpl_yolo_compact_view": (c_int32, [POINTER(YoloLossDesc), c_void_p, c_int32, POINTER(SparseGrad)]),
+    "odpl_head_conv_backward_workspace_bytes": (c_size_t, [POINTER(HeadConv), POINTER(SparseGrad)]),
+    "odpl_head_conv_backward": (c_int32, [POINTER(HeadConv), POINTER(SparseGrad), c_void_p, c_size_t, c_void_p]),
+    "odpl_head_conv_backward_multi_workspace_bytes": (c_size_t, [c_int32, c_void_p, c_void_p]),
+    "odpl_head_conv_backward_multi": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "odpl_head_conv_tune": (c_int32, [c_int32]),
     "odpl_scale_inplace_if_not_one": (c_int32, [c_void_p, c_size_t, c_void_p, c_void_p]),
     "odpl_retina_loss_workspace_bytes": (c_size_t, [POINTER(RetinaLossDesc)]),
     "odpl_retina_loss": (c_int32, [POINTER(RetinaLossDesc), c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
@@ -208,7 +219,7 @@ def tune_set(name, value):
 
 
 PROF_IDS = {"yolo_expand": 0, "yolo_assign": 1, "yolo_loss": 2, "yolo_finalize": 3, "retina_assign": 4, "retina_main": 5,
-            "yolo_nms_prep": 6, "yolo_nms_image": 7, "greedy_nms_prep": 8, "greedy_nms_image": 9, "yolo_decode": 10, "yolov5_dense": 11}
+            "yolo_nms_prep": 6, "yolo_nms_image": 7, "greedy_nms_prep": 8, "greedy_nms_image": 9, "yolo_decode": 10, "yolov5_dense": 11, "headgrad_stream": 12, "headgrad_finish": 13, "yolo_patch": 14}
 
 
 def profile_enable(name, on=True):

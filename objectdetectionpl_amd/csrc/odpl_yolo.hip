@@ -17,10 +17,10 @@
 //                                    the 5+C logits of an obj cell -> x,y,w,h,cls terms, gobj[t][5+C], "Size" metric
 //   finalize (1 workgroup)           fixed-order reduction -> the reference's 7 scalars per scale and total
 // backward consumes the compact gradient:
-//   expand   (one launch)            the dense tensor autograd hands to a generic producer: zeros streamed with 16-B
-//                                    non-temporal stores, gconf in the confidence slots, gobj on the obj cells, all scaled by
-//                                    the upstream scalar read on the device.  HBM-write bound; the kernel the generic path's
-//                                    roofline figure is quoted on.
+//   expand + patch                   the dense tensor autograd hands to a generic producer: zeros streamed with 16-B
+//                                    non-temporal stores and gconf in the confidence slots (HBM-write bound; the kernel the
+//                                    generic path's roofline figure is quoted on), then gobj scattered onto the obj cells;
+//                                    all scaled by the upstream scalar read on the device.
 //   (or odpl_headgrad.hip)           when the producer is a 1x1 convolution the dense tensor is never materialised: the
 //                                    convolution's backward is computed from the compact form directly.
 // No atomics on floats anywhere: results are bitwise reproducible run to run.
@@ -162,21 +162,24 @@ __global__ __launch_bounds__(kAssignThreads) void yolo_assign_kernel(const Param
         }
     }
     __syncthreads();
-    // raster rank of every obj cell (order of pred_boxes[..., 2:4][obj_mask], losses.py:568: (b, a, j, i) ascending); the
-    // interleaved cell index orders (b, j, i, a), so ranks compare the planar key there
+    // raster rank of every obj cell (order of pred_boxes[..., 2:4][obj_mask], losses.py:568: (b, a, j, i) ascending).  The
+    // interleaved cell index orders (b, j, i, a), so ranks compare the planar key; s_cell is rewritten with keys first.
     auto raster_key = [&](int c) {
-        if (S.layout == ODPL_LAYOUT_PLANAR) return c;
+        if (c < 0 || S.layout == ODPL_LAYOUT_PLANAR) return c;
         const int a = c % A, bs = c / A, b = bs / S.G2, s = bs - b * S.G2;
         return (b * A + a) * S.G2 + s;
     };
+    if (S.layout != ODPL_LAYOUT_PLANAR) {
+        for (int t = tid; t < nT && t < kAssignRankCap; t += kAssignThreads) s_cell[t] = raster_key(s_cell[t]);
+        __syncthreads();
+    }
     for (int t = tid; t < nT; t += kAssignThreads) {
-        const int c = t < kAssignRankCap ? s_cell[t] : S.tcell[t];
-        if (c < 0) continue;
-        const int kc = raster_key(c);
+        const int kc = t < kAssignRankCap ? s_cell[t] : raster_key(S.tcell[t]);
+        if (kc < 0) continue;
         int r = 0;
         const int nl = nT < kAssignRankCap ? nT : kAssignRankCap;
-        for (int u = 0; u < nl; ++u) { const int cu = s_cell[u]; r += (cu >= 0) && (raster_key(cu) < kc); }
-        for (int u = kAssignRankCap; u < nT; ++u) { const int cu = S.tcell[u]; r += (cu >= 0) && (raster_key(cu) < kc); }
+        for (int u = 0; u < nl; ++u) { const int ku = s_cell[u]; r += (ku >= 0) & (ku < kc); }
+        for (int u = kAssignRankCap; u < nT; ++u) { const int ku = raster_key(S.tcell[u]); r += (ku >= 0) & (ku < kc); }
         S.trank[t] = r;
     }
     // counts
@@ -458,19 +461,6 @@ __device__ __forceinline__ void expand_block(const Params& P, const Scale& S, in
             }
             cur = seg_end + (next_conf < r1 ? 1 : 0);
         }
-        if (P.nT == 0) return;
-        __syncthreads();                                              // the block's own stores are complete: patch the obj cells
-        const int p_lo = r0 / CH, p_hi = (r1 - 1) / CH;               // planes this block touches
-        for (int t = tid; t < P.nT; t += kExpandThreads) {
-            const int cell = S.tcell[t];
-            if (cell < 0 || cell >= S.cells) continue;
-            const int plane = cell / G2, s = cell - plane * G2;
-            if (plane < p_lo || plane > p_hi) continue;
-            const float* go = S.gobj + (size_t)t * CH;
-            const int q0 = plane * CH;
-            const int c0 = r0 > q0 ? r0 - q0 : 0, c1 = (r1 - q0) < CH ? (r1 - q0) : CH;
-            for (int c = c0; c < c1; ++c) if (c != 4) S.grad[(size_t)(q0 + c) * G2 + s] = go[c] * f;
-        }
     } else {
         // interleaved: a linear chunk of the [cells*CH] array; element e = cell*CH + c, confidence slots at c == 4
         const size_t total = (size_t)S.cells * CH, totalq = total / 4;
@@ -478,7 +468,6 @@ __device__ __forceinline__ void expand_block(const Params& P, const Scale& S, in
         const size_t q0 = (size_t)local * chunk;
         const bool last = q0 + chunk >= totalq;
         const size_t q1 = last ? totalq : q0 + chunk;
-        const size_t e0 = q0 * 4, e1 = last ? total : q1 * 4;         // the last chunk also owns the < 4 tail elements
         v4f* g4 = reinterpret_cast<v4f*>(S.grad);
         for (size_t q = q0 + tid; q < q1; q += kExpandThreads) {
             const unsigned e = (unsigned)(q * 4);
@@ -493,19 +482,6 @@ __device__ __forceinline__ void expand_block(const Params& P, const Scale& S, in
             const size_t c = e / CH;
             S.grad[e] = (e - c * CH == 4) ? S.gconf[c] * f : 0.f;
         }
-        if (P.nT == 0) return;
-        __syncthreads();
-        for (int t = tid; t < P.nT; t += kExpandThreads) {
-            const int cell = S.tcell[t];
-            if (cell < 0 || cell >= S.cells) continue;
-            const size_t b0 = (size_t)cell * CH;
-            if (b0 + CH <= e0 || b0 >= e1) continue;
-            const float* go = S.gobj + (size_t)t * CH;
-            for (int c = 0; c < CH; ++c) {
-                const size_t e = b0 + c;
-                if (c != 4 && e >= e0 && e < e1) S.grad[e] = go[c] * f;
-            }
-        }
     }
 }
 
@@ -517,6 +493,21 @@ __global__ __launch_bounds__(kExpandThreads) void yolo_expand_kernel(const Param
     const Scale& S = P.s[si];
     if (P.fill_nt) expand_block<true>(P, S, bid - S.exp_blk0); else expand_block<false>(P, S, bid - S.exp_blk0);
     stamp_end(P);
+}
+
+// the 4+C non-confidence gradients of each obj cell, written over the zeros of the expand launch (stream order)
+__global__ __launch_bounds__(kObjThreads) void yolo_patch_kernel(const Params P) {
+    const Scale& S = P.s[blockIdx.y];
+    if (!S.grad) return;
+    const int t = blockIdx.x, CH = P.CH;
+    const int cell = S.tcell[t];
+    if (cell < 0 || cell >= S.cells) return;
+    const float f = P.upstream ? *P.upstream : 1.0f;
+    const float* go = S.gobj + (size_t)t * CH;
+    size_t base, cs;
+    if (S.layout == ODPL_LAYOUT_PLANAR) { const int plane = cell / S.G2, s = cell - plane * S.G2; base = (size_t)plane * CH * S.G2 + s; cs = (size_t)S.G2; }
+    else { base = (size_t)cell * CH; cs = 1; }
+    for (int c = threadIdx.x; c < CH; c += kObjThreads) if (c != 4) S.grad[base + (size_t)c * cs] = go[c] * f;
 }
 
 __global__ void scale_if_not_one_kernel(float* __restrict__ g, size_t n, const float* __restrict__ s) {
@@ -705,6 +696,12 @@ int run_backward(const odpl_yolo_loss_desc_t* d, const Plan& pl, const void* com
     hipLaunchKernelGGL(yolo_expand_kernel, dim3(nblk), dim3(kExpandThreads), 0, stream, P);
     prof_end(ODPL_PROF_YOLO_EXPAND, stream);
     ODPL_HIP_TRY(hipGetLastError());
+    if (d->nT > 0) {
+        prof_begin(ODPL_PROF_YOLO_PATCH, stream);
+        hipLaunchKernelGGL(yolo_patch_kernel, dim3(d->nT, d->nscales), dim3(kObjThreads), 0, stream, P);
+        prof_end(ODPL_PROF_YOLO_PATCH, stream);
+        ODPL_HIP_TRY(hipGetLastError());
+    }
     return 0;
 }
 }  // namespace

@@ -14,6 +14,7 @@ from ..LightningFunc.accuracy import get_yolo_statistics as _get_yolo_statistics
 from ..LightningFunc.losses import configure_loss
 from ..LightningFunc.nms import yolo_non_max_suppression
 from ..LightningFunc.utils import bnact as _bnact
+from ..LightningFunc.utils.headconv import HeadConv2d
 from ..LightningFunc.utils.s2d import reorg as _reorg
 
 try:
@@ -70,7 +71,7 @@ class YOLOv2(_Base):
             setattr(self, name, _unit(ci, co, k))
         self.stage2_b_conv = _unit(512, 64, 1)
         self.stage3_conv1 = _unit(256 + 1024, 1024, 3)
-        self.stage3_conv2 = nn.Conv2d(1024, len(self.anchors) * (5 + self.num_classes), 1, 1, 0, bias=False)
+        self.stage3_conv2 = HeadConv2d(1024, len(self.anchors) * (5 + self.num_classes), 1, 1, 0, bias=False)
         self.sample = (1, 3, self.img_size, self.img_size)
         self.criterion = configure_loss(args, None, self.anchors, None, self.num_classes, self.img_size)
         self.checkname = self.backbone

@@ -16,6 +16,7 @@ from ..LightningFunc.accuracy import get_yolo_statistics as _get_yolo_statistics
 from ..LightningFunc.losses import configure_loss
 from ..LightningFunc.nms import yolo_non_max_suppression
 from ..LightningFunc.utils import bnact as _bnact
+from ..LightningFunc.utils.headconv import HeadConv2d
 
 try:
     import pytorch_lightning as pl
@@ -92,7 +93,7 @@ def _head(first, cin, mid, out_ch, conv_name):
         co, k = (mid, 1) if i % 2 == 0 else (mid * 2, 3)
         d[f"{n}_convbatch"] = Conv2dBatchReLU(c, co, k, 1, k // 2); n += 1
         c = co
-    d[conv_name] = nn.Conv2d(c, out_ch, 1, 1, 0)
+    d[conv_name] = HeadConv2d(c, out_ch, 1, 1, 0)              # NCHW head + structured backward (utils/headconv.py)
     return d
 
 

@@ -22,6 +22,7 @@ from ..LightningFunc.accuracy import get_yolo_statistics as _get_yolo_statistics
 from ..LightningFunc.losses import configure_loss
 from ..LightningFunc.utils import bnact as _bnact
 from ..LightningFunc.utils import convsplit as _cs
+from ..LightningFunc.utils.headconv import HeadConv2d
 from ..LightningFunc.utils.spp import spp_cat
 
 try:                                    # PL is optional: the reference derives from pl.LightningModule
@@ -36,7 +37,8 @@ class ConvUnit(nn.Module):
 
     def __init__(self, cin, cout, k, stride, act, bn=True, bias=False):
         super().__init__()
-        layers = [nn.Conv2d(cin, cout, k, stride, (k - 1) // 2, bias=bias)]
+        head = (not bn) and act == "linear" and k == 1 and stride == 1
+        layers = [(HeadConv2d if head else nn.Conv2d)(cin, cout, k, stride, (k - 1) // 2, bias=bias)]
         if bn:
             layers.append(nn.BatchNorm2d(cout))
         if act == "mish":
@@ -60,8 +62,8 @@ class ConvUnit(nn.Module):
                     z = l(z)
                 return residual + z
             return residual + self.forward(x)
-        if self._plain_bias and ConvUnit.fuse_epilogue and x.is_cuda and x.dtype == torch.float32:
-            return _bnact.conv_bias(x, self.conv[0])                 # head conv: bias gradient by the HIP channel sum
+        if self._plain_bias and ConvUnit.fuse_epilogue and x.is_cuda and x.dtype == torch.float32 and not isinstance(self.conv[0], HeadConv2d):
+            return _bnact.conv_bias(x, self.conv[0])                 # a biased linear conv that is not a head: bias gradient by the HIP channel sum
         if self._act is not None and ConvUnit.fuse_epilogue:
             z = _cs.conv2d(x, self.conv[0])
             if _bnact.fusable(z, self.conv[1]):

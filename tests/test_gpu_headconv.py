@@ -1,0 +1,239 @@
+"""The head 1x1 convolution hosted by `utils/headconv.py` and its backward from the criterion's STRUCTURED gradient
+(`csrc/odpl_headgrad.hip`): same numbers as the dense route (conv -> dense d loss/d head -> aten convolution_backward, the
+reference's implicit autograd of model/YOLOV4.py:216-218 + losses.py:583-634) and as the CPU oracle end to end."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from oracle import yolo as oracle_yolo
+
+pytestmark = pytest.mark.gpu
+
+V4_ANCHORS = [[12, 16], [19, 36], [40, 28], [36, 75], [76, 55], [72, 146], [142, 110], [192, 243], [459, 401]]
+V4_MASKS = [[0, 1, 2], [3, 4, 5], [6, 7, 8]]
+DEV = "cuda:0"
+
+
+def _close(a, b, rtol=1e-4, atol_scale=1e-6):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    assert a.shape == b.shape
+    tol = atol_scale * float(b.abs().max()) + 1e-12
+    assert torch.allclose(a, b, rtol=rtol, atol=tol), float((a - b).abs().max())
+
+
+@pytest.mark.parametrize("channels_last", [True, False])
+@pytest.mark.parametrize("bias", [True, False])
+def test_head_conv_forward_and_dense_backward_match_conv2d(channels_last, bias):
+    from objectdetectionpl_amd.LightningFunc.utils.headconv import HeadConv2d
+    g = torch.Generator().manual_seed(0)
+    conv = HeadConv2d(64, 27, 1, bias=bias).to(DEV)
+    x = torch.randn(3, 64, 13, 13, generator=g).to(DEV)
+    if channels_last:
+        x = x.contiguous(memory_format=torch.channels_last)
+    x1, x2 = x.clone().requires_grad_(), x.clone().requires_grad_()
+    y1 = conv(x1)
+    y2 = F.conv2d(x2, conv.weight, conv.bias)
+    assert y1.is_contiguous() and hasattr(y1, "_odpl_head_src")             # NCHW-planar whatever the input's format
+    _close(y1, y2, 1e-5)
+    gy = torch.randn(y1.shape, generator=g).to(DEV)
+    g1 = torch.autograd.grad(y1, [x1, conv.weight] + ([conv.bias] if bias else []), gy)
+    g2 = torch.autograd.grad(y2, [x2, conv.weight] + ([conv.bias] if bias else []), gy)
+    assert g1[0].stride() == x.stride()
+    for a, b in zip(g1, g2):
+        _close(a, b)
+
+
+def _targets(g, B, per, C, shared_cells=True):
+    n = B * per
+    wh = torch.rand(n, 2, generator=g) * 0.48 + 0.02
+    xy = torch.rand(n, 2, generator=g) * (1 - wh)
+    t = torch.cat([torch.arange(B).repeat_interleave(per).float()[:, None], torch.randint(0, C, (n, 1), generator=g).float(), xy, wh], 1)
+    if shared_cells and n >= 4:
+        t[1, 2:4] = t[0, 2:4]                       # same cell, very different shape -> another anchor of the same cell-row
+        t[1, 4:6] = torch.tensor([0.03, 0.05])
+        t[0, 4:6] = torch.tensor([0.45, 0.40])
+        t[3] = t[2]                                 # exact duplicate: last row wins
+    return t
+
+
+class _Heads(nn.Module):
+    def __init__(self, cins, cout, head_cls):
+        super().__init__()
+        self.convs = nn.ModuleList(head_cls(c, cout, 1) for c in cins)
+
+    def forward(self, xs):
+        return [c(x) for c, x in zip(self.convs, xs)]
+
+
+@pytest.mark.parametrize("C,B", [(4, 2), (80, 4)])
+def test_structured_backward_equals_dense_route_and_oracle(C, B):
+    """x -> head conv -> MultiScaleRegionLoss_v4.  Gradients of x, W, b through odpl_head_conv_backward == through the dense
+    tensor, == the CPU oracle's autograd (F.conv2d + oracle loss).  Targets share cells across anchors and repeat rows."""
+    from objectdetectionpl_amd.LightningFunc.losses import MultiScaleRegionLoss_v4, _RegionLossBase
+    from objectdetectionpl_amd.LightningFunc.utils.headconv import HeadConv2d
+    g = torch.Generator().manual_seed(3)
+    cins, Gs, cout = (32, 64, 128), (52, 26, 13), 3 * (5 + C)
+    xs = [torch.randn(B, c, G, G, generator=g) * 0.5 for c, G in zip(cins, Gs)]
+    tgt = _targets(g, B, 5, C)
+    torch.manual_seed(0)
+    net = _Heads(cins, cout, HeadConv2d)
+    crit = MultiScaleRegionLoss_v4(V4_ANCHORS, V4_MASKS, "bce_loss", "smooth_l1_loss", "bce_loss", C, 416)
+
+    def run(fused, scale=1.0):
+        m = _Heads(cins, cout, HeadConv2d).to(DEV)
+        m.load_state_dict(net.state_dict())
+        xd = [x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_() for x in xs]
+        _RegionLossBase.fuse_head_backward = fused
+        try:
+            out = crit(m(xd), tgt.to(DEV))
+            (out["loss"] * scale).backward()
+        finally:
+            _RegionLossBase.fuse_head_backward = True
+        return out, xd, m
+
+    of, xf, mf = run(True)
+    od, xd, md = run(False)
+    for k in of:
+        assert of[k].item() == od[k].item()
+    for a, b in zip(xf, xd):
+        assert a.grad.stride() == a.stride()
+        _close(a.grad, b.grad)
+    for (n1, p1), (n2, p2) in zip(mf.named_parameters(), md.named_parameters()):
+        _close(p1.grad, p2.grad)
+    # upstream scale is applied on the device
+    o3, x3, m3 = run(True, 3.0)
+    for a, b in zip(x3, xf):
+        _close(a.grad, b.grad * 3.0, 1e-5)
+    for p1, p2 in zip(m3.parameters(), mf.parameters()):
+        _close(p1.grad, p2.grad * 3.0, 1e-5)
+    # bitwise reproducible
+    o4, x4, m4 = run(True)
+    for a, b in zip(x4, xf):
+        assert torch.equal(a.grad, b.grad)
+    for p1, p2 in zip(m4.parameters(), mf.parameters()):
+        assert torch.equal(p1.grad, p2.grad)
+    # the oracle, end to end on the CPU
+    xc = [x.clone().requires_grad_() for x in xs]
+    hc = [F.conv2d(x, c.weight, c.bias) for x, c in zip(xc, net.convs)]
+    ref = oracle_yolo.multiscale_region_loss_v4(hc, tgt, V4_ANCHORS, V4_MASKS, C, 416)
+    ref["loss"].backward()
+    for k in ref:
+        assert abs(of[k].item() - ref[k].item()) <= 1e-4 * abs(ref[k].item()) + 1e-6, k
+    for a, b in zip(xf, xc):
+        _close(a.grad, b.grad)
+    for p1, p2 in zip(mf.parameters(), net.parameters()):
+        _close(p1.grad, p2.grad)
+
+
+def _dense_from_sparse(gd, gr, cells, B, G2, A, no, dc, layout):
+    """the dense [B, A*no, G2] tensor an odpl_sparse_grad_t stands for"""
+    full = torch.zeros(B, A, no, G2, dtype=torch.float64)
+    if layout == 0:
+        full[:, :, dc, :] = gd.double().view(B, A, G2)
+    else:
+        full[:, :, dc, :] = gd.double().view(B, G2, A).permute(0, 2, 1)
+    for t, cell in enumerate(cells.tolist()):
+        if cell < 0:
+            continue
+        if layout == 0:
+            plane, s = divmod(cell, G2); b, a = divmod(plane, A)
+        else:
+            n, a = divmod(cell, A); b, s = divmod(n, G2)
+        row = gr[t].double().clone()
+        row[dc] = 0.0                               # slot dc of a row is ignored: that channel lives in `dense`
+        full[b, a, :, s] += row                     # rows that name the same cell accumulate (YOLOv5: index_put(accumulate))
+    return full.view(B, A * no, G2)
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("A,no,Cin,G,nrows", [(3, 9, 64, 13, 7), (5, 25, 1024, 9, 12), (3, 85, 2048, 4, 0), (1, 6, 40, 5, 3)])
+def test_c_abi_head_conv_backward_vs_dense_math(layout, A, no, Cin, G, nrows):
+    """odpl_head_conv_backward on a synthetic odpl_sparse_grad_t (both cell orders, A = 1..5, Cin beyond one column pass,
+    no rows at all, rows that share a cell-row) against float64 dense math."""
+    from objectdetectionpl_amd import _lib
+    g = torch.Generator().manual_seed(A * 100 + no)
+    B, G2, dc = 2, G * G, 4
+    N = B * G2
+    x = torch.randn(N, Cin, generator=g)
+    w = torch.randn(A * no, Cin, generator=g) * 0.1
+    gd = torch.randn(B * A * G2, generator=g)
+    gr = torch.randn(max(nrows, 1), no, generator=g)
+    cells = torch.randint(0, B * A * G2, (max(nrows, 1),), generator=g, dtype=torch.int32)
+    if nrows >= 3:
+        # rows 0 and 1 on the same cell-row n with different anchors; row 2 unused
+        if layout == 0:
+            cells[0] = (0 * A + 0) * G2 + 3; cells[1] = (0 * A + (A - 1)) * G2 + 3
+        else:
+            cells[0] = (0 * G2 + 3) * A + 0; cells[1] = (0 * G2 + 3) * A + (A - 1)
+        cells[2] = -1
+    if nrows == 0:
+        cells[:] = -1
+    dense = _dense_from_sparse(gd, gr[:nrows] if nrows else gr[:0], cells[:nrows] if nrows else cells[:0], B, G2, A, no, dc, layout)
+    up = 0.5
+    xd = x.double().view(B, G2, Cin)
+    ref_gx = up * torch.einsum("bos,oc->bsc", dense, w.double()).reshape(N, Cin)
+    ref_gw = up * torch.einsum("bos,bsc->oc", dense, xd)
+    ref_gb = up * dense.sum((0, 2))
+
+    L = _lib.lib()
+    t = {k: v.to(DEV) for k, v in dict(x=x, w=w, gd=gd, gr=gr, cells=cells).items()}
+    gx, gw, gb = torch.empty_like(t["x"]), torch.empty_like(t["w"]), torch.empty(A * no, device=DEV)
+    upd = torch.tensor(up, device=DEV)
+    sg = _lib.SparseGrad(dense=t["gd"].data_ptr(), rows=t["gr"].data_ptr(), row_cell=t["cells"].data_ptr(), n_rows=nrows,
+                         B=B, G2=G2, A=A, no=no, dense_ch=dc, layout=layout)
+    h = _lib.HeadConv(x=t["x"].data_ptr(), w=t["w"].data_ptr(), grad_x=gx.data_ptr(), grad_w=gw.data_ptr(), grad_b=gb.data_ptr(),
+                      upstream=upd.data_ptr(), Cin=Cin, bf16=0)
+    nb = L.odpl_head_conv_backward_workspace_bytes(ctypes.byref(h), ctypes.byref(sg))
+    assert nb > 0
+    ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    _lib.check(L.odpl_head_conv_backward(ctypes.byref(h), ctypes.byref(sg), _lib.ptr(ws), nb, _lib.current_stream(torch.device(DEV))), "head")
+    torch.cuda.synchronize()
+    _close(gx, ref_gx, 1e-4, 1e-5)
+    _close(gw, ref_gw, 1e-4, 1e-5)
+    _close(gb, ref_gb, 1e-4, 1e-5)
+
+
+def test_yolov4_model_step_uses_the_structured_backward():
+    """The YOLOv4 caller model, channels-last: heads come out NCHW-contiguous, the criterion takes the fused route (no dense
+    gradient launch), and the gradients AT the head convolutions (their inputs, weights and biases) equal the dense route's.
+    (Further upstream MIOpen's backward kernels are not run-to-run reproducible on a random-init batch-2 network -- two
+    identical dense runs differ by 1e-1 relative on some layers, tools/debug_headgrad_model.py -- so nothing is asserted there.)"""
+    import argparse
+    from objectdetectionpl_amd import _lib
+    from objectdetectionpl_amd.LightningFunc.losses import _RegionLossBase
+    from objectdetectionpl_amd.model.YOLOV4 import YOLOv4
+    args = argparse.Namespace(model_name="YOLOv4", cls_criterion="bce_loss", coord_criterion="smooth_l1_loss", data_module="synthetic")
+    torch.manual_seed(0)
+    model = YOLOv4([str(i) for i in range(6)], args).to(DEV).to(memory_format=torch.channels_last).train()
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(2, 3, 416, 416, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    y = _targets(g, 2, 4, 6).to(DEV)
+    res = []
+    for fused in (True, False):
+        _RegionLossBase.fuse_head_backward = fused
+        _lib.profile_enable("yolo_expand", True)
+        _lib.profile_enable("headgrad_stream", True)
+        try:
+            model.zero_grad(set_to_none=True)
+            out = model(x)
+            assert all(o.is_contiguous() for o in out)
+            srcs = [o._odpl_head_src[0] for o in out]
+            for s_ in srcs:
+                s_.retain_grad()
+            model.criterion(out, y)["loss"].backward()
+        finally:
+            _RegionLossBase.fuse_head_backward = True
+            _lib.profile_enable("yolo_expand", False)
+            _lib.profile_enable("headgrad_stream", False)
+        n_expand, n_stream = len(_lib.profile_collect("yolo_expand")[0]), len(_lib.profile_collect("headgrad_stream")[0])
+        assert (n_expand, n_stream) == ((0, 1) if fused else (1, 0))      # one stream launch serves the three heads
+        res.append(([s_.grad.clone() for s_ in srcs], {n: p.grad.clone() for n, p in model.named_parameters() if ".conv.0." in n and
+                                                      n.split(".")[1] in ("conv2", "conv10", "conv18") and n.startswith("head.")}))
+    assert len(res[0][1]) == 6
+    for a, b in zip(res[0][0], res[1][0]):
+        _close(a, b, 1e-3, 1e-3)
+    for n in res[0][1]:
+        _close(res[0][1][n], res[1][1][n], 1e-3, 1e-3)

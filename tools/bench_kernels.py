@@ -68,7 +68,7 @@ def main():
     crit = MultiScaleRegionLoss_v4(A9, M3, "bce_loss", "smooth_l1_loss", "bce_loss", C, 416)
     cells = sum(B * 3 * G * G for G in (52, 26, 13))
     measure("config2 YOLOv4 loss fwd+bwd (B=16, C=80, 416^2)", ["yolo_assign", "yolo_loss", "yolo_finalize", "yolo_expand"],
-            lambda: crit(heads, tgt), {"yolo_expand": 4 * cells * 85 + 4 * cells, "yolo_loss": 16 * cells},
+            lambda: crit(heads, tgt)["loss"].backward(), {"yolo_expand": 4 * cells * 85 + 4 * cells, "yolo_loss": 16 * cells},
             {"yolo_expand": "dense grad write + compact conf-grad read", "yolo_loss": "conf logit + state read, state reset, compact grad write", "yolo_assign": "latency bound",
              "yolo_finalize": "latency bound"})
     hn = []

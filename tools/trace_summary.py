@@ -36,7 +36,7 @@ def main():
     ap.add_argument("trace")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--marker", default="yolo_finalize_kernel")
-    ap.add_argument("--top", type=int, default=40)
+    ap.add_argument("--top", type=int, default=60)
     a = ap.parse_args()
     rows = []
     with open(a.trace, newline="") as f:

@@ -36,7 +36,7 @@ def main():
         _lib.tune_set("yolo_fill_f4_per_block", f4)
         _lib.tune_set("yolo_fill_nt", nt)
         for _ in range(5):
-            crit(heads, tgt)
+            crit(heads, tgt)["loss"].backward()
         torch.cuda.synchronize()
         for k in names:
             _lib.profile_enable(k, True)
@@ -44,7 +44,7 @@ def main():
         for _ in range(N):
             if cold:
                 big.fill_(1.0)
-            crit(heads, tgt)
+            crit(heads, tgt)["loss"].backward()
         torch.cuda.synchronize()
         wall = (time.perf_counter() - t0) / N * 1e6
         row = []
