@@ -34,7 +34,7 @@ def main():
                               coord_criterion="smooth_l1_loss")
     dev = "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0"))
     dm = SyntheticCocoModule(a.batch, img, a.classes, steps_per_epoch=a.steps_per_epoch, device=dev, channels_last=True,
-                             raw_frames=a.raw_frames, seed=1 + int(os.environ.get("RANK", "0")))
+                             raw_frames=a.raw_frames, seed=1)          # rank r draws from seed 1 + r
     model = getattr(__import__(f"objectdetectionpl_amd.model.{mod}", fromlist=[a.model]), a.model)(dm.get_class(), args)
     model = model.to(dev).to(memory_format=torch.channels_last)
     ckpt = ModelCheckpoint(monitor="val_loss", dirpath=os.path.join(a.out, dm.name, model.checkname),

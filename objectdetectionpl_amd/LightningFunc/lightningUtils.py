@@ -1,40 +1,11 @@
-"""`write_Best_model_path` / `read_Best_model_path` of the reference (`LightningFunc/lightningUtils.py:17-37`) and a
-minimal `ModelCheckpoint` with the constructor the reference uses (`run.py:86-93`: monitor / dirpath / filename /
-save_top_k / mode), for machines without pytorch_lightning.  Checkpoints are `{"state_dict", "epoch", monitor}` files
-(PL's key for the weights), so a PL checkpoint's `state_dict` and ours load the same way."""
+"""`write_Best_model_path` / `read_Best_model_path` of the reference (`LightningFunc/lightningUtils.py:17-37`).  The
+`ModelCheckpoint` they read `best_model_path` from lives in `objectdetectionpl_amd/callbacks.py` (run.py:88-95)."""
 import os
 
 import torch
 
 
-class ModelCheckpoint:
-    def __init__(self, monitor="val_loss", dirpath=".", filename="model-{epoch:02d}-{val_loss:.2f}", save_top_k=3, mode="min", verbose=False):
-        self.monitor, self.dirpath, self.filename, self.save_top_k, self.mode, self.verbose = monitor, dirpath, filename, save_top_k, mode, verbose
-        self.best_model_path, self.best_model_score, self._kept = "", None, []
-
-    def _better(self, a, b):
-        return a < b if self.mode == "min" else a > b
-
-    def on_validation_end(self, model, epoch, value):
-        """Keep the `save_top_k` best epochs; returns the path written or None."""
-        if value != value:                                                   # NaN never wins
-            return None
-        if len(self._kept) >= self.save_top_k > 0 and not self._better(value, self._kept[-1][0]):
-            return None
-        os.makedirs(self.dirpath, exist_ok=True)
-        name = self.filename.replace("{epoch:02d}", "epoch=%02d" % epoch).replace("{%s:.2f}" % self.monitor, "%s=%.2f" % (self.monitor, value))
-        path = os.path.join(self.dirpath, name + ".ckpt")
-        torch.save({"state_dict": model.state_dict(), "epoch": epoch, self.monitor: value}, path)
-        self._kept.append((value, path))
-        self._kept.sort(key=lambda t: t[0], reverse=self.mode != "min")
-        while self.save_top_k > 0 and len(self._kept) > self.save_top_k:
-            _, old = self._kept.pop()
-            if os.path.exists(old):
-                os.remove(old)
-        self.best_model_score, self.best_model_path = self._kept[0]
-        if self.verbose:
-            print("checkpoint: %s" % path)
-        return path
+from ..callbacks import ModelCheckpoint  # noqa: E402,F401  (kept importable from here: round-1 location)
 
 
 def write_Best_model_path(self):

@@ -2,6 +2,8 @@
 `(x f32 [B,3,H,W] in [0,1] (BGR order, no mean/std: dataset/Pascal.py:98,179), y f32 [nT,6] = (img_idx_in_batch,
 cls, x, y, w, h) normalised)` -- dataset/Pascal.py:176-186.  Datasets themselves are out of scope (absent data,
 Windows paths); this module exists so that training/eval loops can run at full device speed without a CPU loader."""
+import os
+
 import torch
 
 
@@ -9,10 +11,13 @@ class SyntheticCocoModule:
     name = "synthetic"
 
     def __init__(self, batch_size, img_size, num_classes=80, targets_per_image=7, steps_per_epoch=8, device="cuda", seed=1,
-                 raw_frames=False, channels_last=False):
+                 raw_frames=False, channels_last=False, rank=None):
         self.batch_size, self.img_size, self.num_classes = batch_size, img_size, num_classes
         self.targets_per_image, self.steps_per_epoch = targets_per_image, steps_per_epoch
-        self.device, self.seed = torch.device(device), seed
+        # data-parallel ranks draw different batches (what PL's DistributedSampler does for the reference's datasets): rank r
+        # seeds from `seed + r` (seed 1 + rank); rank=None reads RANK from the launcher's environment
+        rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
+        self.device, self.seed, self.rank = torch.device(device), seed + rank, rank
         # raw_frames: emit COCO-like uint8 frames of varying size + pixel boxes and run the device collate
         # (resize / flips / normalise / row rewrite, dataset/collate.py) -- the train-time chain of Pascal.py:121-186
         self.raw_frames, self.channels_last = raw_frames, channels_last

@@ -114,16 +114,23 @@ class GradAverager:
             b.work = dist.all_reduce(b.flat, group=self.group, async_op=True)
 
     def finish(self):
-        """End of backward: wait for the outstanding collectives (the current stream waits; the host does not block on RCCL)."""
-        for b in self.buckets:
-            if b.pending != 0:
-                raise RuntimeError("a bucket did not fill: every parameter must receive a gradient each step "
-                                   "(static graph, like the reference's training step)")
-            b.work.wait()
-            if self.avg_op is None:
-                b.flat.div_(self.world)
-            b.work, b.pending = None, len(b.params)
-        self._armed = False
+        """End of backward: wait for the outstanding collectives (the current stream waits; the host does not block on RCCL).
+        A bucket that did not fill (a parameter without a gradient this step) is an error -- but the exchange state is reset
+        first, so the next backward starts clean instead of optimising on half-reduced buffers."""
+        unfilled = [i for i, b in enumerate(self.buckets) if b.pending != 0]
+        try:
+            for b in self.buckets:
+                if b.work is not None:
+                    b.work.wait()
+                    if self.avg_op is None:
+                        b.flat.div_(self.world)
+        finally:
+            for b in self.buckets:
+                b.work, b.pending = None, len(b.params)
+            self._armed = False
+        if unfilled:
+            raise RuntimeError(f"gradient bucket(s) {unfilled} did not fill: every parameter must receive a gradient each step "
+                               "(static graph, like the reference's training step)")
 
     def remove(self):
         for h in self._handles:
@@ -132,17 +139,37 @@ class GradAverager:
 
 
 class DataParallelHost(torch.nn.Module):
-    """`.module` + forward passthrough (the DDP surface the training loops use); gradients are averaged by `GradAverager`."""
+    """`.module` + forward passthrough (the DDP surface the training loops use); gradients are averaged by `GradAverager`.
+    broadcast_buffers (DDP's default, hence PL's): before every forward that will synchronise gradients the module's
+    buffers (BatchNorm running statistics, num_batches_tracked) are overwritten with rank 0's, one coalesced broadcast per
+    dtype -- so per-rank validation sees rank 0's statistics, as with the reference under PL's DDP."""
 
-    def __init__(self, module, bucket_mb=48, first_bucket_mb=4, group=None):
+    def __init__(self, module, bucket_mb=48, first_bucket_mb=4, group=None, broadcast_buffers=True):
         super().__init__()
         self.module = module
+        self.group = group
+        self.broadcast_buffers = broadcast_buffers
         with torch.no_grad():                      # replicas start from rank 0's weights and buffers, like DDP
             for t in list(module.parameters()) + list(module.buffers()):
                 dist.broadcast(t, 0, group=group)
         self.averager = GradAverager(module.parameters(), bucket_mb, first_bucket_mb, group)
 
+    def sync_buffers(self):
+        if not self.broadcast_buffers or not self.averager.enabled:          # inside no_sync DDP skips it too
+            return
+        by_dtype = {}
+        for b in self.module.buffers():
+            by_dtype.setdefault((b.dtype, b.device), []).append(b)
+        rank0 = dist.get_rank(self.group) == 0
+        with torch.no_grad():
+            for bufs in by_dtype.values():
+                flat = torch.cat([b.reshape(-1) for b in bufs])
+                dist.broadcast(flat, 0, group=self.group)
+                if not rank0:
+                    torch._foreach_copy_(bufs, [v.view_as(b) for v, b in zip(flat.split([b.numel() for b in bufs]), bufs)])
+
     def forward(self, *a, **k):
+        self.sync_buffers()
         return self.module(*a, **k)
 
     def no_sync(self):
@@ -153,7 +180,7 @@ def wrap_data_parallel(model, device=None, bucket_mb=48, first_bucket_mb=4, broa
     """Data-parallel wrapper; BN statistics stay per rank (no SyncBN), as in the reference.
     impl="bucketed": `DataParallelHost` (default).  impl="torch": torch's DistributedDataParallel with bucket views."""
     if impl == "bucketed":
-        return DataParallelHost(model, bucket_mb, first_bucket_mb)
+        return DataParallelHost(model, bucket_mb, first_bucket_mb, broadcast_buffers=broadcast_buffers)
     dev = None if device is None else torch.device(device)
     ids = [dev.index] if dev is not None and dev.type == "cuda" else None
     # the first bucket's size is a torch-internal default (1 MiB); raise it so the tail of backward is
