@@ -237,11 +237,17 @@ int odpl_ssd_priors(const int32_t* host_fk, const int32_t* host_per_cell, const 
 /* ---- YOLOv5 loss: accuracy.py:472-521, losses.py:37-156, accuracy.py:71-114 ------------------- */
 
 typedef struct {
-    const void* p;                        /* [B, na, G, G, 5+nc] channel-LAST (Yolo_Layers.forward, YOLOV5.py:93-97), fp32 or bf16 */
-    void* grad;                           /* same shape and dtype, or NULL on every layer: forward only */
+    const void* p;                        /* the [B, na, G, G, 5+nc] tensor of Yolo_Layers.forward (YOLOV5.py:93-97), fp32 or bf16, in the
+                                           * memory format `layout` says */
+    void* grad;                           /* same shape, dtype and memory format, or NULL on every layer: forward only */
     int32_t G;
     float anchor_w[ODPL_MAX_ANCHORS];     /* anchors / stride in f32 (losses.py:95-96) */
     float anchor_h[ODPL_MAX_ANCHORS];
+    int32_t layout;                       /* ODPL_LAYOUT_INTERLEAVED (1): contiguous [B,na,G,G,no], the reference's
+                                           * permute().contiguous(); ODPL_LAYOUT_PLANAR (0): the Detect convolution's NCHW output
+                                           * viewed as [B,na,no,G,G] -- strides (na*no*G2, no*G2, G, 1, G2) -- i.e. the permute taken as a
+                                           * VIEW (no copy; the objectness logits are contiguous planes).  Both use the cell index
+                                           * (b*na + a)*G2 + s. */
 } odpl_yolov5_layer_t;
 
 typedef struct {
@@ -255,12 +261,34 @@ typedef struct {
 
 #define ODPL_YOLOV5_STATE_CLEAN 1
 
+/* bytes for the one-call entry (and for a forward with compact == NULL) */
 size_t odpl_yolov5_loss_workspace_bytes(const odpl_yolov5_loss_desc_t* desc);
 /* out4: loss, Localization (lbox*0.05), Classification (lcls*0.58), Conf_obj (lobj*1.0).
  * out_counts int32[ODPL_MAX_SCALES+1]: matched rows per layer, then status (bit0: a target indexes outside
- * the grid/batch -- the reference raises IndexError; the row is dropped here). */
+ * the grid/batch -- the reference raises IndexError; the row is dropped here; bit2: dirty owner map). */
 int odpl_yolov5_loss(const odpl_yolov5_loss_desc_t* desc, void* workspace, size_t workspace_bytes,
                      float* out4, int32_t* out_counts, void* stream);
+/* Split the way autograd calls it (see odpl_yolo_region_loss_forward): forward leaves the STRUCTURED gradient -- the
+ * objectness gradient of every cell + `no` values per matched row -- in `compact`; backward expands it into layer[i].grad
+ * times *upstream; a 1x1-convolution producer (Detect.m, YOLOV5.py:93-97) takes odpl_yolov5_compact_view +
+ * odpl_head_conv_backward instead and the dense tensor is never written. */
+size_t odpl_yolov5_loss_compact_bytes(const odpl_yolov5_loss_desc_t* desc);
+int odpl_yolov5_loss_forward(const odpl_yolov5_loss_desc_t* desc, void* workspace, size_t workspace_bytes, void* compact,
+                             size_t compact_bytes, float* out4, int32_t* out_counts, void* stream);
+int odpl_yolov5_loss_backward(const odpl_yolov5_loss_desc_t* desc, const void* compact, size_t compact_bytes,
+                              const float* upstream, void* stream);
+/* build_targets_v5's rows as the kernels produced them (accuracy.py:472-521: indices (b, a, gj, gi) = row_cell decoded with
+ * cell = ((b*na + a)*G + gj)*G + gi, tbox, anchor index, target row -> tcls) -- HOST struct of DEVICE pointers into `compact` */
+typedef struct {
+    const int32_t* row_target;            /* [cap] row of `target` */
+    const int32_t* row_anchor_group;      /* [cap] (anchor << 4) | group, group 0 = the cell itself, 1..4 = x-1, y-1, x+1, y+1 */
+    const int32_t* row_cell;              /* [cap] linear cell, -1 = dropped / beyond n_rows */
+    const float* row_tbox;                /* [cap, 4] (gx - gi, gy - gj, gw, gh) */
+    const int32_t* n_rows;                /* [1] rows produced */
+    int32_t cap;
+} odpl_yolov5_rows_t;
+int odpl_yolov5_compact_view(const odpl_yolov5_loss_desc_t* desc, const void* compact, int32_t layer, odpl_sparse_grad_t* out,
+                             odpl_yolov5_rows_t* rows);
 
 /* ---- SSD loss: losses.py:159-315 ---------------------------------------------------------------- */
 
@@ -493,6 +521,7 @@ int odpl_debug_set_stamp_buffer(void* dev_u64);
 #define ODPL_PROF_HEADGRAD_STREAM 12  /* headgrad_stream_kernel: X read + dX write of the fused head backward */
 #define ODPL_PROF_HEADGRAD_FINISH 13
 #define ODPL_PROF_YOLO_PATCH 14
+#define ODPL_PROF_YOLOV5_OBJ 15
 #define ODPL_PROF_NUM_KERNELS 16
 int odpl_profile_enable(int32_t kernel_id, int32_t on);
 /* Synchronises the recorded events, writes up to max_n durations (ms) and returns how many launches

@@ -226,14 +226,29 @@ class SSDLoss(nn.Module):
         return {"loss": loss, "Localization": m[0], "Classification": m[1]}
 
 
+def _v5_layout(h):
+    """-> (tensor handed to the library, ODPL layout) for a [B, na, G, G, no] head.  The contiguous tensor (the reference's
+    permute().contiguous()) and the permuted VIEW of the Detect convolution's NCHW output are both consumed in place."""
+    if h.is_contiguous():
+        return h, _lib.LAYOUT_INTERLEAVED
+    B, na, G, G2_, no = h.shape
+    if h.dim() == 5 and h.stride() == (na * no * G * G2_, no * G * G2_, G2_, 1, G * G2_):
+        return h, _lib.LAYOUT_PLANAR
+    return h.contiguous(), _lib.LAYOUT_INTERLEAVED
+
+
 class _V5LossFn(torch.autograd.Function):
+    """forward: loss + the compact gradient; backward: one expand launch (+ the matched cells) into dense tensors with the
+    heads' own strides, scaled by the upstream gradient on the device."""
+
     @staticmethod
     def forward(ctx, owner, target, *heads):
         need = any(ctx.needs_input_grad[2:])
-        hs = [h.contiguous() for h in heads]
-        grads = [torch.empty_like(h) for h in hs] if need else [None] * len(hs)
-        out4, counts = owner._launch(hs, grads, target)
-        ctx.grads = grads
+        pairs = [_v5_layout(h) for h in heads]
+        d, keep = owner._describe([p[0] for p in pairs], [p[1] for p in pairs], target)
+        out4, counts, compact = owner._forward(d, pairs[0][0].device, need)
+        ctx.desc, ctx.keep, ctx.compact = d, keep, compact
+        ctx.like = [p[0] for p in pairs] if need else None
         ctx.used = False
         metrics = out4[1:]
         ctx.mark_non_differentiable(metrics, counts)
@@ -244,15 +259,54 @@ class _V5LossFn(torch.autograd.Function):
         if ctx.used:
             raise RuntimeError("the fused YOLOv5 loss frees its gradient buffers after the first backward")
         ctx.used = True
-        grads = ctx.grads
-        ctx.grads = None
-        g = g_loss.contiguous().float()
-        L = _lib.lib()
-        for gr in grads:
-            if gr is not None:
-                fn = L.odpl_scale_inplace_if_not_one_bf16 if gr.dtype == torch.bfloat16 else L.odpl_scale_inplace_if_not_one
-                _lib.check(fn(_lib.ptr(gr), gr.numel(), _lib.ptr(g), _lib.current_stream(gr.device)), "odpl_scale_inplace_if_not_one")
+        d, compact, like = ctx.desc, ctx.compact, ctx.like
+        ctx.desc = ctx.compact = ctx.like = ctx.keep = None
+        if not all(ctx.needs_input_grad[2:]):
+            raise RuntimeError("the YOLOv5 criterion differentiates all of its heads or none")
+        grads = [torch.empty_like(h) for h in like]                           # preserves the (possibly permuted-view) strides
+        for i, g in enumerate(grads):
+            d.layer[i].grad = g.data_ptr()
+        up = g_loss.contiguous().float()
+        _lib.check(_lib.lib().odpl_yolov5_loss_backward(ctypes.byref(d), _lib.ptr(compact), compact.numel(), _lib.ptr(up),
+                                                        _lib.current_stream(like[0].device)), "odpl_yolov5_loss_backward")
         return (None, None) + tuple(grads)
+
+
+class _V5LossHeadFn(torch.autograd.Function):
+    """The same loss when every head is a view of a `utils.headconv.head_conv` output: the differentiable inputs are the Detect
+    convolutions' (x, weight, bias); their backward runs from the compact gradient (`odpl_head_conv_backward_multi`)."""
+
+    @staticmethod
+    def forward(ctx, owner, target, n, *args):
+        heads, srcs = args[:n], args[n:]
+        d, keep = owner._describe(list(heads), [_lib.LAYOUT_PLANAR] * n, target)
+        out4, counts, compact = owner._forward(d, heads[0].device, True)
+        ctx.desc, ctx.keep, ctx.compact, ctx.n = d, keep, compact, n
+        ctx.srcs = (srcs[0::3], srcs[1::3], srcs[2::3])
+        ctx.used = False
+        metrics = out4[1:]
+        ctx.mark_non_differentiable(metrics, counts)
+        return out4[0], metrics, counts
+
+    @staticmethod
+    def backward(ctx, g_loss, _gm, _gc):
+        from .utils.headconv import head_conv_backward
+        if ctx.used:
+            raise RuntimeError("the fused YOLOv5 loss frees its gradient buffers after the first backward")
+        ctx.used = True
+        d, compact, n = ctx.desc, ctx.compact, ctx.n
+        xs, ws, bs = ctx.srcs
+        ctx.desc = ctx.compact = ctx.srcs = ctx.keep = None
+        up = g_loss.contiguous().float()
+        L = _lib.lib()
+        sparses = []
+        for i in range(n):
+            sg = _lib.SparseGrad()
+            _lib.check(L.odpl_yolov5_compact_view(ctypes.byref(d), _lib.ptr(compact), i, ctypes.byref(sg), None), "odpl_yolov5_compact_view")
+            sparses.append(sg)
+        need_all = ctx.needs_input_grad[3 + n:]
+        out = head_conv_backward(sparses, xs, ws, bs, up, [need_all[3 * i:3 * i + 3] for i in range(n)])
+        return (None, None, None) + (None,) * n + tuple(out)
 
 
 class _PosWeight(nn.Module):
@@ -295,45 +349,91 @@ class MultiScaleRegionLoss_v5(nn.Module):
         self._ws = None
         self._clean_key = None
         self.last_counts = None
+        self.last_compact = (None, None)
 
-    def _launch(self, heads, grads, target):
+    fuse_head_backward = True      # class switch: False = always hand autograd the dense d loss/d p
+
+    def _describe(self, heads, layouts, target):
         _lib.require_cuda(target, *heads)
-        L = _lib.lib()
-        dev = heads[0].device
         d = _lib.YoloV5LossDesc()
         tgt = target.float().contiguous()
         d.nl, d.B, d.na, d.nc, d.nT = len(heads), heads[0].shape[0], self.na, self.nc, tgt.shape[0]
         d.iou_mode = _lib.IOU_MODES[self.iou_mode]
         d.bf16 = 1 if heads[0].dtype == torch.bfloat16 else 0
         d.target = tgt.data_ptr() if d.nT else None
-        for i, (h, g) in enumerate(zip(heads, grads)):
+        for i, (h, lay) in enumerate(zip(heads, layouts)):
             if h.dtype not in (torch.float32, torch.bfloat16) or h.dtype != heads[0].dtype:
                 raise TypeError("YOLOv5 heads must all be fp32 or all be bf16 (arithmetic and sums are fp32 either way)")
             if h.dim() != 5 or h.shape[1] != self.na or h.shape[4] != 5 + self.nc or h.shape[2] != h.shape[3]:
                 raise ValueError(f"layer {i}: expected [B,{self.na},G,G,{5 + self.nc}], got {tuple(h.shape)}")
             l = d.layer[i]
-            l.p, l.grad, l.G = h.data_ptr(), (g.data_ptr() if g is not None else None), h.shape[2]
+            l.p, l.grad, l.G, l.layout = h.data_ptr(), None, h.shape[2], lay
             for a in range(self.na):
                 l.anchor_w[a], l.anchor_h[a] = float(self.anchors[i, a, 0]), float(self.anchors[i, a, 1])
+        return d, (tgt, heads)
+
+    def _forward(self, d, dev, need_grad):
+        L = _lib.lib()
         need = L.odpl_yolov5_loss_workspace_bytes(ctypes.byref(d))
         if need == 0:
             raise OdplError("odpl_yolov5_loss_workspace_bytes rejected the descriptor")
         if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
             self._ws = torch.empty(int(need * 1.25) + 4096, dtype=torch.uint8, device=dev)
             self._clean_key = None
-        key = (dev, torch.cuda.current_stream(dev).cuda_stream, d.B, tuple(h.shape[2] for h in heads))
-        d.flags = _lib.YOLOV5_STATE_CLEAN if self._clean_key == key else 0
-        self._clean_key = None
+        key = (dev, torch.cuda.current_stream(dev).cuda_stream, d.B, tuple(d.layer[i].G for i in range(d.nl)))
+        capturing = torch.cuda.is_current_stream_capturing()           # see losses.py: never claim STATE_CLEAN while recording
+        d.flags = _lib.YOLOV5_STATE_CLEAN if (self._clean_key == key and not capturing) else 0
+        if not capturing:
+            self._clean_key = None
+        compact = torch.empty(L.odpl_yolov5_loss_compact_bytes(ctypes.byref(d)), dtype=torch.uint8, device=dev) if need_grad else None
         out4 = torch.empty(4, dtype=torch.float32, device=dev)
         counts = torch.empty(_lib.MAX_SCALES + 1, dtype=torch.int32, device=dev)
-        _lib.check(L.odpl_yolov5_loss(ctypes.byref(d), _lib.ptr(self._ws), self._ws.numel(), _lib.ptr(out4),
-                                      _lib.ptr(counts), _lib.current_stream(dev)), "odpl_yolov5_loss")
-        self._clean_key = key
+        _lib.check(L.odpl_yolov5_loss_forward(ctypes.byref(d), _lib.ptr(self._ws), self._ws.numel(), _lib.ptr(compact),
+                                              0 if compact is None else compact.numel(), _lib.ptr(out4), _lib.ptr(counts),
+                                              _lib.current_stream(dev)), "odpl_yolov5_loss_forward")
+        if not capturing:
+            self._clean_key = key
         self.last_counts = counts
-        return out4, counts
+        self.last_compact = (d, compact)
+        return out4, counts, compact
+
+    def assignment_rows(self, layer):
+        """build_targets_v5's output for `layer` as the kernels produced it in the last differentiable forward:
+        (b, a, gj, gi) int64 [n], tbox f32 [n,4], anchor index int64 [n], target row int64 [n] (accuracy.py:472-521)."""
+        d, compact = self.last_compact
+        if compact is None:
+            raise OdplError("assignment_rows needs a forward that kept its compact gradient (requires_grad heads)")
+        rows = _lib.YoloV5Rows()
+        _lib.check(_lib.lib().odpl_yolov5_compact_view(ctypes.byref(d), _lib.ptr(compact), layer, None, ctypes.byref(rows)), "odpl_yolov5_compact_view")
+        base = compact.data_ptr()
+
+        def view(ptr, n, dtype):
+            off = ptr - base
+            return compact[off:off + n * 4].view(dtype)
+        n = int(view(rows.n_rows, 1, torch.int32)[0])
+        cell = view(rows.row_cell, rows.cap, torch.int32)[:n].long()
+        ag = view(rows.row_anchor_group, rows.cap, torch.int32)[:n].long()
+        t = view(rows.row_target, rows.cap, torch.int32)[:n].long()
+        tbox = view(rows.row_tbox, rows.cap * 4, torch.float32).view(-1, 4)[:n]
+        G = d.layer[layer].G
+        gi, gj = cell % G, (cell // G) % G
+        plane = cell // (G * G)
+        return (plane // self.na, plane % self.na, gj, gi), tbox, ag >> 4, t, cell
 
     def forward(self, output, target, seen=None):
-        loss, m, _ = _V5LossFn.apply(self, target, *output)
+        from .utils.headconv import fusable_source
+        output = list(output)
+        srcs = []
+        if self.fuse_head_backward:
+            for h in output:                                              # a head is a permuted view of a head_conv output
+                base = getattr(h, "_odpl_head_base", None)
+                src = fusable_source(base) if base is not None else None
+                srcs.append(src if (src is not None and _v5_layout(h)[1] == _lib.LAYOUT_PLANAR and h.data_ptr() == base.data_ptr()) else None)
+        if srcs and all(s is not None for s in srcs):
+            flat = [t for s in srcs for t in s]
+            loss, m, _ = _V5LossHeadFn.apply(self, target, len(output), *[h.detach() for h in output], *flat)
+        else:
+            loss, m, _ = _V5LossFn.apply(self, target, *output)
         return {"loss": loss, "Localization": m[0], "Classification": m[1], "Conf_obj": m[2]}
 
 

@@ -78,7 +78,13 @@ class Image(ctypes.Structure):
 
 class YoloV5Layer(ctypes.Structure):
     _fields_ = [("p", c_void_p), ("grad", c_void_p), ("G", c_int32),
-                ("anchor_w", c_float * MAX_ANCHORS), ("anchor_h", c_float * MAX_ANCHORS)]
+                ("anchor_w", c_float * MAX_ANCHORS), ("anchor_h", c_float * MAX_ANCHORS), ("layout", c_int32)]
+
+
+class YoloV5Rows(ctypes.Structure):
+    """odpl_yolov5_rows_t"""
+    _fields_ = [("row_target", c_void_p), ("row_anchor_group", c_void_p), ("row_cell", c_void_p), ("row_tbox", c_void_p),
+                ("n_rows", c_void_p), ("cap", c_int32)]
 
 
 class YoloV5LossDesc(ctypes.Structure):
@@ -125,6 +131,10 @@ SIGNATURES = {
     "odpl_yolo_decode": (c_int32, [POINTER(YoloDecodeDesc), c_void_p, c_void_p, c_void_p]),
     "odpl_yolov5_loss_workspace_bytes": (c_size_t, [POINTER(YoloV5LossDesc)]),
     "odpl_yolov5_loss": (c_int32, [POINTER(YoloV5LossDesc), c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "odpl_yolov5_loss_compact_bytes": (c_size_t, [POINTER(YoloV5LossDesc)]),
+    "odpl_yolov5_loss_forward": (c_int32, [POINTER(YoloV5LossDesc), c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "odpl_yolov5_loss_backward": (c_int32, [POINTER(YoloV5LossDesc), c_void_p, c_size_t, c_void_p, c_void_p]),
+    "odpl_yolov5_compact_view": (c_int32, [POINTER(YoloV5LossDesc), c_void_p, c_int32, POINTER(SparseGrad), POINTER(YoloV5Rows)]),
     "odpl_ssd_loss_workspace_bytes": (c_size_t, [POINTER(SsdLossDesc)]),
     "odpl_ssd_loss": (c_int32, [POINTER(SsdLossDesc), c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "odpl_debug_set_stamp_buffer": (c_int32, [c_void_p]),
@@ -219,7 +229,7 @@ def tune_set(name, value):
 
 
 PROF_IDS = {"yolo_expand": 0, "yolo_assign": 1, "yolo_loss": 2, "yolo_finalize": 3, "retina_assign": 4, "retina_main": 5,
-            "yolo_nms_prep": 6, "yolo_nms_image": 7, "greedy_nms_prep": 8, "greedy_nms_image": 9, "yolo_decode": 10, "yolov5_dense": 11, "headgrad_stream": 12, "headgrad_finish": 13, "yolo_patch": 14}
+            "yolo_nms_prep": 6, "yolo_nms_image": 7, "greedy_nms_prep": 8, "greedy_nms_image": 9, "yolo_decode": 10, "yolov5_dense": 11, "headgrad_stream": 12, "headgrad_finish": 13, "yolo_patch": 14, "yolov5_obj": 15}
 
 
 def profile_enable(name, on=True):

@@ -1,23 +1,31 @@
 // YOLOv5 loss for MI355X (gfx950): build_targets_v5 (accuracy.py:472-521) + MultiScaleRegionLoss_v5.forward
 // (losses.py:98-156) with FocalLoss (losses.py:37-64) and bbox_iou_v5 in IoU/GIoU/DIoU/CIoU mode
-// (accuracy.py:71-114), forward AND d loss/d p for a unit upstream gradient.
+// (accuracy.py:71-114), forward AND d loss/d p.
 //
-// Layout: p[i] is [B, na, G, G, no] (channel-LAST, what Yolo_Layers.forward hands the criterion,
-// YOLOV5.py:93-97): a cell's no = 5+nc logits are 4*no contiguous bytes.  Heads and their gradients may be bf16
-// (desc.bf16: BASELINE config 5 trains under bf16 autocast): loads widen to fp32, every sum stays fp32, the gradient
-// stream packs 8 bf16 per 16-B store.
+// Layout: p[i] is the [B, na, G, G, no] tensor Yolo_Layers.forward hands the criterion (YOLOV5.py:93-97) in either memory
+// format -- both use the cell index (b*na + a)*G*G + s:
+//   interleaved  contiguous [B,na,G,G,no]: element (cell, c) at cell*no + c            (the reference's permute().contiguous())
+//   planar       the Detect convolution's own NCHW output viewed as [B,na,no,G,G]:     element at ((cell/G2)*no + c)*G2 + cell%G2
+//                -- the permute is a VIEW, no copy is made, and the objectness logits are contiguous planes
+// Heads and their gradients may be bf16 (desc.bf16: BASELINE config 5 trains under bf16 autocast): loads widen to fp32,
+// every sum stays fp32, gradients are rounded once.
 //
+// Like the v2/v3/v4 region loss the gradient is STRUCTURED: one dense value per cell (the objectness logit) + `no` values on
+// each matched row.  forward leaves it compact (gobj[cells], row_grad[rows, no], row_cell[rows]):
 //   assign (1 WG / layer)  ratio test < 4, 'rect4' neighbour expansion, rows in the reference's order
 //                          [base | x-1 | y-1 | x+1 | y+1] by ballot/popcount compaction; owner map
 //                          atomicMax(row) => "last row wins" for tobj (and marks each cell's leader row)
-//   rows   (1 wave / row)  coalesced 4*no-byte gather of the cell, box decode, IoU-family value AND its
-//                          gradient by forward-mode differentiation (4 tangents), focal-BCE over the classes
-//   dense  (chunks)        per chunk: objectness focal-BCE(x, tobj) of its <= 194 cells up front (gathers -> LDS), then
-//                          a pure 16-B store stream over the gradient tensor; owner map reset
-//                          [HBM-write bound: the roofline kernel of config 5]
+//   rows   (1 wave / row)  the cell's no logits, box decode, IoU-family value AND its gradient by forward-mode
+//                          differentiation (4 tangents), focal-BCE over the classes -> row_grad
+//   obj    (thread = cell) objectness focal-BCE(x, tobj) value + gobj[cell]; owner map reset.  planar: the logits are
+//                          contiguous planes (coalesced, no over-fetch); interleaved: one request per cell
+//   finalize (1 WG)        fixed-order sums -> lbox*0.05 + lobj*1.0 + lcls*0.58
+// backward: a 1x1-convolution producer consumes the compact form directly (odpl_headgrad.hip, no dense tensor); any other
+// producer gets the dense d loss/d p:
+//   expand (chunks)        pure 16-B non-temporal store stream over the gradient tensor (zeros + gobj in the objectness
+//                          slots), scaled by the upstream scalar           [HBM-write bound]
 //   cells  (1 wave / row)  leader rows add the row gradients of all rows that share their cell, ascending row
 //                          order (index_put accumulate semantics, deterministic), over the zeros
-//   finalize (1 WG)        fixed-order sums -> lbox*0.05 + lobj*1.0 + lcls*0.58
 #include <hip/hip_bf16.h>
 #include "odpl_common.hpp"
 #include "odpl_yolo_dev.hpp"
@@ -32,7 +40,10 @@ constexpr int kChunkF4 = 4096;        // float4 per dense workgroup
 
 struct Layer {
     const void* p; void* grad;        // fp32 or bf16 (VParams.bf16): loads widen to fp32, sums stay fp32, the gradient is rounded once
-    int G, cells;                     // cells = B*na*G*G
+    int G, G2, cells, layout;         // cells = B*na*G*G; layout: ODPL_LAYOUT_*
+    float* gobj;                      // [cells] compact objectness gradient (NULL: forward only)
+    float* row_tbox;                  // [cap*4] tbox of every row (aux output for the index-parity tests; may be NULL)
+    unsigned long long inv_g2;        // ceil(2^40 / G2)
     float aw[ODPL_MAX_ANCHORS], ah[ODPL_MAX_ANCHORS];
     int* owner;                       // [cells]  -1 clean; max row index that maps here
     int* row_t; int* row_ag;          // [cap] target row ; (a << 4) | group
@@ -52,6 +63,7 @@ struct VParams {
     Layer L[ODPL_MAX_SCALES];
     const float* target;
     int nl, B, na, nc, no, nT, cap, iou_mode, want_grad, bf16;
+    const float* upstream;            // device scalar (backward) or NULL = 1
     int* status;
     float* out4; int* out_counts;
 };
@@ -117,6 +129,7 @@ __global__ __launch_bounds__(kAT) void v5_assign_kernel(const VParams P) {
         const int cell = S.row_cell[r];
         S.row_lead[r] = (cell >= 0 && __hip_atomic_load(&S.owner[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == r) ? 1 : 0;
     }
+    for (int r = n + tid; r < P.cap; r += kAT) { S.row_cell[r] = -1; S.row_lead[r] = 0; }      // consumers of the compact form see "no row"
     if (tid == 0) { S.nrows[0] = n; if (bad) atomicOr(&P.status[0], 1); }
 }
 
@@ -129,6 +142,12 @@ __device__ __forceinline__ void st_grad(void* p, size_t i, float v, int bf16) {
     if (bf16) reinterpret_cast<__hip_bfloat16*>(p)[i] = __float2bfloat16(v); else reinterpret_cast<float*>(p)[i] = v;
 }
 __device__ __forceinline__ unsigned short bf16_bits(float v) { const __hip_bfloat16 h = __float2bfloat16(v); return *reinterpret_cast<const unsigned short*>(&h); }
+
+// element offset of (cell, channel c) in the head / gradient tensor
+__device__ __forceinline__ size_t elem_off(const Layer& S, int no, int cell, int c) {
+    if (S.layout == ODPL_LAYOUT_PLANAR) { const int plane = cell / S.G2, s = cell - plane * S.G2; return ((size_t)plane * no + c) * S.G2 + s; }
+    return (size_t)cell * no + c;
+}
 
 struct D4 { float v; float d[4]; };
 __device__ __forceinline__ D4 dconst(float c) { D4 r; r.v = c; r.d[0] = r.d[1] = r.d[2] = r.d[3] = 0.f; return r; }
@@ -199,11 +218,11 @@ __global__ __launch_bounds__(64) void v5_rows_kernel(const VParams P) {
     if (cell < 0) {
         for (int k = lane; k < no; k += 64) rg[k] = 0.f;
         if (lane == 0) { S.row_iou[r] = 0.f; S.row_part[r * 2] = 0.f; S.row_part[r * 2 + 1] = 0.f; }
+        if (S.row_tbox && lane < 4) S.row_tbox[(size_t)r * 4 + lane] = 0.f;
         return;
     }
     const int t = S.row_t[r], ag = S.row_ag[r], a = ag >> 4, grp = ag & 15;
-    const size_t pb = (size_t)cell * no;
-    auto ps = [&](int k) { return ld_head(S.p, pb + k, P.bf16); };
+    auto ps = [&](int k) { return ld_head(S.p, elem_off(S, no, cell, k), P.bf16); };
     const float* y = P.target + (size_t)t * 6;
     const float fG = (float)S.G, fn = (float)n;
     // ---- box (lane 0): losses.py:115-119, accuracy.py:512-517
@@ -212,6 +231,7 @@ __global__ __launch_bounds__(64) void v5_rows_kernel(const VParams P) {
         const float ox = grp == 1 ? 0.5f : (grp == 3 ? -0.5f : 0.0f), oy = grp == 2 ? 0.5f : (grp == 4 ? -0.5f : 0.0f);
         const float gi = (float)trunc_ll(gx - ox), gj = (float)trunc_ll(gy - oy);
         const float tx = gx - gi, ty = gy - gj;                     // tbox = (gxy - gij, gwh)
+        if (S.row_tbox) { float* tb = S.row_tbox + (size_t)r * 4; tb[0] = tx; tb[1] = ty; tb[2] = gw; tb[3] = gh; }
         const float s0 = sigmoidf_(ps(0)), s1 = sigmoidf_(ps(1)), s2 = sigmoidf_(ps(2)), s3 = sigmoidf_(ps(3));
         const float px = s0 * 2.0f - 0.5f, py = s1 * 2.0f - 0.5f;
         const float u2 = s2 * 2.0f, u3 = s3 * 2.0f;
@@ -246,42 +266,26 @@ __global__ __launch_bounds__(64) void v5_rows_kernel(const VParams P) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// dense pass: a workgroup owns a contiguous chunk of kChunkF4 float4 of the gradient tensor.
-//   phase 1: the <= 194 cells whose objectness element falls in the chunk are handled by one thread each:
-//            gather x (stride 4*no bytes), owner row, its IoU -> focal-BCE(x, tobj) value and gradient into LDS;
-//            owner map reset.  All loads are issued up front, in parallel.
-//   phase 2: pure store stream: every quad is ONE 16-byte non-temporal store; a quad that contains a cell's
-//            objectness element takes that element from LDS.  No load sits in the store stream and no partial
-//            (dword) store is issued, so the fill runs at the HBM write ceiling.
-template <bool GRAD, bool BF16>
-__global__ __launch_bounds__(kDT) void v5_dense_kernel(const VParams P) {
-    constexpr int EPQ = BF16 ? 8 : 4;                        // elements per 16-byte quad
+// obj pass: thread = cell.  objectness focal-BCE against tobj (the clamped IoU of the cell's owner row, 0 elsewhere),
+// its gradient into the compact gobj, owner map reset.
+__global__ __launch_bounds__(kDT) void v5_obj_kernel(const VParams P) {
     __shared__ float sh[kDT / 64];
-    __shared__ float s_g[kChunkF4 * 8 / 6 + 3];              // cells per chunk at the smallest row (no = 6), bf16 quads
     const int tid = threadIdx.x;
     int li = 0;
-    for (int i = 0; i < P.nl; ++i) if ((int)blockIdx.x >= P.L[i].dense_blk0) li = i;
+    for (int i = 0; i < P.nl; ++i) if ((int)blockIdx.x >= P.L[i].conf_blk0) li = i;
     const Layer& S = P.L[li];
-    const unsigned no = (unsigned)P.no;
-    const size_t total = (size_t)S.cells * no, totalq = total / EPQ;
-    const size_t q0 = (size_t)(blockIdx.x - S.dense_blk0) * kChunkF4;
-    const bool last = (q0 + kChunkF4) >= totalq;
-    const size_t q1 = last ? totalq : (q0 + kChunkF4);
-    const size_t e0 = q0 * EPQ, e1 = last ? total : q1 * EPQ; // the last chunk also owns the < EPQ tail elements
-    const unsigned c_lo = e0 <= 4 ? 0u : (unsigned)((e0 - 4 + no - 1) / no);
-    const int n_loc = e1 >= 5 ? (int)((e1 - 5) / no) - (int)c_lo + 1 : 0;        // cells with e0 <= no*c+4 < e1
-    float acc = 0.f;
+    const int c = (blockIdx.x - S.conf_blk0) * kDT + tid;
     const int nrows_now = S.nrows[0];                         // rows the assign kernel of THIS call produced
-    for (int i = tid; i < n_loc; i += kDT) {                  // one pass at no = 85 fp32 (<= 194 cells per chunk)
-        const unsigned c = c_lo + i;
+    float acc = 0.f;
+    if (c < S.cells) {
         int ow = S.owner[c];
         if (ow >= nrows_now) { atomicOr(P.status, 4); S.owner[c] = -1; ow = -1; }   // a dirty map (broken STATE_CLEAN promise) never indexes the row arrays
-        const float tobj = ow >= 0 ? fmaxf(S.row_iou[ow], 0.0f) : 0.0f;         // losses.py:123 (gr = 1)
+        const float tobj = ow >= 0 ? fmaxf(S.row_iou[ow], 0.0f) : 0.0f;             // losses.py:123 (gr = 1)
         float l, dx;
-        focal_bce(ld_head(S.p, (size_t)c * no + 4, BF16), tobj, l, dx);
-        acc += l;
-        s_g[i] = dx * (1.0f / (float)S.cells);                // mean over all cells, gain 1.0 (losses.py:135,138)
-        if (ow >= 0) S.owner[c] = -1;                         // leave the map clean
+        focal_bce(ld_head(S.p, elem_off(S, P.no, c, 4), P.bf16), tobj, l, dx);
+        acc = l;
+        if (S.gobj) S.gobj[c] = dx * (1.0f / (float)S.cells);                       // mean over all cells, gain 1.0 (losses.py:135,138)
+        if (ow >= 0) S.owner[c] = -1;                                               // leave the map clean
     }
     acc = wave_sum(acc);
     if ((tid & 63) == 0) sh[tid >> 6] = acc;
@@ -289,35 +293,84 @@ __global__ __launch_bounds__(kDT) void v5_dense_kernel(const VParams P) {
     if (tid == 0) {
         float a = 0.f;
         for (int w = 0; w < kDT / 64; ++w) a += sh[w];
-        S.dense_part[blockIdx.x - S.dense_blk0] = a;
+        S.dense_part[blockIdx.x - S.conf_blk0] = a;
     }
-    if (!GRAD) return;
+}
+
+// ---------------------------------------------------------------------------------------------
+// expand: the dense d loss/d p for a generic producer.  A workgroup owns a contiguous chunk of kChunkF4 16-byte quads of the
+// gradient tensor; every quad is ONE non-temporal store (zeros, with gobj * upstream in the objectness slots).
+template <bool BF16>
+__global__ __launch_bounds__(kDT) void v5_expand_kernel(const VParams P) {
+    constexpr int EPQ = BF16 ? 8 : 4;                        // elements per 16-byte quad
+    const int tid = threadIdx.x;
+    int li = 0;
+    for (int i = 0; i < P.nl; ++i) if ((int)blockIdx.x >= P.L[i].dense_blk0) li = i;
+    const Layer& S = P.L[li];
+    const float f = P.upstream ? *P.upstream : 1.0f;
+    const unsigned no = (unsigned)P.no, G2 = (unsigned)S.G2;
+    const size_t total = (size_t)S.cells * no, totalq = total / EPQ;
+    const size_t q0 = (size_t)(blockIdx.x - S.dense_blk0) * kChunkF4;
+    const bool last = (q0 + kChunkF4) >= totalq;
+    const size_t q1 = last ? totalq : (q0 + kChunkF4);
+    // value of element e: gobj of its cell if it is an objectness slot, else 0
+    auto elem = [&](size_t e) -> float {
+        if (S.layout == ODPL_LAYOUT_PLANAR) {
+            const unsigned row = (unsigned)(((unsigned long long)e * S.inv_g2) >> 40), s = (unsigned)e - row * G2;
+            const unsigned plane = (unsigned)(((unsigned long long)row * S.inv_no) >> 40);
+            return (row - plane * no == 4u) ? S.gobj[(size_t)plane * G2 + s] * f : 0.f;
+        }
+        const unsigned c = (unsigned)(((unsigned long long)e * S.inv_no) >> 40);
+        return ((unsigned)e - c * no == 4u) ? S.gobj[c] * f : 0.f;
+    };
     v4f* g4 = reinterpret_cast<v4f*>(S.grad);
     for (size_t q = q0 + tid; q < q1; q += kDT) {
-        const unsigned e = (unsigned)(q * EPQ);
-        const unsigned c = (unsigned)(((unsigned long long)e * S.inv_no) >> 40);
-        const unsigned r = e - c * no;
-        if (!BF16) {
-            v4f o = {0.f, 0.f, 0.f, 0.f};
-            if (r >= 1u && r <= 4u) o[4 - r] = s_g[c - c_lo];      // this quad holds cell c's objectness element
-            __builtin_nontemporal_store(o, g4 + q);
+        const size_t e = q * EPQ;
+        float v[EPQ];
+        bool any = false;
+        if (S.layout == ODPL_LAYOUT_PLANAR) {
+            // a quad inside one row: either all objectness (row % no == 4) or all zero
+            const unsigned row = (unsigned)(((unsigned long long)e * S.inv_g2) >> 40), s = (unsigned)e - row * G2;
+            if (s + EPQ <= G2) {
+                const unsigned plane = (unsigned)(((unsigned long long)row * S.inv_no) >> 40);
+                if (row - plane * no == 4u) {
+                    any = true;
+                    const float* src = S.gobj + (size_t)plane * G2 + s;
+#pragma unroll
+                    for (int k = 0; k < EPQ; ++k) v[k] = src[k] * f;
+                }
+            } else {
+                any = true;
+#pragma unroll
+                for (int k = 0; k < EPQ; ++k) v[k] = elem(e + k);
+            }
         } else {
-            // 8 bf16 per quad: it can hold cell c's objectness (offset 4 - r) and/or cell c+1's (offset no + 4 - r)
-            unsigned short h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (r <= 4u) h[4 - r] = bf16_bits(s_g[c - c_lo]);
-            const unsigned k2 = no + 4u - r;
-            if (k2 < 8u && (size_t)(c + 1) < (size_t)S.cells) h[k2] = bf16_bits(s_g[c + 1 - c_lo]);
-            v4f o;
-            unsigned* ob = reinterpret_cast<unsigned*>(&o);
-            ob[0] = h[0] | ((unsigned)h[1] << 16); ob[1] = h[2] | ((unsigned)h[3] << 16);
-            ob[2] = h[4] | ((unsigned)h[5] << 16); ob[3] = h[6] | ((unsigned)h[7] << 16);
-            __builtin_nontemporal_store(o, g4 + q);
+            const unsigned c = (unsigned)(((unsigned long long)e * S.inv_no) >> 40);
+            const unsigned r = (unsigned)e - c * no;
+            // the quad can hold cell c's objectness slot (offset 4 - r) and, with 8 elements, cell c+1's (offset no + 4 - r)
+            if (r <= 4u || r + EPQ > no + 4u) {
+                any = true;
+#pragma unroll
+                for (int k = 0; k < EPQ; ++k) v[k] = 0.f;
+                if (r <= 4u && 4u - r < (unsigned)EPQ) v[4 - r] = S.gobj[c] * f;
+                const unsigned k2 = no + 4u - r;
+                if (k2 < (unsigned)EPQ && (size_t)(c + 1) < (size_t)S.cells) v[k2] = S.gobj[c + 1] * f;
+            }
         }
+        v4f o = {0.f, 0.f, 0.f, 0.f};
+        if (any) {
+            if (!BF16) { o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3]; }
+            else {
+                unsigned* ob = reinterpret_cast<unsigned*>(&o);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) ob[k] = bf16_bits(v[2 * k]) | ((unsigned)bf16_bits(v[2 * k + 1]) << 16);
+            }
+        }
+        __builtin_nontemporal_store(o, g4 + q);
     }
     if (last && (size_t)tid < total - totalq * EPQ) {         // < EPQ tail elements of the layer
         const size_t e = totalq * EPQ + tid;
-        const unsigned c = (unsigned)(e / no);
-        st_grad(S.grad, e, (e - (size_t)c * no) == 4 ? s_g[c - c_lo] : 0.f, BF16);
+        st_grad(S.grad, e, elem(e), BF16);
     }
 }
 
@@ -328,6 +381,7 @@ __global__ __launch_bounds__(64) void v5_cells_kernel(const VParams P) {
     const int n = S.nrows[0];
     if (r >= n || !S.row_lead[r]) return;
     const int cell = S.row_cell[r];
+    const float f = P.upstream ? *P.upstream : 1.0f;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;             // lane handles channels lane, lane+64, +128, +192
     for (int base = 0; base < n; base += 64) {
         const int rr = base + lane;
@@ -342,11 +396,10 @@ __global__ __launch_bounds__(64) void v5_cells_kernel(const VParams P) {
             if (lane + 192 < no) a3 += g[lane + 192];
         }
     }
-    const size_t db = (size_t)cell * no;
-    if (lane < no && lane != 4) st_grad(S.grad, db + lane, a0, P.bf16);
-    if (lane + 64 < no) st_grad(S.grad, db + lane + 64, a1, P.bf16);
-    if (lane + 128 < no) st_grad(S.grad, db + lane + 128, a2, P.bf16);
-    if (lane + 192 < no) st_grad(S.grad, db + lane + 192, a3, P.bf16);
+    if (lane < no && lane != 4) st_grad(S.grad, elem_off(S, no, cell, lane), a0 * f, P.bf16);
+    if (lane + 64 < no) st_grad(S.grad, elem_off(S, no, cell, lane + 64), a1 * f, P.bf16);
+    if (lane + 128 < no) st_grad(S.grad, elem_off(S, no, cell, lane + 128), a2 * f, P.bf16);
+    if (lane + 192 < no) st_grad(S.grad, elem_off(S, no, cell, lane + 192), a3 * f, P.bf16);
 }
 
 __global__ __launch_bounds__(256) void v5_finalize_kernel(const VParams P) {
@@ -360,7 +413,7 @@ __global__ __launch_bounds__(256) void v5_finalize_kernel(const VParams P) {
         const int n = S.nrows[0];
         double a = 0, b = 0, c = 0;
         for (int r = tid; r < n; r += 256) { a += (double)S.row_part[r * 2]; b += (double)S.row_part[r * 2 + 1]; }
-        for (int i = tid; i < S.dense_nblk; i += 256) c += (double)S.dense_part[i];
+        for (int i = tid; i < S.conf_nblk; i += 256) c += (double)S.dense_part[i];
         for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); b += __shfl_down(b, o, 64); c += __shfl_down(c, o, 64); }
         if ((tid & 63) == 0) { sh[(tid >> 6) * 3] = a; sh[(tid >> 6) * 3 + 1] = b; sh[(tid >> 6) * 3 + 2] = c; }
         __syncthreads();
@@ -387,10 +440,13 @@ __global__ __launch_bounds__(256) void v5_finalize_kernel(const VParams P) {
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct VPlan {
-    size_t status, owner[ODPL_MAX_SCALES], row_t[ODPL_MAX_SCALES], row_ag[ODPL_MAX_SCALES], row_cell[ODPL_MAX_SCALES],
-        row_lead[ODPL_MAX_SCALES], row_iou[ODPL_MAX_SCALES], row_part[ODPL_MAX_SCALES], row_grad[ODPL_MAX_SCALES],
-        nrows[ODPL_MAX_SCALES], dense_part[ODPL_MAX_SCALES];
-    size_t owner_bytes_total, total;
+    // workspace: persistent owner maps + per-call scratch
+    size_t status, owner[ODPL_MAX_SCALES], row_t[ODPL_MAX_SCALES], row_ag[ODPL_MAX_SCALES], row_iou[ODPL_MAX_SCALES],
+        row_part[ODPL_MAX_SCALES], dense_part[ODPL_MAX_SCALES];
+    // compact gradient (survives until backward; lives at the workspace's tail in a forward-only / one-call use)
+    size_t gobj[ODPL_MAX_SCALES], row_grad[ODPL_MAX_SCALES], row_cell[ODPL_MAX_SCALES], row_lead[ODPL_MAX_SCALES],
+        row_tbox[ODPL_MAX_SCALES], nrows[ODPL_MAX_SCALES], crow_t[ODPL_MAX_SCALES], crow_ag[ODPL_MAX_SCALES];
+    size_t owner_bytes_total, ws_total, compact_total;
     int dense_nblk[ODPL_MAX_SCALES], conf_nblk[ODPL_MAX_SCALES], cap, no;
 };
 
@@ -402,70 +458,74 @@ bool make_vplan(const odpl_yolov5_loss_desc_t* d, VPlan* p) {
     p->cap = 5 * d->na * (d->nT > 0 ? d->nT : 1);
     size_t off = 0;
     p->status = off; off += 256;
-    for (int i = 0; i < d->nl; ++i) {            // owner maps first, contiguous: one memset(0xFF) when not clean
+    for (int i = 0; i < d->nl; ++i) {            // owner maps first, contiguous: one fill(0xFF) when not clean
         const odpl_yolov5_layer_t& l = d->layer[i];
         if (!l.p || l.G < 1) return false;
+        if (l.layout != ODPL_LAYOUT_PLANAR && l.layout != ODPL_LAYOUT_INTERLEAVED) return false;
         const long long cells = (long long)d->B * d->na * l.G * l.G;
-        if (cells * p->no > 0xfffffff0LL) return false;
+        if (cells * p->no > 0x7ffffff0LL) return false;
         p->owner[i] = off; off += align_up((size_t)cells * 4, 256);
     }
     p->owner_bytes_total = off - 256;
+    size_t coff = 0;
     for (int i = 0; i < d->nl; ++i) {
         const size_t cap = (size_t)p->cap;
         const long long cells = (long long)d->B * d->na * d->layer[i].G * d->layer[i].G;
         p->dense_nblk[i] = (int)(((size_t)cells * p->no / (d->bf16 ? 8 : 4) + kChunkF4 - 1) / kChunkF4); if (p->dense_nblk[i] < 1) p->dense_nblk[i] = 1;
         p->conf_nblk[i] = (int)((cells + kDT - 1) / kDT);
-        p->row_t[i] = off;    off += align_up(cap * 4, 256);
-        p->row_ag[i] = off;   off += align_up(cap * 4, 256);
-        p->row_cell[i] = off; off += align_up(cap * 4, 256);
-        p->row_lead[i] = off; off += align_up(cap * 4, 256);
         p->row_iou[i] = off;  off += align_up(cap * 4, 256);
         p->row_part[i] = off; off += align_up(cap * 8, 256);
-        p->row_grad[i] = off; off += align_up(cap * p->no * 4, 256);
-        p->nrows[i] = off;    off += 256;
-        p->dense_part[i] = off; off += align_up((size_t)p->dense_nblk[i] * 4, 256);
+        p->dense_part[i] = off; off += align_up((size_t)p->conf_nblk[i] * 4, 256);
+        p->gobj[i] = coff;     coff += align_up((size_t)cells * 4, 256);
+        p->row_grad[i] = coff; coff += align_up(cap * p->no * 4, 256);
+        p->row_cell[i] = coff; coff += align_up(cap * 4, 256);
+        p->row_lead[i] = coff; coff += align_up(cap * 4, 256);
+        p->row_tbox[i] = coff; coff += align_up(cap * 16, 256);
+        p->crow_t[i] = coff;   coff += align_up(cap * 4, 256);
+        p->crow_ag[i] = coff;  coff += align_up(cap * 4, 256);
+        p->nrows[i] = coff;    coff += 256;
     }
-    p->total = off;
+    p->ws_total = off;
+    p->compact_total = coff;
     return true;
 }
-}  // namespace
 
-extern "C" size_t odpl_yolov5_loss_workspace_bytes(const odpl_yolov5_loss_desc_t* d) {
-    VPlan p;
-    return make_vplan(d, &p) ? p.total : 0;
-}
-
-extern "C" int odpl_yolov5_loss(const odpl_yolov5_loss_desc_t* d, void* workspace, size_t workspace_bytes,
-                                float* out4, int32_t* out_counts, void* stream_) {
-    VPlan pl;
-    if (!make_vplan(d, &pl) || !workspace || workspace_bytes < pl.total || !out4) return ODPL_EINVAL;
-    if ((uintptr_t)workspace & 15) return ODPL_EINVAL;
-    hipStream_t stream = (hipStream_t)stream_;
-    char* ws = (char*)workspace;
-    VParams P;
+int fill_params(const odpl_yolov5_loss_desc_t* d, const VPlan& pl, char* ws, char* compact, VParams* out) {
+    VParams& P = *out;
     P.target = d->target; P.nl = d->nl; P.B = d->B; P.na = d->na; P.nc = d->nc; P.no = pl.no; P.nT = d->nT; P.cap = pl.cap;
     P.bf16 = d->bf16 ? 1 : 0;
-    P.iou_mode = d->iou_mode; P.status = (int*)(ws + pl.status); P.out4 = out4; P.out_counts = out_counts;
-    int blk = 0, want = 0;
+    P.iou_mode = d->iou_mode; P.status = ws ? (int*)(ws + pl.status) : nullptr; P.out4 = nullptr; P.out_counts = nullptr;
+    P.upstream = nullptr; P.want_grad = 0;
+    int dblk = 0, cblk = 0;
     for (int i = 0; i < d->nl; ++i) {
         const odpl_yolov5_layer_t& l = d->layer[i];
         Layer& S = P.L[i];
         if (((uintptr_t)l.p | (uintptr_t)l.grad) & 15) return ODPL_EINVAL;
-        S.p = l.p; S.grad = l.grad; S.G = l.G; S.cells = d->B * d->na * l.G * l.G;
+        S.p = l.p; S.grad = l.grad; S.G = l.G; S.G2 = l.G * l.G; S.cells = d->B * d->na * l.G * l.G; S.layout = l.layout;
         for (int a = 0; a < ODPL_MAX_ANCHORS; ++a) { S.aw[a] = l.anchor_w[a]; S.ah[a] = l.anchor_h[a]; }
-        S.owner = (int*)(ws + pl.owner[i]); S.row_t = (int*)(ws + pl.row_t[i]); S.row_ag = (int*)(ws + pl.row_ag[i]);
-        S.row_cell = (int*)(ws + pl.row_cell[i]); S.row_lead = (int*)(ws + pl.row_lead[i]);
-        S.row_iou = (float*)(ws + pl.row_iou[i]); S.row_part = (float*)(ws + pl.row_part[i]);
-        S.row_grad = (float*)(ws + pl.row_grad[i]); S.nrows = (int*)(ws + pl.nrows[i]);
-        S.dense_part = (float*)(ws + pl.dense_part[i]);
-        S.conf_blk0 = 0; S.conf_nblk = 0;
-        S.dense_blk0 = blk; S.dense_nblk = pl.dense_nblk[i]; blk += S.dense_nblk;
+        if (ws) {
+            S.owner = (int*)(ws + pl.owner[i]); S.row_iou = (float*)(ws + pl.row_iou[i]); S.row_part = (float*)(ws + pl.row_part[i]);
+            S.dense_part = (float*)(ws + pl.dense_part[i]);
+        } else { S.owner = nullptr; S.row_iou = nullptr; S.row_part = nullptr; S.dense_part = nullptr; }
+        S.gobj = (float*)(compact + pl.gobj[i]); S.row_grad = (float*)(compact + pl.row_grad[i]);
+        S.row_cell = (int*)(compact + pl.row_cell[i]); S.row_lead = (int*)(compact + pl.row_lead[i]);
+        S.row_tbox = (float*)(compact + pl.row_tbox[i]); S.nrows = (int*)(compact + pl.nrows[i]);
+        S.row_t = (int*)(compact + pl.crow_t[i]); S.row_ag = (int*)(compact + pl.crow_ag[i]);
+        S.conf_blk0 = cblk; S.conf_nblk = pl.conf_nblk[i]; cblk += S.conf_nblk;
+        S.dense_blk0 = dblk; S.dense_nblk = pl.dense_nblk[i]; dblk += S.dense_nblk;
         S.inv_no = ((1ull << 40) + (unsigned long long)pl.no - 1ull) / (unsigned long long)pl.no;
-        if (l.grad) want++;
+        S.inv_g2 = ((1ull << 40) + (unsigned long long)S.G2 - 1ull) / (unsigned long long)S.G2;
     }
-    if (want != 0 && want != d->nl) return ODPL_EINVAL;
-    P.want_grad = want ? 1 : 0;
+    return 0;
+}
 
+int v5_forward(const odpl_yolov5_loss_desc_t* d, const VPlan& pl, char* ws, char* compact, float* out4, int32_t* out_counts, hipStream_t stream) {
+    VParams P;
+    const int rc = fill_params(d, pl, ws, compact, &P);
+    if (rc) return rc;
+    P.out4 = out4; P.out_counts = out_counts;
+    int cblk = 0;
+    for (int i = 0; i < d->nl; ++i) cblk += P.L[i].conf_nblk;
     if (!(d->flags & ODPL_YOLOV5_STATE_CLEAN)) {
         ODPL_HIP_TRY(odpl::fill_bytes(ws + pl.status, 0, 256, stream));
         ODPL_HIP_TRY(odpl::fill_bytes(ws + 256, 0xFF, pl.owner_bytes_total, stream));
@@ -476,21 +536,103 @@ extern "C" int odpl_yolov5_loss(const odpl_yolov5_loss_desc_t* d, void* workspac
         hipLaunchKernelGGL(v5_rows_kernel, dim3(pl.cap, d->nl), dim3(64), 0, stream, P);
         ODPL_HIP_TRY(hipGetLastError());
     }
+    prof_begin(ODPL_PROF_YOLOV5_OBJ, stream);
+    hipLaunchKernelGGL(v5_obj_kernel, dim3(cblk), dim3(kDT), 0, stream, P);
+    prof_end(ODPL_PROF_YOLOV5_OBJ, stream);
+    ODPL_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(v5_finalize_kernel, dim3(1), dim3(256), 0, stream, P);
+    ODPL_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int v5_backward(const odpl_yolov5_loss_desc_t* d, const VPlan& pl, char* compact, const float* upstream, hipStream_t stream) {
+    VParams P;
+    const int rc = fill_params(d, pl, nullptr, compact, &P);
+    if (rc) return rc;
+    int want = 0, dblk = 0;
+    for (int i = 0; i < d->nl; ++i) { if (d->layer[i].grad) want++; dblk += P.L[i].dense_nblk; }
+    if (want == 0) return 0;
+    if (want != d->nl) return ODPL_EINVAL;
+    P.upstream = upstream; P.want_grad = 1;
     prof_begin(ODPL_PROF_YOLOV5_DENSE, stream);
-    if (P.bf16) {
-        if (P.want_grad) hipLaunchKernelGGL((v5_dense_kernel<true, true>), dim3(blk), dim3(kDT), 0, stream, P);
-        else hipLaunchKernelGGL((v5_dense_kernel<false, true>), dim3(blk), dim3(kDT), 0, stream, P);
-    } else {
-        if (P.want_grad) hipLaunchKernelGGL((v5_dense_kernel<true, false>), dim3(blk), dim3(kDT), 0, stream, P);
-        else hipLaunchKernelGGL((v5_dense_kernel<false, false>), dim3(blk), dim3(kDT), 0, stream, P);
-    }
+    if (P.bf16) hipLaunchKernelGGL((v5_expand_kernel<true>), dim3(dblk), dim3(kDT), 0, stream, P);
+    else hipLaunchKernelGGL((v5_expand_kernel<false>), dim3(dblk), dim3(kDT), 0, stream, P);
     prof_end(ODPL_PROF_YOLOV5_DENSE, stream);
     ODPL_HIP_TRY(hipGetLastError());
-    if (d->nT > 0 && P.want_grad) {
+    if (d->nT > 0) {
         hipLaunchKernelGGL(v5_cells_kernel, dim3(pl.cap, d->nl), dim3(64), 0, stream, P);
         ODPL_HIP_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(v5_finalize_kernel, dim3(1), dim3(256), 0, stream, P);
-    ODPL_HIP_TRY(hipGetLastError());
+    return 0;
+}
+}  // namespace
+
+extern "C" size_t odpl_yolov5_loss_workspace_bytes(const odpl_yolov5_loss_desc_t* d) {
+    VPlan p;
+    return make_vplan(d, &p) ? p.ws_total + p.compact_total : 0;      // the one-call entry keeps the compact form at the workspace's tail
+}
+
+extern "C" size_t odpl_yolov5_loss_compact_bytes(const odpl_yolov5_loss_desc_t* d) {
+    VPlan p;
+    return make_vplan(d, &p) ? p.compact_total : 0;
+}
+
+extern "C" int odpl_yolov5_loss_forward(const odpl_yolov5_loss_desc_t* d, void* workspace, size_t workspace_bytes, void* compact,
+                                        size_t compact_bytes, float* out4, int32_t* out_counts, void* stream) {
+    VPlan pl;
+    if (!make_vplan(d, &pl) || !workspace || !out4) return ODPL_EINVAL;
+    char* ws = (char*)workspace;
+    char* cp = (char*)compact;
+    if (!cp) {                                                   // no gradient wanted: the compact scratch sits in the workspace
+        if (workspace_bytes < pl.ws_total + pl.compact_total) return ODPL_EINVAL;
+        cp = ws + pl.ws_total;
+    } else if (workspace_bytes < pl.ws_total || compact_bytes < pl.compact_total) return ODPL_EINVAL;
+    if (((uintptr_t)ws | (uintptr_t)cp) & 15) return ODPL_EINVAL;
+    return v5_forward(d, pl, ws, cp, out4, out_counts, (hipStream_t)stream);
+}
+
+extern "C" int odpl_yolov5_loss_backward(const odpl_yolov5_loss_desc_t* d, const void* compact, size_t compact_bytes,
+                                         const float* upstream, void* stream) {
+    VPlan pl;
+    if (!make_vplan(d, &pl) || !compact || compact_bytes < pl.compact_total || ((uintptr_t)compact & 15)) return ODPL_EINVAL;
+    return v5_backward(d, pl, (char*)compact, upstream, (hipStream_t)stream);
+}
+
+extern "C" int odpl_yolov5_loss(const odpl_yolov5_loss_desc_t* d, void* workspace, size_t workspace_bytes,
+                                float* out4, int32_t* out_counts, void* stream_) {
+    VPlan pl;
+    if (!make_vplan(d, &pl) || !workspace || workspace_bytes < pl.ws_total + pl.compact_total || !out4) return ODPL_EINVAL;
+    if ((uintptr_t)workspace & 15) return ODPL_EINVAL;
+    int want = 0;
+    for (int i = 0; i < d->nl; ++i) if (d->layer[i].grad) want++;
+    if (want != 0 && want != d->nl) return ODPL_EINVAL;
+    char* ws = (char*)workspace;
+    char* cp = ws + pl.ws_total;
+    const int rc = v5_forward(d, pl, ws, cp, out4, out_counts, (hipStream_t)stream_);
+    if (rc || !want) return rc;
+    return v5_backward(d, pl, cp, nullptr, (hipStream_t)stream_);
+}
+
+extern "C" int odpl_yolov5_compact_view(const odpl_yolov5_loss_desc_t* d, const void* compact, int32_t layer, odpl_sparse_grad_t* out,
+                                        odpl_yolov5_rows_t* rows) {
+    VPlan pl;
+    if (!make_vplan(d, &pl) || !compact || layer < 0 || layer >= d->nl) return ODPL_EINVAL;
+    const char* c = (const char*)compact;
+    if (out) {
+        out->dense = (const float*)(c + pl.gobj[layer]);
+        out->rows = (const float*)(c + pl.row_grad[layer]);
+        out->row_cell = (const int32_t*)(c + pl.row_cell[layer]);
+        out->n_rows = pl.cap;                                     // rows beyond the produced count carry row_cell = -1
+        out->B = d->B; out->G2 = d->layer[layer].G * d->layer[layer].G; out->A = d->na; out->no = pl.no; out->dense_ch = 4;
+        out->layout = ODPL_LAYOUT_PLANAR;                         // the CELL order (b*na + a)*G2 + s, whatever the memory format of p
+    }
+    if (rows) {
+        rows->row_target = (const int32_t*)(c + pl.crow_t[layer]);
+        rows->row_anchor_group = (const int32_t*)(c + pl.crow_ag[layer]);
+        rows->row_cell = (const int32_t*)(c + pl.row_cell[layer]);
+        rows->row_tbox = (const float*)(c + pl.row_tbox[layer]);
+        rows->n_rows = (const int32_t*)(c + pl.nrows[layer]);
+        rows->cap = pl.cap;
+    }
     return 0;
 }

@@ -15,6 +15,7 @@ from ..LightningFunc.accuracy import get_yolo_statistics as _get_yolo_statistics
 from ..LightningFunc.losses import configure_loss
 from ..LightningFunc.nms import yolo_non_max_suppression
 from ..LightningFunc.utils import bnact as _bnact
+from ..LightningFunc.utils.headconv import HeadConv2d
 from ..LightningFunc.utils.s2d import focus as _focus
 from ..LightningFunc.utils.spp import spp_cat
 from ..LightningFunc.utils.spp import tile_path as _spp_tile_path
@@ -134,13 +135,13 @@ class backbone_head(nn.Module):
         self.seq8_SPP = SPP(1024, 1024, [5, 9, 13], **kw)
         self.seq9_BottleneckCSP = BottleneckCSP(1024, 1024, 6, **kd)
         self.seq10_BottleneckCSP = BottleneckCSP(1024, 1024, 3, False, **kd)
-        self.seq11_Conv2d = nn.Conv2d(_w(1024, wm), self.no, 1, 1, 0)
+        self.seq11_Conv2d = HeadConv2d(_w(1024, wm), self.no, 1, 1, 0)        # Detect.m: NCHW heads + structured backward (utils/headconv.py)
         self.seq14_Conv = Conv(1536, 512, 1, 1, **kw)
         self.seq15_BottleneckCSP = BottleneckCSP(512, 512, 3, False, **kd)
-        self.seq16_Conv2d = nn.Conv2d(_w(512, wm), self.no, 1, 1, 0)
+        self.seq16_Conv2d = HeadConv2d(_w(512, wm), self.no, 1, 1, 0)
         self.seq19_Conv = Conv(768, 256, 1, 1, **kw)
         self.seq20_BottleneckCSP = BottleneckCSP(256, 256, 3, False, **kd)
-        self.seq21_Conv2d = nn.Conv2d(_w(256, wm), self.no, 1, 1, 0)
+        self.seq21_Conv2d = HeadConv2d(_w(256, wm), self.no, 1, 1, 0)
 
     @staticmethod
     def _up2(x):
@@ -152,7 +153,7 @@ class backbone_head(nn.Module):
         r1 = self.seq6_BottleneckCSP(self.seq5_Conv(r0))
         x = self.seq9_BottleneckCSP(self.seq8_SPP(self.seq7_Conv(r1)))
         route = self.seq10_BottleneckCSP(x)
-        head = (lambda conv, t: _bnact.conv_bias(t, conv)) if route.is_cuda and route.dtype in (torch.float32, torch.bfloat16) else (lambda conv, t: conv(t))
+        head = lambda conv, t: conv(t)                                         # noqa: E731  (HeadConv2d on the device, plain conv on the CPU)
         out0 = head(self.seq11_Conv2d, route)
         route = self.seq15_BottleneckCSP(self.seq14_Conv(torch.cat([self._up2(route), r1], 1)))
         out1 = head(self.seq16_Conv2d, route)
@@ -161,14 +162,28 @@ class backbone_head(nn.Module):
 
 
 class Yolo_Layers(nn.Module):
-    """YOLOV5.py:81-97: [B, na*no, G, G] -> [B, na, G, G, no] (contiguous, as the criterion and the NMS expect)."""
+    """YOLOV5.py:81-97: [B, na*no, G, G] -> [B, na, G, G, no].  The reference makes the permuted tensor contiguous (a full copy
+    per head per step); here an NCHW-contiguous head (what `HeadConv2d` writes) is returned as the permuted VIEW -- same shape,
+    same values, strides (na*no*G2, no*G2, G, 1, G2) -- which the criterion consumes in place (`ODPL_LAYOUT_PLANAR`) and the
+    NMS makes contiguous itself when it needs the reference's memory reinterpretation (YOLOV5.py:176-182)."""
 
     def __init__(self, nc=80, anchors=()):
         super().__init__()
         self.no, self.nl, self.na = nc + 5, len(anchors), len(anchors[0]) // 2
 
+    view_heads = True               # class switch: False = always .contiguous() like the reference
+
     def forward(self, x, inference=False):
-        return [t.view(t.shape[0], self.na, self.no, t.shape[2], t.shape[3]).permute(0, 1, 3, 4, 2).contiguous() for t in x]
+        out = []
+        for t in x:
+            v = t.view(t.shape[0], self.na, self.no, t.shape[2], t.shape[3]).permute(0, 1, 3, 4, 2)
+            if Yolo_Layers.view_heads and t.is_cuda and t.is_contiguous():
+                if hasattr(t, "_odpl_head_src"):
+                    v._odpl_head_base = t                     # lets the criterion run the Detect convolution's backward itself
+                out.append(v)
+            else:
+                out.append(v.contiguous())
+        return out
 
 
 class YOLOv5(_Base):

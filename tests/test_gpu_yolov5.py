@@ -95,3 +95,154 @@ def test_v5_loss_bf16_heads():
         got, want = h.grad.float().cpu(), (o.grad * 2.0)
         assert torch.equal(got != 0, want.bfloat16().float() != 0) or torch.allclose(got, want, rtol=2e-2, atol=1e-9)
         assert torch.allclose(got, want, rtol=2e-2, atol=1e-6 * float(want.abs().max()))
+
+
+def _planar_view(h):
+    """the [B,na,G,G,no] tensor as the permuted VIEW of an NCHW [B, na*no, G, G] buffer (what Yolo_Layers returns for a
+    HeadConv2d output): same values, strides (na*no*G2, no*G2, G, 1, G2)"""
+    B, na, G, _, no = h.shape
+    base = h.permute(0, 1, 4, 2, 3).contiguous().view(B, na * no, G, G)
+    return base, base.view(B, na, no, G, G).permute(0, 1, 3, 4, 2)
+
+
+@pytest.mark.parametrize("case", ["plain", "dup", "empty"])
+def test_v5_assignment_indices_vs_golden(golden, case):
+    """the rows v5_assign_kernel / v5_rows_kernel produce -- (b, a, gj, gi), tbox, anchors, tcls of
+    build_targets_v5 (accuracy.py:472-521) -- exported from the compact buffer and compared with the reference's own arrays,
+    bit for bit, in the reference's row order."""
+    from objectdetectionpl_amd.LightningFunc.losses_dense import MultiScaleRegionLoss_v5
+    g = golden("yolov5")
+    d = torch.device("cuda:0")
+    heads = [T(g[f"{case}_head{i}"]).to(d).requires_grad_() for i in range(3)]
+    tgt = T(g[f"{case}_target"])
+    crit = MultiScaleRegionLoss_v5(V5_ANCHORS, None, None, None, None, 4, 640)
+    crit(heads, tgt.to(d))
+    for i in range(3):
+        (b, a, gj, gi), tbox, anc_idx, trow, _cell = crit.assignment_rows(i)
+        for name, got in (("b", b), ("a", a), ("gj", gj), ("gi", gi)):
+            assert np.array_equal(got.cpu().numpy(), g[f"{case}_L{i}_{name}"]), (i, name)
+        assert np.array_equal(tbox.cpu().numpy(), g[f"{case}_L{i}_tbox"]), i                      # fp32 subtraction: exact
+        assert np.array_equal(crit.anchors[i][anc_idx.cpu()].numpy(), g[f"{case}_L{i}_anch"]), i
+        assert np.array_equal(tgt[trow.cpu(), 1].long().numpy(), g[f"{case}_L{i}_tcls"]), i
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_v5_planar_view_heads_equal_contiguous_heads(dtype):
+    """The permuted view of an NCHW head (no copy) gives the same loss and the same gradient, returned with the view's strides."""
+    from objectdetectionpl_amd.LightningFunc.losses_dense import MultiScaleRegionLoss_v5
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(17)
+    B, C = 3, 20
+    heads = [torch.randn(B, 3, G, G, 5 + C, generator=g).to(dtype) for G in (20, 10, 5)]
+    n = B * 5
+    wh = torch.rand(n, 2, generator=g) * 0.4 + 0.02
+    tgt = torch.cat([torch.arange(B).repeat_interleave(5).float()[:, None], torch.randint(0, C, (n, 1), generator=g).float(),
+                     torch.rand(n, 2, generator=g) * 0.9 + 0.05, wh], 1).to(d)
+    crit = MultiScaleRegionLoss_v5(V5_ANCHORS, None, None, None, None, C, 160)
+    ha = [h.to(d).requires_grad_() for h in heads]
+    oa = crit(ha, tgt); (oa["loss"] * 1.5).backward()
+    bases, views = [], []
+    for h in heads:
+        base, _ = _planar_view(h.to(d))
+        base.requires_grad_()
+        bases.append(base)
+        views.append(base.view(B, 3, 5 + C, h.shape[2], h.shape[2]).permute(0, 1, 3, 4, 2))
+    assert not views[0].is_contiguous()
+    ob = crit(views, tgt); (ob["loss"] * 1.5).backward()
+    for k in KEYS:
+        assert abs(oa[k].item() - ob[k].item()) <= 1e-6 * abs(oa[k].item())
+    for h, base in zip(ha, bases):
+        G = h.shape[2]
+        gv = base.grad.view(B, 3, 5 + C, G, G).permute(0, 1, 3, 4, 2)
+        assert torch.equal(h.grad, gv)                    # same arithmetic per element
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_v5_detect_convs_structured_backward(dtype):
+    """x -> Detect 1x1 convs (HeadConv2d) -> Yolo_Layers view -> criterion: the convolutions' backward from the compact
+    gradient equals the dense route (bf16: activations and their gradients in bf16, weights fp32)."""
+    import torch.nn as nn
+    from objectdetectionpl_amd import _lib
+    from objectdetectionpl_amd.LightningFunc.losses_dense import MultiScaleRegionLoss_v5
+    from objectdetectionpl_amd.LightningFunc.utils.headconv import HeadConv2d
+    from objectdetectionpl_amd.model.YOLOV5 import Yolo_Layers
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(23)
+    B, C = 4, 12
+    cins, Gs = (64, 128, 256), (20, 10, 5)
+    xs = [(torch.randn(B, c, G, G, generator=g) * 0.5).to(dtype) for c, G in zip(cins, Gs)]
+    n = B * 6
+    wh = torch.rand(n, 2, generator=g) * 0.4 + 0.02
+    tgt = torch.cat([torch.arange(B).repeat_interleave(6).float()[:, None], torch.randint(0, C, (n, 1), generator=g).float(),
+                     torch.rand(n, 2, generator=g) * 0.9 + 0.05, wh], 1).to(d)
+    torch.manual_seed(1)
+    convs = nn.ModuleList(HeadConv2d(c, 3 * (5 + C), 1) for c in cins).to(d)
+    layers = Yolo_Layers(C, V5_ANCHORS)
+    crit = MultiScaleRegionLoss_v5(V5_ANCHORS, None, None, None, None, C, 160)
+    res = []
+    for fused in (True, False):
+        MultiScaleRegionLoss_v5.fuse_head_backward = fused
+        _lib.profile_enable("headgrad_stream", True); _lib.profile_enable("yolov5_dense", True)
+        try:
+            convs.zero_grad(set_to_none=True)
+            xd = [x.to(d).contiguous(memory_format=torch.channels_last).requires_grad_() for x in xs]
+            heads = layers([c(x) for c, x in zip(convs, xd)])
+            assert all(not h.is_contiguous() and h.shape == (B, 3, G, G, 5 + C) for h, G in zip(heads, Gs))
+            out = crit(heads, tgt)
+            (out["loss"] * 2.0).backward()
+        finally:
+            MultiScaleRegionLoss_v5.fuse_head_backward = True
+            _lib.profile_enable("headgrad_stream", False); _lib.profile_enable("yolov5_dense", False)
+        launches = (len(_lib.profile_collect("headgrad_stream")[0]), len(_lib.profile_collect("yolov5_dense")[0]))
+        assert launches == ((1, 0) if fused else (0, 1))
+        res.append((out, [x.grad.float().clone() for x in xd], [p.grad.clone() for p in convs.parameters()]))
+    (of, xf, pf), (od, xdn, pd) = res
+    for k in KEYS:
+        assert of[k].item() == od[k].item()
+    # fp32: same numbers to summation order.  bf16: the dense route first rounds d loss/d head to bf16 and then the products
+    # again; the structured route keeps the compact gradient in fp32 and rounds dX once -- they agree to bf16 resolution
+    rtol, arel = (1e-4, 1e-6) if dtype == torch.float32 else (3e-2, 1e-2)
+    for a, b in zip(xf, xdn):
+        assert torch.allclose(a, b, rtol=rtol, atol=arel * float(b.abs().max()) + 1e-12), float((a - b).abs().max())
+    for a, b in zip(pf, pd):
+        assert torch.allclose(a, b, rtol=rtol, atol=arel * float(b.abs().max()) + 1e-12), float((a - b).abs().max())
+
+
+def test_v5_config5_full_size_bf16_vs_oracle():
+    """BASELINE config 5 at full size: B = 32, 640^2 (G = 80 / 40 / 20), 80 classes, bf16 heads, 7 targets per image.  Loss
+    scalars vs the CPU oracle on the identical bf16-valued inputs (1e-4), row counts, gradient support and the gradient on a
+    sample of matched cells + the whole objectness plane of one (image, anchor) per layer."""
+    from objectdetectionpl_amd.LightningFunc.losses_dense import MultiScaleRegionLoss_v5
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(55)
+    B, C = 32, 80
+    heads = [torch.randn(B, 3, G, G, 5 + C, generator=g).bfloat16() for G in (80, 40, 20)]
+    n = B * 7
+    wh = torch.rand(n, 2, generator=g) * 0.48 + 0.02
+    tgt = torch.cat([torch.arange(B).repeat_interleave(7).float()[:, None], torch.randint(0, C, (n, 1), generator=g).float(),
+                     torch.rand(n, 2, generator=g) * (1 - wh) * 0.98 + 0.01, wh], 1)
+    ho = [h.float().requires_grad_() for h in heads]
+    ref = oracle_v5.v5_loss(ho, tgt, V5_ANCHORS, C)
+    ref["loss"].backward()
+    crit = MultiScaleRegionLoss_v5(V5_ANCHORS, None, None, None, None, C, 640)
+    hd = [h.to(d).requires_grad_() for h in heads]
+    out = crit(hd, tgt.to(d))
+    out["loss"].backward()
+    for k in KEYS:
+        a, b = out[k].item(), ref[k].item()
+        assert abs(a - b) <= 1e-4 * abs(b) + 1e-6, (k, a, b)
+    anc = oracle_v5.grid_anchors(V5_ANCHORS)
+    for i, (h, o) in enumerate(zip(hd, ho)):
+        G = h.shape[2]
+        bb, aa, gj, gi, *_ = oracle_v5.assign_layer(G, tgt, anc[i])
+        assert int(crit.last_counts[i]) == bb.shape[0]
+        got, want = h.grad.float().cpu(), o.grad
+        # support: every element outside the objectness channel and the matched cells is exactly zero on both sides
+        mask = torch.zeros(B, 3, G, G, dtype=torch.bool)
+        mask[bb, aa, gj, gi] = True
+        assert int((got[~mask][:, :4] != 0).sum()) == 0 and int((got[~mask][:, 5:] != 0).sum()) == 0
+        # matched cells: the oracle's gradient rounded to bf16 once
+        gm, wm = got[mask], want[mask]
+        assert torch.allclose(gm, wm, rtol=2e-2, atol=1e-6 * float(wm.abs().max()) + 1e-12)
+        assert torch.allclose(got[3, 1, :, :, 4], want[3, 1, :, :, 4], rtol=2e-2, atol=1e-12)
+    assert int(crit.last_counts[4]) == 0                                  # status word
