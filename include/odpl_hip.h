@@ -192,7 +192,9 @@ typedef struct {
     int32_t B, An, C, nT;
     int32_t coord_mode;             /* ODPL_COORD_*: nn.SmoothL1Loss / nn.MSELoss, reduction='sum' */
     int32_t flags;                  /* ODPL_RETINA_STATE_CLEAN */
-    float img_size;                 /* scalar target scale, losses.py:425 */
+    float img_size;                 /* scalar target scale, losses.py:425: boxes = y[:, 2:] * img_size */
+    float img_size_y;               /* EXTENSION for non-square inputs (BASELINE config 4 is 1333 x 800): when > 0 the y / h columns
+                                     * are scaled by it and the x / w columns by img_size (= input width); 0 = the reference's one scalar */
 } odpl_retina_loss_desc_t;
 
 /* the caller promises the last use of this workspace was a successful odpl_retina_loss call */

@@ -60,7 +60,10 @@ class RetinaNetLoss(nn.Module):
     """losses.py:351-472.  ctor `(iou_boxes, cls_criterion, coord_criterion, num_classes, img_size)`;
     forward((loc_preds, cls_preds), targets) -> {"loss", "Localization", "Classification"}.
     An image without any box makes the reference raise (max over an empty dim): here the three scalars
-    come back NaN and `last_counts[1] & 1` is set (no host sync on the hot path)."""
+    come back NaN and `last_counts[1] & 1` is set (no host sync on the hot path).
+    Extension: `img_size=(width, height)` scales the x / w target columns by width and the y / h columns by height (the
+    reference multiplies all four by one scalar, losses.py:425, which is only right for square inputs; BASELINE config 4 is
+    1333 x 800).  A scalar -- the default -- is the reference's behaviour bit for bit."""
 
     def __init__(self, iou_boxes, cls_criterion, coord_criterion, num_classes=20, img_size=600):
         super().__init__()
@@ -104,7 +107,10 @@ class RetinaNetLoss(nn.Module):
         d.target = tgt.data_ptr() if tgt.shape[0] else None
         d.B, d.An, d.C, d.nT = B, An, C, tgt.shape[0]
         d.coord_mode = _lib.COORD_MODES[self._coord_name]
-        d.img_size = float(self.img_size)
+        if isinstance(self.img_size, (tuple, list)):        # extension: (width, height) of a non-square input; the reference has one scalar
+            d.img_size, d.img_size_y = float(self.img_size[0]), float(self.img_size[1])
+        else:
+            d.img_size, d.img_size_y = float(self.img_size), 0.0
         need = L.odpl_retina_loss_workspace_bytes(ctypes.byref(d))
         if need == 0:
             raise OdplError("odpl_retina_loss_workspace_bytes rejected the descriptor")

@@ -47,7 +47,7 @@ class RetinaLossDesc(ctypes.Structure):
     _fields_ = [("loc", c_void_p), ("cls", c_void_p), ("grad_loc", c_void_p), ("grad_cls", c_void_p),
                 ("anchors", c_void_p), ("target", c_void_p),
                 ("B", c_int32), ("An", c_int32), ("C", c_int32), ("nT", c_int32),
-                ("coord_mode", c_int32), ("flags", c_int32), ("img_size", c_float)]
+                ("coord_mode", c_int32), ("flags", c_int32), ("img_size", c_float), ("img_size_y", c_float)]
 
 
 class YoloNmsDesc(ctypes.Structure):

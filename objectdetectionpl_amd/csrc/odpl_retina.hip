@@ -31,7 +31,7 @@ struct RParams {
     const float* loc; const float* cls; float* grad_loc; float* grad_cls;
     const float* anchors; const float* target;
     int B, An, C, nT, coord_sl1, nblk_x, ntiles;
-    float img_size;
+    float img_size, img_size_y;       // target scale of the x / w columns and of the y / h columns (equal in the reference)
     int* code;                     // [B*An]  -1 ignore, 0 background, (target_row << 12 | label+1) positive
     int* tile_cnt;                 // [ntiles] positives per tile
     int* tile_off;                 // [ntiles+1] exclusive scan; tile_off[ntiles] = num_pos
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(kT) void retina_assign_kernel(const RParams P) {
         for (int w = 0; w < kT / 64; ++w) { if (w < wv) off += s_wcnt[w]; n += s_wcnt[w]; }
         if (match) {
             GtLds r;
-            const float cx = y2 * P.img_size, cy = y3 * P.img_size, w = y4 * P.img_size, h = y5 * P.img_size;
+            const float cx = y2 * P.img_size, cy = y3 * P.img_size_y, w = y4 * P.img_size, h = y5 * P.img_size_y;
             r.x1 = cx - w / 2.0f; r.y1 = cy - h / 2.0f; r.x2 = cx + w / 2.0f; r.y2 = cy + h / 2.0f;
             r.area = (r.x2 - r.x1 + 1.0f) * (r.y2 - r.y1 + 1.0f);         // losses.py:401
             r.row = t; r.label = (int)trunc_ll(y1);
@@ -173,9 +173,9 @@ __global__ __launch_bounds__(kT) void retina_main_kernel(const RParams P) {
             if (lane < 4) {
                 float tgt;
                 if (lane == 0) tgt = (y[2] * P.img_size - an.x) / an.z;
-                else if (lane == 1) tgt = (y[3] * P.img_size - an.y) / an.w;
+                else if (lane == 1) tgt = (y[3] * P.img_size_y - an.y) / an.w;
                 else if (lane == 2) tgt = logf(y[4] * P.img_size / an.z);
-                else tgt = logf(y[5] * P.img_size / an.w);
+                else tgt = logf(y[5] * P.img_size_y / an.w);
                 const float d = P.loc[ga * 4 + lane] - tgt;
                 l_loc = coord_elem(d, P.coord_sl1);
                 if (want_grad) P.grad_loc[ga * 4 + lane] = coord_deriv(d, P.coord_sl1) * inv;
@@ -289,7 +289,7 @@ extern "C" int odpl_retina_loss(const odpl_retina_loss_desc_t* d, void* workspac
     P.loc = d->loc; P.cls = d->cls; P.grad_loc = d->grad_loc; P.grad_cls = d->grad_cls;
     P.anchors = d->anchors; P.target = d->target;
     P.B = d->B; P.An = d->An; P.C = d->C; P.nT = d->nT; P.coord_sl1 = d->coord_mode == ODPL_COORD_SMOOTH_L1;
-    P.nblk_x = pl.nblk_x; P.ntiles = pl.ntiles; P.img_size = d->img_size;
+    P.nblk_x = pl.nblk_x; P.ntiles = pl.ntiles; P.img_size = d->img_size; P.img_size_y = d->img_size_y > 0.0f ? d->img_size_y : d->img_size;
     P.code = (int*)(ws + pl.code); P.tile_cnt = (int*)(ws + pl.tile_cnt); P.tile_off = (int*)(ws + pl.tile_off);
     P.row_tile = (int*)(ws + pl.row_tile); P.tile_pos = (unsigned char*)(ws + pl.tile_pos);
     P.status = (int*)(ws + pl.status); P.part = (float*)(ws + pl.part);

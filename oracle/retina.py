@@ -44,7 +44,10 @@ def encode_targets(anchors, targets, batch_size, img_size):
     locs, clss = [], []
     for bid in range(batch_size):
         sel = targets[:, 0] == bid
-        boxes = targets[sel][:, 2:] * img_size
+        # losses.py:425 multiplies by ONE scalar; a (width, height) pair is the build's documented extension for non-square
+        # inputs (x / w by width, y / h by height) and has no counterpart in the reference
+        scale = torch.tensor([img_size[0], img_size[1], img_size[0], img_size[1]], dtype=torch.float32) if isinstance(img_size, (tuple, list)) else img_size
+        boxes = targets[sel][:, 2:] * scale
         labels = targets[sel][:, 1].long()
         ious = iou_matrix_plus1(anchors, boxes, order="xywh")
         max_ious, max_ids = ious.max(1)

@@ -184,3 +184,29 @@ def test_greedy_prep_scores_and_labels_equal_the_max_over_sigmoids():
     picked = cls[0].gather(1, lab[:, None])[:, 0]                       # near ties: the label is one of the contenders within the
     assert bool((torch.sigmoid(picked[near]) >= torch.sigmoid(top2[near, 0]) - 1.2e-7).all())   # ... whose sigmoid ties with the maximum
     assert label_ref.shape == lab.shape
+
+
+def test_yolo_merge_nms_at_config5_size_vs_oracle():
+    """BASELINE config 5's NMS size: 3 x (80^2 + 40^2 + 20^2) = 25 200 candidates per image, 85 answers each, through the v5
+    memory reinterpretation (YOLOV5.py:176-182), vs the oracle's sequential loop (kept set, order and merged boxes)."""
+    from objectdetectionpl_amd.LightningFunc.nms import yolo_non_max_suppression
+    from oracle import nms as oracle_nms
+    g = torch.Generator().manual_seed(77)
+    B, C = 2, 80
+    heads = []
+    for G in (80, 40, 20):
+        h = torch.randn(B, 3, 85, G, G, generator=g)                 # what the NMS reads the [B,3,G,G,85] memory as
+        h[:, :, 0:2] = torch.rand(B, 3, 2, 1, 1, generator=g) * 400 + 100 + torch.randn(B, 3, 2, G, G, generator=g) * 60
+        h[:, :, 2:4] = torch.rand(B, 3, 2, G, G, generator=g) * 90 + 25
+        h[:, :, 4] = torch.randn(B, 3, G, G, generator=g) * 0.6 - 1.6   # ~ 1 % above the -0.0151 threshold
+        h[:, :, 5:] = torch.rand(B, 3, C, G, G, generator=g)
+        heads.append(h.contiguous().view(B, 3, G, G, 85))            # same memory, v5's logical shape
+    ref = oracle_nms.yolo_weighted_nms([h.reshape(B, 3 * 85, h.shape[2], h.shape[2]).clone() for h in heads])
+    got = yolo_non_max_suppression([h.cuda() for h in heads])
+    assert sum(h.shape[1] * h.shape[2] * h.shape[3] for h in heads) == 25200
+    for r, o in zip(ref, got):
+        assert (r is None) == (o is None)
+        if r is not None:
+            assert o.shape == r.shape and r.shape[0] > 50
+            assert torch.equal(o[:, 6].cpu(), r[:, 6])                                  # labels: index work
+            assert torch.allclose(o.cpu(), r, rtol=1e-4, atol=1e-3)

@@ -114,3 +114,58 @@ def test_image_without_boxes_gives_nan_and_status():
     loc = torch.zeros(2, anchors.shape[0], 4, device=d); cls = torch.zeros(2, anchors.shape[0], 4, device=d)
     out = crit((loc, cls), torch.tensor([[0, 1, .5, .5, .4, .4]], device=d))
     assert np.isnan(out["loss"].item()) and int(crit.last_counts[1]) & 1
+
+
+def test_retina_config4_full_size_vs_oracle():
+    """BASELINE config 4 at full size: B = 4, 1333 x 800 input -> 200 700 anchors, C = 80, 8 boxes per image, focal + SmoothL1.
+    Scalars, num_pos, gradient support and values vs the CPU oracle.  Targets are scaled per axis (x / w by 1333, y / h by 800:
+    the build's extension -- the reference's single scalar, losses.py:425, cannot place boxes in a non-square image)."""
+    from objectdetectionpl_amd.LightningFunc.losses_dense import RetinaNetLoss, focal_loss
+    from objectdetectionpl_amd.LightningFunc.utils.RetinaUtils import get_anchor_boxes
+    d = dev()
+    anchors = get_anchor_boxes([1333, 800], d)
+    An, C, B = anchors.shape[0], 80, 4
+    assert An == 200700
+    g = torch.Generator().manual_seed(44)
+    loc = torch.randn(B, An, 4, generator=g) * 0.3
+    cls = torch.randn(B, An, C, generator=g)
+    n = B * 8
+    wh = torch.rand(n, 2, generator=g) * 0.45 + 0.05
+    tgt = torch.cat([torch.arange(B).repeat_interleave(8).float()[:, None], torch.randint(0, C, (n, 1), generator=g).float(),
+                     torch.rand(n, 2, generator=g) * 0.6 + 0.2, wh], 1)
+    lo = loc.clone().requires_grad_(); co = cls.clone().requires_grad_()
+    ref = oracle_retina.retina_loss(lo, co, tgt, anchors.cpu(), C, (1333, 800))
+    ref["loss"].backward()
+    ld = loc.to(d).requires_grad_(); cd = cls.to(d).requires_grad_()
+    crit = RetinaNetLoss(anchors, focal_loss, "smooth_l1_loss", C, (1333, 800))
+    out = crit((ld, cd), tgt.to(d)); out["loss"].backward()
+    for k in ref:
+        assert abs(out[k].item() - ref[k].item()) <= 1e-4 * abs(ref[k].item()) + 1e-6, k
+    _, cls_t = oracle_retina.encode_targets(anchors.cpu(), tgt, B, (1333, 800))
+    assert int(crit.last_counts[0]) == int((cls_t > 0).sum()) > 0 and int(crit.last_counts[1]) == 0
+    gc, gl = cd.grad.cpu(), ld.grad.cpu()
+    assert torch.equal(gc != 0, co.grad != 0) and torch.equal(gl != 0, lo.grad != 0)
+    assert torch.allclose(gc, co.grad, rtol=1e-4, atol=1e-9) and torch.allclose(gl, lo.grad, rtol=1e-4, atol=1e-9)
+
+
+def test_retina_per_axis_scale_equals_scalar_on_square_inputs():
+    """the extension flag is inert where the reference is defined: (600, 600) == 600, bit for bit"""
+    from objectdetectionpl_amd.LightningFunc.losses_dense import RetinaNetLoss, focal_loss
+    from objectdetectionpl_amd.LightningFunc.utils.RetinaUtils import get_anchor_boxes
+    d = dev()
+    anchors = get_anchor_boxes([600, 600], d)
+    g = torch.Generator().manual_seed(45)
+    B, C, An = 2, 20, anchors.shape[0]
+    loc = (torch.randn(B, An, 4, generator=g) * 0.3).to(d); cls = torch.randn(B, An, C, generator=g).to(d)
+    wh = torch.rand(8, 2, generator=g) * 0.45 + 0.05
+    tgt = torch.cat([torch.arange(B).repeat_interleave(4).float()[:, None], torch.randint(0, C, (8, 1), generator=g).float(),
+                     torch.rand(8, 2, generator=g) * 0.6 + 0.2, wh], 1).to(d)
+    res = []
+    for size in (600, (600, 600)):
+        l, c = loc.clone().requires_grad_(), cls.clone().requires_grad_()
+        out = RetinaNetLoss(anchors, focal_loss, "smooth_l1_loss", C, size)((l, c), tgt)
+        out["loss"].backward()
+        res.append((out, l.grad, c.grad))
+    for k in res[0][0]:
+        assert res[0][0][k].item() == res[1][0][k].item()
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])

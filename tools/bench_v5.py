@@ -28,8 +28,18 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--type", default="Yolov5l")
     ap.add_argument("--miopen-find", action="store_true", help="cudnn.benchmark=True (exhaustive MIOpen search: minutes on a fresh box)")
+    ap.add_argument("--no-fused-head", action="store_true", help="A/B: dense d loss/d p instead of the structured Detect backward")
+    ap.add_argument("--contiguous-heads", action="store_true", help="A/B: Yolo_Layers copies to [B,na,G,G,no] like the reference")
+    ap.add_argument("--no-head-gemm", action="store_true", help="A/B: Detect convolutions on MIOpen")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
+    from objectdetectionpl_amd import _lib
+    from objectdetectionpl_amd.LightningFunc.losses_dense import MultiScaleRegionLoss_v5
+    from objectdetectionpl_amd.LightningFunc.utils.headconv import HeadConv2d
+    from objectdetectionpl_amd.model.YOLOV5 import Yolo_Layers
+    MultiScaleRegionLoss_v5.fuse_head_backward = not a.no_fused_head
+    Yolo_Layers.view_heads = not a.contiguous_heads
+    HeadConv2d.enabled = not a.no_head_gemm
     torch.backends.cudnn.benchmark = bool(a.miopen_find)
     torch.manual_seed(0)
     Args.type = a.type
@@ -57,14 +67,23 @@ def main():
         d, out = step()
         torch.cuda.synchronize()
         print(f"[{time.perf_counter() - t0:6.1f}s] warmup {i + 1}/{a.warmup}", file=sys.stderr, flush=True)
+    PROF = ("yolov5_obj", "yolov5_dense", "headgrad_stream", "headgrad_finish")
+    for k in PROF:
+        _lib.profile_enable(k, True)
     t1 = time.perf_counter()
     for _ in range(a.steps):
         d, out = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t1) / a.steps
+    kern = {}
+    for k in PROF:
+        _lib.profile_enable(k, False)
+        ms = _lib.profile_collect(k)[0]
+        if ms:
+            kern[k + "_us"] = round(1e3 * sum(ms) / len(ms), 2)
     print(json.dumps({"workload": f"{a.type} {a.img}x{a.img} bs={a.batch} training step, convs {a.dtype}", "img_per_s": round(a.batch / dt, 1),
                       "ms_per_step": round(dt * 1e3, 2), "head_dtype": str(out[0].dtype), "loss": round(float(d["loss"].detach()), 4),
-                      "miopen_find": bool(a.miopen_find)}))
+                      "miopen_find": bool(a.miopen_find), "head_contiguous": bool(out[0].is_contiguous()), **kern}))
 
 
 if __name__ == "__main__":
