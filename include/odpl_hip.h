@@ -426,7 +426,7 @@ typedef struct {
     const uint8_t* data;
     int32_t h, w;
     int32_t flip;
-    int32_t reserved;
+    int32_t reserved;     /* bit 0: warp this image (odpl_collate_images_warp) */
     const uint8_t* lut;   /* NULL, or device uint8 [3][256]: per-channel point operation applied to the resized uint8 frame (the
                            * host composes RandomBrightnessContrast / RGBShift -- LUT operations in albumentations -- into it) */
 } odpl_image_t;
@@ -437,6 +437,17 @@ int odpl_collate_images(const odpl_image_t* host_images, int32_t B, int32_t S, f
  * (h, w, flip) (device arrays) -> y [nT, 6] = (img, label, x, y, w, h) normalised, after the flips. */
 int odpl_collate_targets(const float* objects, const int32_t* row_image, const int32_t* image_dims, int32_t nT,
                          int32_t S, float* y, void* stream);
+/* The same two entries with A.ShiftScaleRotate (dataset/Pascal.py:217, Coco.py:259: cv2.warpAffine, INTER_LINEAR,
+ * BORDER_REFLECT_101, applied to the resized + flipped uint8 frame, before the photometric tables).  Images with bit 0 of
+ * `reserved` set are warped by host_inverse_affine[b] = the 2x3 DESTINATION -> SOURCE map warpAffine inverts its argument
+ * to (doubles, pixels of the S x S frame); OpenCV's fixed-point arithmetic (1/32-pixel positions, 2^15 bilinear weights).
+ * Targets: image_affine [B][7] doubles (device) = flag, then the FORWARD 2x3 matrix; boxes become the axis-aligned hull of
+ * their transformed corners, are clipped to the frame, and keep[t] = 0 marks rows albumentations drops (no area left).
+ * keep may be NULL. */
+int odpl_collate_images_warp(const odpl_image_t* host_images, const double* host_inverse_affine, int32_t B, int32_t S, float* x,
+                             const int64_t* host_x_strides, void* stream);
+int odpl_collate_targets_warp(const float* objects, const int32_t* row_image, const int32_t* image_dims, const double* image_affine,
+                              int32_t nT, int32_t S, float* y, uint8_t* keep, void* stream);
 
 /* Bias gradient of a convolution from an NCHW-dense output gradient [B, C, HW]: grad_bias[c] = sum over (b, hw)
  * (what ATen's convolution_backward computes with sum((0, 2, 3)); the linear head convs of model/YOLOV4.py:89-127). */
@@ -499,6 +510,9 @@ int odpl_bn_act_backward_strided(const void* x, const void* grad_y, int64_t gy_r
 #define ODPL_TUNE_YOLO_FILL_F4_PER_BLOCK 0
 #define ODPL_TUNE_YOLO_FILL_NT 1
 #define ODPL_TUNE_RETINA_FILL_NT 2
+#define ODPL_TUNE_BN_TARGET_BLOCKS 3      /* row tiles of the BN reduce passes (default 1024) */
+#define ODPL_TUNE_BN_STREAM_MAX_BLOCKS 4  /* grid cap of the BN apply / dx streams (0 = by size: 4096 / 16384) */
+#define ODPL_TUNE_BN_MAX_ROWS_PER_TILE 5  /* rows per reduce tile at most (default 2048) */
 int odpl_tune_set(int32_t key, int32_t value);
 
 /* diagnostic: when non-NULL, every workgroup w of yolo_expand_kernel stores its start / end reading of the

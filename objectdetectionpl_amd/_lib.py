@@ -145,6 +145,8 @@ SIGNATURES = {
     "odpl_yolo_stats_reduce": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_void_p, c_void_p]),
     "odpl_collate_images": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, POINTER(ctypes.c_int64), c_void_p]),
     "odpl_collate_targets": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
+    "odpl_collate_images_warp": (c_int32, [c_void_p, POINTER(ctypes.c_double), c_int32, c_int32, c_void_p, POINTER(ctypes.c_int64), c_void_p]),
+    "odpl_collate_targets_warp": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "odpl_bias_grad_nchw": (c_int32, [c_void_p, c_int32, c_int32, c_int32, ctypes.c_int64, c_void_p, c_void_p]),
     "odpl_focus": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, POINTER(ctypes.c_int64), POINTER(ctypes.c_int64), c_int32, c_void_p]),
     "odpl_reorg": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, POINTER(ctypes.c_int64), c_int32, c_void_p]),
@@ -221,7 +223,7 @@ YOLO_STATE_CLEAN = 1
 RETINA_STATE_CLEAN = 1
 YOLOV5_STATE_CLEAN = 1
 IOU_MODES = {"iou": 0, "giou": 1, "diou": 2, "ciou": 3}
-TUNE_KEYS = {"yolo_fill_f4_per_block": 0, "yolo_fill_nt": 1, "retina_fill_nt": 2}
+TUNE_KEYS = {"yolo_fill_f4_per_block": 0, "yolo_fill_nt": 1, "retina_fill_nt": 2, "bn_target_blocks": 3, "bn_stream_max_blocks": 4, "bn_max_rows_per_tile": 5}
 
 
 def tune_set(name, value):

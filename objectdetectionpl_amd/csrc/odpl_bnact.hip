@@ -20,6 +20,13 @@
 namespace {
 using namespace odpl;
 constexpr int kT = 256;
+}
+namespace odpl {
+int g_bn_target_blocks = 1024;          // row tiles of the two reduce passes (odpl_tune_set)
+int g_bn_stream_max_blocks = 0;         // grid cap of the apply / dx streams; 0 = by size (4096, or 16384 from 8 M quads on)
+int g_bn_max_rows_per_tile = 2048;
+}
+namespace {
 
 // Mish through ONE exponential: with n = e^z,  tanh(softplus(z)) = n(n+2) / (n(n+2) + 2)  and  sigmoid(z) = n / (1+n).
 // (ATen evaluates tanh(log1p(exp(z))): three transcendentals, which makes the epilogue VALU-bound instead of
@@ -255,7 +262,8 @@ __global__ __launch_bounds__(kT) void bias_grad_nchw_kernel(const void* __restri
 
 bool plan(long long R, int C, int* rows_per_blk, int* nblk, size_t* lds) {
     if (R < 1 || C < 4 || (C & 3)) return false;
-    long long rpb = R / 1024; if (rpb < 16) rpb = 16; if (rpb > 512) rpb = 512;
+    // ~1024 row tiles; at most 2048 rows each so that the one-workgroup-per-channel finalize stays short on the widest maps
+    long long rpb = R / odpl::g_bn_target_blocks; if (rpb < 16) rpb = 16; if (rpb > odpl::g_bn_max_rows_per_tile) rpb = odpl::g_bn_max_rows_per_tile;
     *rows_per_blk = (int)rpb;
     *nblk = (int)((R + rpb - 1) / rpb);
     const int c4n = C >> 2, tpr = c4n < kT ? c4n : kT, rows_par = kT / tpr;
@@ -316,7 +324,8 @@ extern "C" int odpl_bn_act_forward_strided(const void* x, const void* residual, 
         ODPL_HIP_TRY(hipGetLastError());
     }   // eval: the caller filled save_mean / save_invstd from the running statistics
     const long long n4 = R * (C >> 2);
-    long long blocks = (n4 + kT - 1) / kT; if (blocks > 4096) blocks = 4096;
+    long long blocks = (n4 + kT - 1) / kT;
+    { const long long cap = odpl::g_bn_stream_max_blocks > 0 ? odpl::g_bn_stream_max_blocks : (n4 >= (8LL << 20) ? 16384 : 4096); if (blocks > cap) blocks = cap; }
     if (bf16) hipLaunchKernelGGL(bn_apply_kernel<true>, dim3((unsigned)blocks), dim3(kT), 0, stream, P);
     else hipLaunchKernelGGL(bn_apply_kernel<false>, dim3((unsigned)blocks), dim3(kT), 0, stream, P);
     ODPL_HIP_TRY(hipGetLastError());
@@ -354,7 +363,8 @@ extern "C" int odpl_bn_act_backward_strided(const void* x, const void* grad_y, i
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(kT), 0, stream, P);
     ODPL_HIP_TRY(hipGetLastError());
     const long long n4 = R * (C >> 2);
-    long long blocks = (n4 + kT - 1) / kT; if (blocks > 4096) blocks = 4096;
+    long long blocks = (n4 + kT - 1) / kT;
+    { const long long cap = odpl::g_bn_stream_max_blocks > 0 ? odpl::g_bn_stream_max_blocks : (n4 >= (8LL << 20) ? 16384 : 4096); if (blocks > cap) blocks = cap; }
     if (bf16) hipLaunchKernelGGL(bn_bwd_dx_kernel<true>, dim3((unsigned)blocks), dim3(kT), 0, stream, P);
     else hipLaunchKernelGGL(bn_bwd_dx_kernel<false>, dim3((unsigned)blocks), dim3(kT), 0, stream, P);
     ODPL_HIP_TRY(hipGetLastError());

@@ -33,7 +33,7 @@ using namespace odpl;
 constexpr int kThreads = 256;
 constexpr int kMaxA = 5;
 constexpr int kMaxRows = 4096;          // matched rows per head the finish kernel stages in LDS
-int g_rows_per_tile = 64;
+int g_rows_per_tile = 32;
 
 struct Head {
     const void* x; const float* w; void* gx; float* gw; float* gb;
@@ -51,15 +51,19 @@ struct Multi { Head h[ODPL_MAX_SCALES]; int n, cap; };      // cap: LDS row-list
 
 template <bool BF> struct Vec { static constexpr int N = BF ? 8 : 4; float v[BF ? 8 : 4]; };
 
-template <bool BF>
+template <bool BF, bool NT = false>
 __device__ __forceinline__ Vec<BF> ldv(const void* p, size_t i) {
     Vec<BF> r;
     if (!BF) {
-        const float4 t = reinterpret_cast<const float4*>(p)[i];
+        v4f t4;
+        if (NT) t4 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p) + i); else t4 = reinterpret_cast<const v4f*>(p)[i];
+        const float4 t = make_float4(t4[0], t4[1], t4[2], t4[3]);
         r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
     } else {
-        const uint4 u = reinterpret_cast<const uint4*>(p)[i];
-        const unsigned w[4] = {u.x, u.y, u.z, u.w};
+        typedef unsigned u4v __attribute__((ext_vector_type(4)));
+        u4v u;
+        if (NT) u = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(p) + i); else u = reinterpret_cast<const u4v*>(p)[i];
+        const unsigned w[4] = {u[0], u[1], u[2], u[3]};
 #pragma unroll
         for (int k = 0; k < 4; ++k) { r.v[2 * k] = __uint_as_float(w[k] << 16); r.v[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u); }
     }
@@ -121,24 +125,21 @@ __global__ __launch_bounds__(kThreads) void headgrad_stream_kernel(const Multi M
     const int nrows = min(P.rows_per_tile, P.N - n0);
     const float f = P.upstream ? *P.upstream : 1.0f;
     float* s_g = lds;
-    for (int i = tid; i < nrows * A; i += kThreads) {
-        const int r = i / A, a = i - r * A;
-        s_g[i] = P.gd[gd_index(P, n0 + r, a)] * f;
-    }
-    __syncthreads();
     const int tpr = P.tpr;                               // threads along Cin (power of two, <= 64)
     const int lane_c = tid & (tpr - 1), rl = tid / tpr;  // column slot, row lane
     const int rows_par = P.rows_par;                     // = kThreads / tpr row lanes
     const int cv = P.cv;                                 // 16-byte vectors per row of X
-    float* s_red = lds + P.rows_per_tile * A;
-    if (cs == 0 && tid < A && P.part_b) {                // db partial of anchor `tid` over this row tile
-        float s = 0.f;
-        for (int r = 0; r < nrows; ++r) s += s_g[r * A + tid];
-        P.part_b[(size_t)tile * A + tid] = s;
-    }
     const int q = cs * tpr + lane_c;
     const bool col_ok = q < cv;
     const bool want_w = P.gw != nullptr, want_x = P.gx != nullptr;
+    // the first four rows of X are requested BEFORE the gd tile is staged: every workgroup of the grid is resident from the
+    // start, so a load-free staging phase would be a chip-wide bubble
+    Vec<BF> xv[4];
+    const bool pre = col_ok && want_w && rl + 3 * rows_par < nrows;
+    if (pre) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) xv[u] = ldv<BF, true>(P.x, (size_t)(n0 + rl + u * rows_par) * cv + q);
+    }
     Vec<BF> wv[A], acc[A];
 #pragma unroll
     for (int a = 0; a < A; ++a) {
@@ -146,13 +147,23 @@ __global__ __launch_bounds__(kThreads) void headgrad_stream_kernel(const Multi M
         for (int e = 0; e < E; ++e) { acc[a].v[e] = 0.f; wv[a].v[e] = 0.f; }
         if (col_ok) wv[a] = ldf<BF>(P.w + (size_t)(a * P.no + P.dc) * P.Cin, q);
     }
+    for (int i = tid; i < nrows * A; i += kThreads) {
+        const int r = i / A, a = i - r * A;
+        s_g[i] = P.gd[gd_index(P, n0 + r, a)] * f;
+    }
+    __syncthreads();
+    float* s_red = lds + P.rows_per_tile * A;
+    if (cs == 0 && tid < A && P.part_b) {                // db partial of anchor `tid` over this row tile
+        float s = 0.f;
+        for (int r = 0; r < nrows; ++r) s += s_g[r * A + tid];
+        P.part_b[(size_t)tile * A + tid] = s;
+    }
     if (col_ok) {
         int r = rl;
         for (; r + 3 * rows_par < nrows; r += 4 * rows_par) {        // four rows in flight
-            Vec<BF> xv[4];
-            if (want_w) {
+            if (want_w && !(pre && r == rl)) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) xv[u] = ldv<BF>(P.x, (size_t)(n0 + r + u * rows_par) * cv + q);
+                for (int u = 0; u < 4; ++u) xv[u] = ldv<BF, true>(P.x, (size_t)(n0 + r + u * rows_par) * cv + q);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -171,15 +182,15 @@ __global__ __launch_bounds__(kThreads) void headgrad_stream_kernel(const Multi M
         }
         for (; r < nrows; r += rows_par) {
             const float* g = s_g + r * A;
-            Vec<BF> xv, o;
+            Vec<BF> x1, o;
 #pragma unroll
-            for (int e = 0; e < E; ++e) { o.v[e] = 0.f; xv.v[e] = 0.f; }
-            if (want_w) xv = ldv<BF>(P.x, (size_t)(n0 + r) * cv + q);
+            for (int e = 0; e < E; ++e) { o.v[e] = 0.f; x1.v[e] = 0.f; }
+            if (want_w) x1 = ldv<BF, true>(P.x, (size_t)(n0 + r) * cv + q);
 #pragma unroll
             for (int a = 0; a < A; ++a) {
                 const float ga = g[a];
 #pragma unroll
-                for (int e = 0; e < E; ++e) { o.v[e] += ga * wv[a].v[e]; if (want_w) acc[a].v[e] += ga * xv.v[e]; }
+                for (int e = 0; e < E; ++e) { o.v[e] += ga * wv[a].v[e]; if (want_w) acc[a].v[e] += ga * x1.v[e]; }
             }
             if (want_x) stv<BF, true>(P.gx, (size_t)(n0 + r) * cv + q, o);
         }

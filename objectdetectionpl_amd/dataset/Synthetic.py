@@ -38,7 +38,7 @@ class SyntheticCocoModule:
         return x, torch.cat([b[:, None], cls[:, None], xy, wh], 1)
 
     def _raw_batch(self, g, hg, train):
-        from .collate import draw_flips, gpu_collate, photometric_luts
+        from .collate import draw_flips, draw_shift_scale_rotate, gpu_collate, photometric_luts
         images, objects = [], []
         for _ in range(self.batch_size):
             h, w = [int(v) for v in torch.randint(320, 641, (2,), generator=hg)]            # COCO-sized frames
@@ -50,8 +50,9 @@ class SyntheticCocoModule:
             cls = torch.randint(0, self.num_classes, (n, 1), generator=g, device=self.device).float()
             objects.append(torch.cat([xy * scale, wh * scale, cls], 1))
         flips = draw_flips(self.batch_size, hg) if train else None                         # val / test: Resize only
+        ssr = draw_shift_scale_rotate(self.batch_size, hg) if train else None              # ShiftScaleRotate (p = 0.2)
         luts = photometric_luts(self.batch_size, hg) if train else None                    # RandomBrightnessContrast, RGBShift (p = 0.2)
-        return gpu_collate(images, objects, self.img_size, flips, self.channels_last, luts)
+        return gpu_collate(images, objects, self.img_size, flips, self.channels_last, luts, ssr)
 
     def _loader(self, offset):
         g = torch.Generator(device=self.device).manual_seed(self.seed + offset)

@@ -1,7 +1,9 @@
 """Device-side collate: raw uint8 frames in HBM -> the reference's wire format `(x f32 [B,3,S,S] in [0,1], y f32 [nT,6])`
-(`dataset/Pascal.py:121-186`): A.Resize (cv2 INTER_LINEAR fixed-point) + Horizontal/VerticalFlip + /255 + HWC->CHW and
-the COCO-pixel -> normalised row rewrite, in two HIP launches per batch instead of 5 CPU workers."""
+(`dataset/Pascal.py:121-186`): the whole train transform -- A.Resize (cv2 INTER_LINEAR fixed-point), Horizontal/VerticalFlip,
+ShiftScaleRotate (cv2.warpAffine, reflect-101), RandomBrightnessContrast + RGBShift (one composed LUT) -- then /255, HWC->CHW
+and the COCO-pixel -> normalised row rewrite, in two HIP launches per batch instead of 5 CPU workers."""
 import ctypes
+import math
 
 import torch
 
@@ -36,10 +38,44 @@ def photometric_luts(batch_size, generator=None, p_bc=0.2, p_rgb=0.2, brightness
     return luts
 
 
-def gpu_collate(images, objects, img_size, flips=None, channels_last=False, luts=None):
+def draw_shift_scale_rotate(batch_size, generator=None, p=0.2, shift_limit=0.0625, scale_limit=0.1, rotate_limit=45.0):
+    """`A.ShiftScaleRotate(p=0.2)` with albumentations 0.5.2's defaults (`Pascal.py:217`): per image None, or
+    (angle in degrees, scale, dx, dy) drawn uniformly from (-45, 45), (0.9, 1.1), (-0.0625, 0.0625)^2."""
+    u = torch.rand(batch_size, 5, generator=generator)
+    out = []
+    for b in range(batch_size):
+        if u[b, 0] < p:
+            out.append(((float(u[b, 1]) * 2 - 1) * rotate_limit, 1.0 + (float(u[b, 2]) * 2 - 1) * scale_limit,
+                        (float(u[b, 3]) * 2 - 1) * shift_limit, (float(u[b, 4]) * 2 - 1) * shift_limit))
+        else:
+            out.append(None)
+    return out
+
+
+def affine_matrices(params, S):
+    """(angle, scale, dx, dy) -> (forward 2x3, inverse 2x3) in pixels of the S x S frame, exactly as albumentations 0.5.2 +
+    OpenCV build them: `cv2.getRotationMatrix2D((S/2, S/2), angle, scale)`, `M[0,2] += dx*S`, `M[1,2] += dy*S`
+    (functional.shift_scale_rotate), and cv2.warpAffine's own inversion of that matrix (imgwarp.cpp), all in double."""
+    angle, scale, dx, dy = params
+    a = angle * math.pi / 180.0
+    alpha, beta = math.cos(a) * scale, math.sin(a) * scale
+    cx = cy = S / 2
+    M = [alpha, beta, (1 - alpha) * cx - beta * cy + dx * S, -beta, alpha, beta * cx + (1 - alpha) * cy + dy * S]
+    D = M[0] * M[4] - M[1] * M[3]
+    D = 1.0 / D if D != 0 else 0.0
+    A11, A22 = M[4] * D, M[0] * D
+    inv = [A11, M[1] * -D, 0.0, M[3] * -D, A22, 0.0]
+    inv[2] = -inv[0] * M[2] - inv[1] * M[5]
+    inv[5] = -inv[3] * M[2] - inv[4] * M[5]
+    return M, inv
+
+
+def gpu_collate(images, objects, img_size, flips=None, channels_last=False, luts=None, ssr=None):
     """images: list of uint8 [h, w, 3] CUDA tensors (contiguous, any sizes); objects: list of float [n_i, 5] CUDA tensors
     `(x, y, w, h, label)` in source pixels; flips: list of ints (None = no flips); luts: uint8 [B, 3, 256] (None = none),
-    see `photometric_luts` -> `(x, y)` on the same device."""
+    see `photometric_luts`; ssr: list of None / (angle, scale, dx, dy) per image, see `draw_shift_scale_rotate`
+    -> `(x, y)` on the same device.  A batch in which ShiftScaleRotate fired drops the rows whose box left the frame, as
+    albumentations does -- the row count then comes from the device (one host sync, only for those batches)."""
     B = len(images)
     if B == 0:
         raise ValueError("empty batch")
@@ -59,8 +95,21 @@ def gpu_collate(images, objects, img_size, flips=None, channels_last=False, luts
     x = torch.empty((B, 3, img_size, img_size), dtype=torch.float32, device=dev,
                     memory_format=torch.channels_last if channels_last else torch.contiguous_format)
     stream = _lib.current_stream(dev)
-    _lib.check(_lib.lib().odpl_collate_images(descs, B, img_size, _lib.ptr(x), (ctypes.c_int64 * 4)(*x.stride()), stream),
-               "odpl_collate_images")
+    warped = ssr is not None and any(p is not None for p in ssr)
+    inv_host, fwd_rows = None, None
+    if warped:
+        inv_host = (ctypes.c_double * (6 * B))()
+        fwd_rows = []
+        for i, prm in enumerate(ssr):
+            if prm is None:
+                fwd_rows.append([0.0] * 7)
+                continue
+            fwd, inv = affine_matrices(prm, img_size)
+            descs[i].reserved = 1
+            inv_host[6 * i:6 * i + 6] = inv
+            fwd_rows.append([1.0] + fwd)
+    _lib.check(_lib.lib().odpl_collate_images_warp(descs, inv_host, B, img_size, _lib.ptr(x), (ctypes.c_int64 * 4)(*x.stride()), stream),
+               "odpl_collate_images_warp")
     counts = [int(o.shape[0]) for o in objects]
     nT = sum(counts)
     y = torch.empty((nT, 6), dtype=torch.float32, device=dev)
@@ -68,6 +117,10 @@ def gpu_collate(images, objects, img_size, flips=None, channels_last=False, luts
         obj = torch.cat([o.reshape(-1, 5).float() for o in objects], 0).contiguous()
         row_img = torch.repeat_interleave(torch.arange(B, dtype=torch.int32), torch.tensor(counts)).to(dev, non_blocking=True)
         dims = torch.tensor([[im.shape[0], im.shape[1], f] for im, f in zip(images, flips)], dtype=torch.int32).to(dev, non_blocking=True)
-        _lib.check(_lib.lib().odpl_collate_targets(_lib.ptr(obj), _lib.ptr(row_img), _lib.ptr(dims), nT, img_size, _lib.ptr(y), stream),
-                   "odpl_collate_targets")
+        aff = torch.tensor(fwd_rows, dtype=torch.float64).to(dev, non_blocking=True) if warped else None
+        keep = torch.empty(nT, dtype=torch.uint8, device=dev) if warped else None
+        _lib.check(_lib.lib().odpl_collate_targets_warp(_lib.ptr(obj), _lib.ptr(row_img), _lib.ptr(dims), _lib.ptr(aff), nT, img_size,
+                                                        _lib.ptr(y), _lib.ptr(keep), stream), "odpl_collate_targets_warp")
+        if warped:
+            y = y[keep.bool()]                      # albumentations' filter_bboxes: rows without area left are dropped
     return x, y

@@ -22,6 +22,9 @@ n = B * 7
 wh = torch.rand(n, 2, generator=g) * 0.48 + 0.02
 tgt = torch.cat([torch.arange(B).repeat_interleave(7).float()[:, None], torch.randint(0, C, (n, 1), generator=g).float(),
                  torch.rand(n, 2, generator=g) * (1 - wh), wh], 1).to(dev)
+if "HG_ROWS" in os.environ:
+    from objectdetectionpl_amd import _lib
+    _lib.check(_lib.lib().odpl_head_conv_tune(int(os.environ["HG_ROWS"])), "odpl_head_conv_tune")
 crit = MultiScaleRegionLoss_v4(A9, M3, "bce_loss", "smooth_l1_loss", "bce_loss", C, 416)
 big = torch.empty(1 << 28, dtype=torch.float32, device=dev) if cold else None
 xs = [torch.randn(B, c, G, G, generator=g).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_() for c, G in ((256, 52), (512, 26), (1024, 13))]
