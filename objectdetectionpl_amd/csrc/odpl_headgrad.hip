@@ -33,7 +33,7 @@ using namespace odpl;
 constexpr int kThreads = 256;
 constexpr int kMaxA = 5;
 constexpr int kMaxRows = 4096;          // matched rows per head the finish kernel stages in LDS
-int g_rows_per_tile = 32;
+int g_rows_per_tile = 32;              // rows of X per workgroup (measured best at config 2: 28.2 us; 0 = auto: one resident wave of workgroups, 29.8 us)
 
 struct Head {
     const void* x; const float* w; void* gx; float* gw; float* gb;
@@ -435,7 +435,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct HPlan { int ntiles, rows_per_tile, tpr, rows_par, ncs, cv, cq; size_t part_w, part_b, bytes; size_t lds_stream; };
 
-bool plan_one(const odpl_head_conv_t* h, const odpl_sparse_grad_t* g, HPlan* p) {
+bool plan_one(const odpl_head_conv_t* h, const odpl_sparse_grad_t* g, int rows_per_tile, HPlan* p) {
     if (!h || !g || !h->x || !h->w) return false;
     const int E = h->bf16 ? 8 : 4;
     if (h->Cin < E || h->Cin % E != 0) return false;
@@ -449,13 +449,30 @@ bool plan_one(const odpl_head_conv_t* h, const odpl_sparse_grad_t* g, HPlan* p) 
     int tpr = 1; while (tpr < p->cv && tpr < 64) tpr <<= 1;
     p->tpr = tpr; p->rows_par = kThreads / tpr;
     p->ncs = (p->cv + tpr - 1) / tpr;
-    p->rows_per_tile = g_rows_per_tile;
+    p->rows_per_tile = rows_per_tile;
     p->ntiles = (int)((N + p->rows_per_tile - 1) / p->rows_per_tile);
     p->part_w = 0;
     p->part_b = align_up((size_t)p->ntiles * g->A * h->Cin * sizeof(float), 256);
     p->bytes = p->part_b + align_up((size_t)p->ntiles * g->A * sizeof(float), 256);
     p->lds_stream = ((size_t)p->rows_per_tile * g->A + (size_t)p->rows_par * g->A * tpr * E) * sizeof(float);
     return p->lds_stream <= 64 * 1024;
+}
+
+// rows per tile for a set of heads: the tunable, or (auto) the smallest height >= 16 for which all heads' workgroups are
+// resident at once -- 256 CUs x 8 workgroups of 256 threads -- so that no CU is left with a ninth tile while others idle
+int pick_rows(int n, const odpl_head_conv_t* heads, const odpl_sparse_grad_t* grads) {
+    if (g_rows_per_tile > 0) return g_rows_per_tile;
+    for (int r = 16; r < 1024; ++r) {
+        long long blocks = 0;
+        for (int i = 0; i < n; ++i) {
+            const int E = heads[i].bf16 ? 8 : 4, cv = heads[i].Cin / E;
+            int tpr = 1; while (tpr < cv && tpr < 64) tpr <<= 1;
+            const long long N = (long long)grads[i].B * grads[i].G2;
+            blocks += ((N + r - 1) / r) * ((cv + tpr - 1) / tpr);
+        }
+        if (blocks <= 2048) return r;
+    }
+    return 1024;
 }
 
 template <bool BF>
@@ -484,9 +501,11 @@ int launch(const Multi& M, int A, int nstream, int nfinish, size_t lds_stream, h
 extern "C" size_t odpl_head_conv_backward_multi_workspace_bytes(int32_t n, const odpl_head_conv_t* heads, const odpl_sparse_grad_t* grads) {
     if (n < 1 || n > ODPL_MAX_SCALES || !heads || !grads) return 0;
     size_t total = 0;
+    for (int i = 0; i < n; ++i) if (!heads[i].x || heads[i].Cin < 4 || grads[i].B < 1 || grads[i].G2 < 1) return 0;
+    const int rows = pick_rows(n, heads, grads);
     for (int i = 0; i < n; ++i) {
         HPlan p;
-        if (!plan_one(&heads[i], &grads[i], &p)) return 0;
+        if (!plan_one(&heads[i], &grads[i], rows, &p)) return 0;
         if (grads[i].A != grads[0].A || (heads[i].bf16 != 0) != (heads[0].bf16 != 0)) return 0;
         total += p.bytes;
     }
@@ -506,11 +525,12 @@ extern "C" int odpl_head_conv_backward_multi(int32_t n, const odpl_head_conv_t* 
     char* ws = (char*)workspace;
     size_t off = 0, lds_stream = 0;
     int nst = 0;
+    const int rows = pick_rows(n, heads, grads);
     for (int k = 0; k < n; ++k) {
         const odpl_head_conv_t* h = &heads[order[k]];
         const odpl_sparse_grad_t* g = &grads[order[k]];
         HPlan pl;
-        if (!plan_one(h, g, &pl)) return ODPL_EINVAL;
+        if (!plan_one(h, g, rows, &pl)) return ODPL_EINVAL;
         if (((uintptr_t)h->x & 15) || ((uintptr_t)h->w & 15) || ((uintptr_t)h->grad_x & 15) || ((uintptr_t)h->grad_w & 15)) return ODPL_EINVAL;
         Head& P = M.h[k];
         P.x = h->x; P.w = h->w; P.gx = h->grad_x; P.gw = h->grad_w; P.gb = h->grad_b;
@@ -548,7 +568,7 @@ extern "C" int odpl_head_conv_backward(const odpl_head_conv_t* h, const odpl_spa
 }
 
 extern "C" int odpl_head_conv_tune(int32_t rows_per_tile) {
-    if (rows_per_tile < 4 || rows_per_tile > 1024) return ODPL_EINVAL;
+    if (rows_per_tile != 0 && (rows_per_tile < 4 || rows_per_tile > 1024)) return ODPL_EINVAL;
     g_rows_per_tile = rows_per_tile;
     return 0;
 }

@@ -149,24 +149,31 @@ class DataParallelHost(torch.nn.Module):
         self.module = module
         self.group = group
         self.broadcast_buffers = broadcast_buffers
+        self._groups = None
         with torch.no_grad():                      # replicas start from rank 0's weights and buffers, like DDP
             for t in list(module.parameters()) + list(module.buffers()):
                 dist.broadcast(t, 0, group=group)
         self.averager = GradAverager(module.parameters(), bucket_mb, first_bucket_mb, group)
 
+    def _buffer_groups(self):
+        """buffers grouped by (dtype, device), with their sizes -- built once (the module's buffer set is static)"""
+        if self._groups is None:
+            by = {}
+            for b in self.module.buffers():
+                by.setdefault((b.dtype, b.device), []).append(b)
+            self._groups = [(bufs, [b.numel() for b in bufs]) for bufs in by.values()]
+        return self._groups
+
     def sync_buffers(self):
         if not self.broadcast_buffers or not self.averager.enabled:          # inside no_sync DDP skips it too
             return
-        by_dtype = {}
-        for b in self.module.buffers():
-            by_dtype.setdefault((b.dtype, b.device), []).append(b)
         rank0 = dist.get_rank(self.group) == 0
         with torch.no_grad():
-            for bufs in by_dtype.values():
-                flat = torch.cat([b.reshape(-1) for b in bufs])
+            for bufs, sizes in self._buffer_groups():
+                flat = torch.cat([b.reshape(-1) for b in bufs])               # one pack, one broadcast, one unpack per dtype
                 dist.broadcast(flat, 0, group=self.group)
                 if not rank0:
-                    torch._foreach_copy_(bufs, [v.view_as(b) for v, b in zip(flat.split([b.numel() for b in bufs]), bufs)])
+                    torch._foreach_copy_(bufs, [v.view_as(b) for v, b in zip(flat.split(sizes), bufs)])
 
     def forward(self, *a, **k):
         self.sync_buffers()
