@@ -197,11 +197,11 @@ def rocprof_row(kernel):
     """Average duration of `kernel` in the committed `rocprofv3 --kernel-trace --stats` summary of this command
     (profiles/r02_rocprof_stats_bench.csv), so the live event timing and the profiler's figure sit side by side."""
     import csv
-    for name in ("r02_rocprof_stats_bench.csv", "r01_rocprof_stats_yolo.csv"):
+    for name in ("r02_rocprof_stats_bench.csv", "r02dense_rocprof_stats_bench.csv"):
         try:
             with open(os.path.join(REPO, "profiles", name)) as f:
                 for row in csv.DictReader(f):
-                    if row.get("Name", "").startswith(kernel):
+                    if kernel + "(" in row.get("Name", "") or kernel + "<" in row.get("Name", ""):
                         return {"file": "profiles/" + name, "avg_us": round(float(row["AverageNs"]) / 1e3, 2), "calls": int(row["Calls"])}
         except Exception:  # noqa: BLE001
             continue

@@ -94,9 +94,9 @@ def main():
     loc = (torch.randn(B, An, 4, generator=g) * 0.3).to(dev).requires_grad_()
     cls = torch.randn(B, An, C, generator=g).to(dev).requires_grad_()
     tg = targets(g, B, 8, C, 0.05, 0.5)
-    rc = RetinaNetLoss(anchors, focal_loss, "smooth_l1_loss", C, 800)
+    rc = RetinaNetLoss(anchors, focal_loss, "smooth_l1_loss", C, (1333, 800))
     measure(f"config4 RetinaNet loss fwd+bwd (B=4, {An} anchors, C=80)", ["retina_assign", "retina_main"],
-            lambda: rc((loc, cls), tg), {"retina_main": 4 * B * An * 84 + 4 * B * An, "retina_assign": 16 * An + 4 * B * An},
+            lambda: rc((loc, cls), tg)["loss"].backward(), {"retina_main": 4 * B * An * 84 + 4 * B * An, "retina_assign": 16 * An + 4 * B * An},
             {"retina_main": "grad write + code read", "retina_assign": "anchors read + code write; IoU compute"})
     cls_n = (cls.detach() - 3.0)
     measure("config4 Retina greedy top-100 NMS", ["greedy_nms_prep", "greedy_nms_image"],
@@ -104,18 +104,30 @@ def main():
             {"greedy_nms_prep": 4 * B * An * C + 8 * B * An}, {"greedy_nms_prep": "class rows read (LDS staged) + score/label write",
                                                                  "greedy_nms_image": "1 WG/image"})
     del loc, cls, cls_n
-    # ---- config 5: YOLOv5-l loss (fp32 here)
+    # ---- config 5: YOLOv5-l loss; heads as the reference hands them (contiguous [B,na,G,G,no] = "interleaved") and as the
+    # permuted VIEW of the Detect convolution's NCHW output ("planar": what Yolo_Layers returns here)
     B, C = 32, 80
-    h5 = [torch.randn(B, 3, G, G, 85, generator=g).to(dev).requires_grad_() for G in (80, 40, 20)]
     t5 = targets(g, B, 7, C)
     c5 = MultiScaleRegionLoss_v5(V5A, None, None, None, None, C, 640)
     cells5 = sum(B * 3 * G * G for G in (80, 40, 20))
-    measure("config5 YOLOv5 loss fwd+bwd (B=32, C=80, 640^2, fp32)", ["yolov5_dense"], lambda: c5(h5, t5),
-            {"yolov5_dense": 4 * cells5 * 85 + 12 * cells5}, {"yolov5_dense": "grad write + objectness gather + owner map read/reset"})
-    h5b = [h.detach().bfloat16().requires_grad_() for h in h5]
-    del h5
-    measure("config5 YOLOv5 loss fwd+bwd (B=32, C=80, 640^2, bf16 heads -- the BASELINE dtype)", ["yolov5_dense"], lambda: c5(h5b, t5),
-            {"yolov5_dense": 2 * cells5 * 85 + 10 * cells5}, {"yolov5_dense": "bf16 grad write + objectness gather + owner map read/reset"})
+    base = [torch.randn(B, 3 * 85, G, G, generator=g).to(dev) for G in (80, 40, 20)]
+
+    def views(dtype, planar):
+        out = []
+        for t in base:
+            t = t.to(dtype)
+            v = t.view(B, 3, 85, t.shape[2], t.shape[3]).permute(0, 1, 3, 4, 2)
+            out.append((v if planar else v.contiguous()).detach().requires_grad_())
+        return out
+    for dtype, es, tag in ((torch.float32, 4, "fp32"), (torch.bfloat16, 2, "bf16 heads -- the BASELINE dtype")):
+        for planar in (False, True):
+            hs = views(dtype, planar)
+            measure(f"config5 YOLOv5 loss fwd+bwd (B=32, C=80, 640^2, {tag}, {'planar view' if planar else 'interleaved'})",
+                    ["yolov5_obj", "yolov5_dense"], lambda: c5(hs, t5)["loss"].backward(),
+                    {"yolov5_dense": es * cells5 * 85 + 4 * cells5, "yolov5_obj": es * cells5 + 12 * cells5},
+                    {"yolov5_dense": "v5_expand_kernel: dense grad write + compact objectness-grad read",
+                     "yolov5_obj": "objectness logit + owner map read, owner reset, compact grad write"})
+            del hs
 
 
 if __name__ == "__main__":

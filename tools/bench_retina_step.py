@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""BASELINE config 4 as a full training step (secondary number; the judged bench is config 2): RetinaNet-R50-FPN, C = 80,
+B = 4, 800 x 1333 input (x[4, 3, 800, 1333]) -> 200 700 anchors, focal + SmoothL1 through the HIP RetinaNet loss with the
+per-axis target scale (width 1333, height 800), fused Adam, fp32, channels-last.  MIOpen immediate mode unless --miopen-find."""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from objectdetectionpl_amd import _lib
+from objectdetectionpl_amd.LightningFunc.losses_dense import RetinaNetLoss, focal_loss
+from objectdetectionpl_amd.LightningFunc.utils.RetinaUtils import get_anchor_boxes
+from objectdetectionpl_amd.model.RetinaNet import RetinaNet
+
+
+class Args:
+    model_name = "RetinaNet"; cls_criterion = "focal_loss"; coord_criterion = "smooth_l1_loss"; data_module = "synthetic"
+    lr = 1e-3; weight_decay = 1e-5
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--height", type=int, default=800)
+    ap.add_argument("--width", type=int, default=1333)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--miopen-find", action="store_true")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    torch.backends.cudnn.benchmark = bool(a.miopen_find)
+    torch.manual_seed(0)
+    model = RetinaNet([str(i) for i in range(80)], Args()).to(dev).to(memory_format=torch.channels_last).train()
+    anchors = get_anchor_boxes(torch.Tensor([a.width, a.height]), dev)              # RetinaUtils.get_anchor_boxes takes (w, h)
+    crit = RetinaNetLoss(anchors, focal_loss, "smooth_l1_loss", 80, (a.width, a.height))
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5, fused=True)
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(a.batch, 3, a.height, a.width, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    n = a.batch * 8
+    wh = torch.rand(n, 2, generator=g) * 0.45 + 0.05
+    y = torch.cat([torch.arange(a.batch).repeat_interleave(8).float()[:, None], torch.randint(0, 80, (n, 1), generator=g).float(),
+                   torch.rand(n, 2, generator=g) * 0.6 + 0.2, wh], 1).to(dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        model.iou_boxes = anchors                         # forward only needs the table to exist on the device
+        out = model(x)
+        d = crit(out, y)
+        d["loss"].backward()
+        opt.step()
+        return d, out
+
+    t0 = time.perf_counter()
+    for i in range(a.warmup):
+        d, out = step()
+        torch.cuda.synchronize()
+        print(f"[{time.perf_counter() - t0:6.1f}s] warmup {i + 1}/{a.warmup}", file=sys.stderr, flush=True)
+    PROF = ("retina_assign", "retina_main")
+    for k in PROF:
+        _lib.profile_enable(k, True)
+    t1 = time.perf_counter()
+    for _ in range(a.steps):
+        d, out = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t1) / a.steps
+    kern = {}
+    for k in PROF:
+        _lib.profile_enable(k, False)
+        ms = _lib.profile_collect(k)[0]
+        if ms:
+            kern[k + "_us"] = round(1e3 * sum(ms) / len(ms), 2)
+    assert out[0].shape[1] == anchors.shape[0] == 200700 or (a.height, a.width) != (800, 1333)
+    print(json.dumps({"workload": f"RetinaNet-R50-FPN {a.height}x{a.width} bs={a.batch} training step, fp32, C=80, {anchors.shape[0]} anchors",
+                      "img_per_s": round(a.batch / dt, 2), "ms_per_step": round(dt * 1e3, 2), "loss": round(float(d["loss"].detach()), 4),
+                      "num_pos": int(crit.last_counts[0]), "miopen_find": bool(a.miopen_find), **kern}))
+
+
+if __name__ == "__main__":
+    main()
