@@ -63,3 +63,59 @@ def test_region_loss_replays_from_a_hip_graph():
             assert torch.equal(got[k], ref[k]), (trial, k)           # same kernels, same order: bitwise equal
         for a, b in zip(got_g, eager_heads):
             assert torch.equal(a, b.grad)
+
+
+def test_hosted_heads_and_structured_backward_replay_from_a_hip_graph():
+    """The training route of the package's models -- x -> hosted head convs (library GEMM) -> criterion -> structured head backward
+    (odpl_headgrad.hip) -- captured as one HIP graph: replays bitwise equal to the eager run on new data in the same buffers."""
+    import torch.nn as nn
+    from objectdetectionpl_amd.LightningFunc.losses import MultiScaleRegionLoss_v4
+    from objectdetectionpl_amd.LightningFunc.utils.headconv import HeadConv2d
+    dev = torch.device("cuda:0")
+    B, C = 4, 20
+    g = torch.Generator().manual_seed(6)
+    cins, Gs = (64, 128, 256), (52, 26, 13)
+    torch.manual_seed(2)
+    convs = nn.ModuleList(HeadConv2d(c, 3 * (5 + C), 1) for c in cins).to(dev)
+    crit = MultiScaleRegionLoss_v4(ANCHORS, MASKS, "bce_loss", "smooth_l1_loss", "bce_loss", C, 416)
+    static_x = [(torch.randn(B, c, G, G, generator=g) * 0.5).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+                for c, G in zip(cins, Gs)]
+    static_tgt = _targets(g, B, 5, C).to(dev)
+
+    def run(xs, tgt):
+        for t in list(xs) + list(convs.parameters()):
+            t.grad = None
+        out = crit([c(x) for c, x in zip(convs, xs)], tgt)
+        out["loss"].backward()
+        return out
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            run(static_x, static_tgt)
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    for t in list(static_x) + list(convs.parameters()):
+        t.grad = None
+    with torch.cuda.graph(graph):
+        static_out = run(static_x, static_tgt)
+    static_grads = [x.grad for x in static_x] + [p.grad for p in convs.parameters()]
+    for trial in range(2):
+        new_x = [(torch.randn(x.shape, generator=g) * 0.5).to(dev).contiguous(memory_format=torch.channels_last) for x in static_x]
+        new_tgt = _targets(g, B, 5, C).to(dev)
+        with torch.no_grad():
+            for x, n in zip(static_x, new_x):
+                x.copy_(n)
+            static_tgt.copy_(new_tgt)
+        graph.replay()
+        torch.cuda.synchronize()
+        got = {k: v.clone() for k, v in static_out.items()}
+        got_g = [t.clone() for t in static_grads]
+        eager_x = [n.clone().requires_grad_() for n in new_x]
+        ref = run(eager_x, new_tgt)
+        ref_g = [x.grad for x in eager_x] + [p.grad for p in convs.parameters()]
+        for k in ref:
+            assert torch.equal(got[k], ref[k]), (trial, k)
+        for a, b in zip(got_g, ref_g):
+            assert torch.equal(a, b)

@@ -237,3 +237,38 @@ def test_yolov4_model_step_uses_the_structured_backward():
         _close(a, b, 1e-3, 1e-3)
     for n in res[0][1]:
         _close(res[0][1][n], res[1][1][n], 1e-3, 1e-3)
+
+
+def test_structured_backward_under_the_rccl_gradient_averager():
+    """World size 1 over RCCL ("nccl" IS RCCL on ROCm): the YOLOv4 model wrapped by `parallel.wrap_data_parallel` -- buffer
+    broadcast, bucketed all-reduce fired from the parameter hooks, gradients re-pointed at the flat buckets -- with the
+    criterion running the head convolutions' backward itself.  The averaged gradients equal the unwrapped model's."""
+    import argparse
+    import os
+    import torch.distributed as dist
+    from objectdetectionpl_amd import parallel
+    from objectdetectionpl_amd.model.YOLOV4 import YOLOv4
+    args = argparse.Namespace(model_name="YOLOv4", cls_criterion="bce_loss", coord_criterion="smooth_l1_loss", data_module="synthetic")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("nccl", device_id=torch.device(DEV))
+    try:
+        torch.manual_seed(0)
+        model = YOLOv4([str(i) for i in range(6)], args).to(DEV).to(memory_format=torch.channels_last).train()
+        g = torch.Generator().manual_seed(1)
+        x = torch.rand(2, 3, 416, 416, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+        y = _targets(g, 2, 4, 6).to(DEV)
+        heads = ("head.conv2.conv.0.weight", "head.conv10.conv.0.bias", "head.conv18.conv.0.weight")
+        model.criterion(model(x), y)["loss"].backward()
+        want = {n: p.grad.clone() for n, p in model.named_parameters() if n in heads}
+        model.zero_grad(set_to_none=True)
+        net = parallel.wrap_data_parallel(model, DEV)
+        model.criterion(net(x), y)["loss"].backward()
+        torch.cuda.synchronize()
+        got = dict(model.named_parameters())
+        for n in heads:
+            assert got[n].grad.data_ptr() != 0 and torch.isfinite(got[n].grad).all()
+            _close(got[n].grad, want[n], 1e-3, 1e-3)
+        assert all(p.grad is not None for p in model.parameters())
+        net.averager.remove()
+    finally:
+        dist.destroy_process_group()
