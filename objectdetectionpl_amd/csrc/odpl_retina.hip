@@ -217,11 +217,16 @@ __global__ __launch_bounds__(kT) void retina_main_kernel(const RParams P) {
         fill_zero<NT, kT>(P.grad_cls, r0 * C, (r0 + na) * C);
         fill_zero<NT, kT>(P.grad_loc, r0 * 4, (r0 + na) * 4);
     } else {
+        // the runs of rows BETWEEN the tile's positive rows (ascending local indices in tile_pos) are 16-byte store streams
+        // like the clean tiles; only the positive rows themselves are left to the row waves
         if (tid < na && P.code[r0 + tid] <= 0) reinterpret_cast<float4*>(P.grad_loc)[r0 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int row = wv; row < na; row += kT / 64) {
-            if (P.code[r0 + row] > 0) continue;
-            float* gx = P.grad_cls + (r0 + row) * C;
-            for (int k = lane; k < C; k += 64) gx[k] = 0.f;
+        const int cnt = P.tile_cnt[tile];
+        const unsigned char* pos = P.tile_pos + (size_t)tile * kT;
+        int start = 0;
+        for (int i = 0; i <= cnt; ++i) {
+            const int end = i < cnt ? (int)pos[i] : na;
+            if (end > start) fill_zero<NT, kT>(P.grad_cls, (r0 + start) * C, (r0 + end) * C);
+            start = end + 1;
         }
     }
 }
