@@ -55,6 +55,13 @@ __device__ __forceinline__ void block_sum(float (&v)[N], float* sh) {
 }
 
 __device__ __forceinline__ float sigmoidf_(float z) { return 1.0f / (1.0f + expf(-z)); }
+// Hardware exp2 / reciprocal (1 ulp each; the scaled argument adds |z| * 2^-24 relative): for inference outputs whose
+// tests carry a 1e-5 relative tolerance.  -inf -> 0, +inf -> 1, NaN -> NaN like the exact form.
+__device__ __forceinline__ float sigmoid_fast(float z) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -1.44269504088896f)); }
+// e / d for 0 <= e < 2^16 and 1 <= d <= 2^16 with the host-side magic number ceil(2^32 / d) (exact: the excess e*r/(d*2^32) stays
+// below 1/d); d = 1 has no 32-bit magic and is passed as 0
+__device__ __forceinline__ int fastdiv16(int e, unsigned magic) { return magic ? (int)__umulhi((unsigned)e, magic) : e; }
+inline unsigned fastdiv16_magic(unsigned d) { return d <= 1 ? 0u : (unsigned)((0xffffffffull + d) / d); }
 
 // nn.BCELoss element (log clamped at -100; ATen uses log1p(-p) for the negative branch).
 __device__ __forceinline__ float bce_elem(float p, float t) {

@@ -23,6 +23,7 @@ struct DParams {
     int H[ODPL_MAX_SCALES], W[ODPL_MAX_SCALES], A[ODPL_MAX_SCALES], first[ODPL_MAX_SCALES + 1], blk0[ODPL_MAX_SCALES + 1];
     float aw[ODPL_MAX_SCALES][ODPL_MAX_ANCHORS], ah[ODPL_MAX_SCALES][ODPL_MAX_ANCHORS];
     int nscales, B, C, Ntot;
+    unsigned magic_c4, magic_c;       // ceil(2^32 / (C/4)), ceil(2^32 / C): the write phase divides tile-local indices < 2^16
     float sxy, sxy_off;               // scale_x_y and 0.5*(scale_x_y-1), YoloV4Utils.py:78
     float* boxes; float* confs;
 };
@@ -54,30 +55,30 @@ __global__ __launch_bounds__(kThreads) void yolo_decode_kernel(const DParams P) 
     if (tid < nc) {
         const int sp = sp0 + tid, gy = sp / P.W[s], gx = sp - gy * P.W[s];
         // YoloV4Utils.py:78-79, 110-145
-        const float bx = (sigmoidf_(s_t[0 * ld + tid]) * P.sxy - P.sxy_off + (float)gx) / (float)P.W[s];
-        const float by = (sigmoidf_(s_t[1 * ld + tid]) * P.sxy - P.sxy_off + (float)gy) / (float)P.H[s];
+        const float bx = (sigmoid_fast(s_t[0 * ld + tid]) * P.sxy - P.sxy_off + (float)gx) / (float)P.W[s];
+        const float by = (sigmoid_fast(s_t[1 * ld + tid]) * P.sxy - P.sxy_off + (float)gy) / (float)P.H[s];
         const float bw = (expf(s_t[2 * ld + tid]) * P.aw[s][a]) / (float)P.W[s];
         const float bh = (expf(s_t[3 * ld + tid]) * P.ah[s][a]) / (float)P.H[s];
         const float x1 = bx - bw * 0.5f, y1 = by - bh * 0.5f;                     // :153-156
         reinterpret_cast<float4*>(P.boxes)[n0 + tid] = make_float4(x1, y1, x1 + bw, y1 + bh);
-        s_t[4 * ld + tid] = sigmoidf_(s_t[4 * ld + tid]);                         // det conf, reused below
+        s_t[4 * ld + tid] = sigmoid_fast(s_t[4 * ld + tid]);                         // det conf, reused below
     }
     __syncthreads();
     float* dst = P.confs + n0 * C;                       // 64 candidates x C classes, contiguous
     if ((C & 3) == 0 && ((n0 * C) & 3) == 0) {           // 16-B stores: 4 consecutive classes of one candidate
         const int c4 = C >> 2;
         for (int e = tid; e < nc * c4; e += kThreads) {
-            const int i = e / c4, k = 4 * (e - i * c4);
+            const int i = fastdiv16(e, P.magic_c4), k = 4 * (e - i * c4);
             const float dc = s_t[4 * ld + i];
             float4 o;
-            o.x = sigmoidf_(s_t[(5 + k) * ld + i]) * dc; o.y = sigmoidf_(s_t[(6 + k) * ld + i]) * dc;      // :170
-            o.z = sigmoidf_(s_t[(7 + k) * ld + i]) * dc; o.w = sigmoidf_(s_t[(8 + k) * ld + i]) * dc;
+            o.x = sigmoid_fast(s_t[(5 + k) * ld + i]) * dc; o.y = sigmoid_fast(s_t[(6 + k) * ld + i]) * dc;      // :170
+            o.z = sigmoid_fast(s_t[(7 + k) * ld + i]) * dc; o.w = sigmoid_fast(s_t[(8 + k) * ld + i]) * dc;
             reinterpret_cast<float4*>(dst)[e] = o;
         }
     } else {
         for (int e = tid; e < nc * C; e += kThreads) {
-            const int i = e / C, k = e - i * C;
-            dst[e] = sigmoidf_(s_t[(5 + k) * ld + i]) * s_t[4 * ld + i];          // :170
+            const int i = fastdiv16(e, P.magic_c), k = e - i * C;
+            dst[e] = sigmoid_fast(s_t[(5 + k) * ld + i]) * s_t[4 * ld + i];       // :170
         }
     }
 }
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(kThreads) void yolo_decode_kernel(const DParams P) 
 extern "C" int odpl_yolo_decode(const odpl_yolo_decode_desc_t* d, float* boxes, float* confs, void* stream_) {
     if (!d || !boxes || !confs || d->nscales < 1 || d->nscales > ODPL_MAX_SCALES || d->B < 1 || d->C < 1) return ODPL_EINVAL;
     if ((uintptr_t)boxes & 15) return ODPL_EINVAL;
-    if ((size_t)(5 + d->C) * (kCells + 1) * 4 > 150 * 1024) return ODPL_EINVAL;
+    if ((size_t)(5 + d->C) * (kCells + 1) * 4 > 150 * 1024 || d->C > 1023) return ODPL_EINVAL;      // kCells * C < 2^16 (fastdiv16)
     DParams P;
     int first = 0, blk = 0;
     for (int i = 0; i < ODPL_MAX_SCALES; ++i) {
@@ -104,6 +105,7 @@ extern "C" int odpl_yolo_decode(const odpl_yolo_decode_desc_t* d, float* boxes, 
     P.nscales = d->nscales; P.B = d->B; P.C = d->C; P.Ntot = first;
     P.sxy = d->scale_x_y; P.sxy_off = d->scale_x_y_offset;
     P.boxes = boxes; P.confs = confs;
+    P.magic_c = fastdiv16_magic((unsigned)d->C); P.magic_c4 = fastdiv16_magic((unsigned)(d->C >> 2));
     hipStream_t stream = (hipStream_t)stream_;
     prof_begin(ODPL_PROF_YOLO_DECODE, stream);
     hipLaunchKernelGGL(yolo_decode_kernel, dim3(blk, d->B), dim3(kThreads), (size_t)(5 + d->C) * (kCells + 1) * 4, stream, P);

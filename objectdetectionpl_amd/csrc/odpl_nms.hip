@@ -472,6 +472,7 @@ extern "C" int odpl_yolo_nms(const odpl_yolo_nms_desc_t* d, void* workspace, siz
 // (2) RetinaNet / SSD greedy top-k NMS
 namespace {
 constexpr int kRows = 64;             // anchors per LDS sub-tile in the prep kernel (4 lanes scan one row)
+constexpr int kPrepLoads = 5;         // 16-B loads in flight per lane while a tile is staged
 constexpr int kMaxTopk = 1024;
 constexpr int kKeyRegs = 48;           // candidate keys per thread held in registers during the top-k bisection (49 152 candidates)
 
@@ -481,6 +482,7 @@ struct GParams {
     float nms_thresh, class_thresh;
     float* score; int* label;          // [B*An] all anchors
     float* ckey; int* cidx;            // [B*An] candidates (compacted, index order)
+    unsigned magic_c4, magic_c;        // fastdiv16 magics of C/4 and C (tile-local indices < 2^16)
     int* tile_cnt; int ntiles;         // [B*ntiles] candidates per kRows-anchor tile (written by the prep kernel)
     float* out; int* out_counts;
 };
@@ -492,40 +494,18 @@ __device__ __forceinline__ Box4 decode_anchor(const float* loc4, const float* an
     return corners_of(x, y, w, h);
 }
 
-__global__ __launch_bounds__(256) void greedy_nms_prep_kernel(const GParams P) {
-    extern __shared__ float s_tile[];                       // kRows * ld
-    const int b = blockIdx.y, tid = threadIdx.x, C = P.C;
-    const bool vec = (C & 3) == 0;
-    const int ld = vec ? C + 4 : C + 1;                     // C+4: rows stay 16-B aligned, and (C+4) mod 32 spreads the 8 rows
-    const int a0 = blockIdx.x * kRows;                      // of a 32-lane group over distinct banks for C = 80
-    const int nr = (P.An - a0) < kRows ? (P.An - a0) : kRows;
-    const float* src = P.cls + ((size_t)b * P.An + a0) * C;
-    const int n = nr * C;
-    if (vec) {                                              // the 64 x C tile is contiguous: 16-B loads, 4 in flight per lane
-        const float4* src4 = reinterpret_cast<const float4*>(src);
-        const int n4 = n >> 2, c4 = C >> 2;
-        for (int e = tid; e < n4; e += 4 * 256) {
-            float4 v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = (e + u * 256) < n4 ? src4[e + u * 256] : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int ee = e + u * 256;
-                if (ee < n4) { const int r = ee / c4; *reinterpret_cast<float4*>(&s_tile[r * ld + 4 * (ee - r * c4)]) = v[u]; }
-            }
-        }
-    } else {
-        for (int e = tid; e < n; e += 256) { const int r = e / C; s_tile[r * ld + (e - r * C)] = src[e]; }
-    }
-    __syncthreads();
-    const int r = tid >> 2, q = tid & 3;
-    float best = -1.f; int bi = 0x7fffffff;                 // sigmoid > 0 > -1
-    if (r < nr) {
-        for (int k = q; k < C; k += 4) {
-            const float s = sigmoidf_(s_tile[r * ld + k]);
-            if (s > best || (s != s && best == best)) { best = s; bi = k; }
-        }
-    }
+// Scores and labels of one tile of kRows anchors: torch.max(sigmoid(cls), 1) (RetinaNet.py:128).
+//
+// The kernel streams 4*C bytes per anchor and is bounded by HBM only while a wave spends < ~500 VALU issues per 20-KB tile (a
+// wave64 instruction occupies its SIMD for 4 cycles; tools/probe_rowmax.hip: 49 us with a bare row maximum, 99 us with 20
+// exact sigmoids per lane).  So the sigmoid is evaluated on few elements.  With m the row's largest logit, an element
+// l < m - 1/16 has sigmoid(l) STRICTLY below sigmoid(m) once both are rounded, provided l <= 8 (relative gap >=
+// (1 - sigmoid(8)) / 16 = 2e-5, against a few 6e-8 ulps of evaluation error; above 8 neighbours can round to the same float, up
+// to 1.0f) and m >= -80 (below, 1 + exp(-l) overflows towards a sigmoid of 0 for everything).  Such elements can neither win
+// nor tie; all the others -- NaNs included, `!(l < thr)` -- are evaluated exactly, in index order.  Lanes walk a bit mask of
+// their survivors: a wave runs max-over-lanes (about 2) sigmoids instead of C/4.
+__device__ __forceinline__ float prep_threshold(float m) { return !(m >= -80.0f) ? -INFINITY : fminf(m - 0.0625f, 8.0f); }
+__device__ __forceinline__ void prep_combine_and_store(const GParams& P, int b, int a0, int r, int q, int nr, float best, int bi) {
     // combine the 4 lanes of a row: larger value, then smaller index (torch.max(1): first index on ties)
     for (int o = 1; o < 4; o <<= 1) {
         const float ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
@@ -539,9 +519,99 @@ __global__ __launch_bounds__(256) void greedy_nms_prep_kernel(const GParams P) {
     // sweeping all An scores behind workgroup barriers
     __shared__ int s_tc[4];
     const unsigned long long pm = __ballot(r < nr && q == 0 && best > P.class_thresh);
-    if ((tid & 63) == 0) s_tc[tid >> 6] = __popcll(pm);
+    if ((threadIdx.x & 63) == 0) s_tc[threadIdx.x >> 6] = __popcll(pm);
     __syncthreads();
-    if (tid == 0) P.tile_cnt[(size_t)b * P.ntiles + blockIdx.x] = s_tc[0] + s_tc[1] + s_tc[2] + s_tc[3];
+    if (threadIdx.x == 0) P.tile_cnt[(size_t)b * P.ntiles + blockIdx.x] = s_tc[0] + s_tc[1] + s_tc[2] + s_tc[3];
+}
+
+// Class count known at compile time and a multiple of 16 (80: COCO, the BASELINE configs).  The tile is a plain contiguous copy
+// into LDS (pitch C, no padding, no index arithmetic); lane q of a row owns the contiguous quarter [q*C/4, (q+1)*C/4) and reads
+// it with 16-B LDS loads -- conflict-free without padding: the 16 lanes of one LDS pass start at the 16-B groups
+// 20 r + 5 q (mod 16) = 4 r + 5 q, all distinct for r, q in 0..3 -- and keeps it in registers for both scans.
+template <int CT>
+__global__ __launch_bounds__(256) void greedy_nms_prep_ct_kernel(const GParams P) {
+    static_assert(CT % 16 == 0 && CT / 4 <= 32, "quarter rows of whole 16-B vectors, one 32-bit survivor mask per lane");
+    constexpr int C4 = CT / 4, PER = CT / 4, V = PER / 4, N4 = kRows * C4, U = (N4 + 255) / 256;
+    extern __shared__ __align__(16) float s_tile[];         // kRows * CT
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int a0 = blockIdx.x * kRows;
+    const int nr = (P.An - a0) < kRows ? (P.An - a0) : kRows;
+    const float4* src4 = reinterpret_cast<const float4*>(P.cls + ((size_t)b * P.An + a0) * CT);
+    float4* s4 = reinterpret_cast<float4*>(s_tile);
+    const int n4 = nr * C4;
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = (tid + u * 256) < n4 ? src4[tid + u * 256] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < U; ++u) if (tid + u * 256 < N4) s4[tid + u * 256] = v[u];
+    __syncthreads();
+    const int r = tid >> 2, q = tid & 3;
+    float l[PER];
+#pragma unroll
+    for (int i = 0; i < V; ++i) { const float4 t = s4[r * C4 + q * V + i]; l[4 * i] = t.x; l[4 * i + 1] = t.y; l[4 * i + 2] = t.z; l[4 * i + 3] = t.w; }
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) m = fmaxf(m, l[j]);                      // fmaxf skips NaNs
+    m = fmaxf(m, __shfl_xor(m, 1, 64)); m = fmaxf(m, __shfl_xor(m, 2, 64));
+    const float thr = prep_threshold(m);
+    unsigned need = 0u;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) need |= (unsigned)(!(l[j] < thr)) << j;
+    float best = -1.f; int bi = 0x7fffffff;                 // sigmoid > 0 > -1
+    const float* mine = s_tile + r * CT + q * PER;
+    while (need) {
+        const int j = __builtin_ctz(need);
+        need &= need - 1u;
+        const float sg = sigmoidf_(mine[j]);
+        if (sg > best || (sg != sg && best == best)) { best = sg; bi = q * PER + j; }
+    }
+    prep_combine_and_store(P, b, a0, r, q, nr, best, bi);
+}
+
+// Any class count: lanes q, q+4, ... of a row (pitch C+4 / C+1: conflict-free 4-B LDS reads), two scans of the LDS row.
+__global__ __launch_bounds__(256) void greedy_nms_prep_kernel(const GParams P) {
+    extern __shared__ __align__(16) float s_tile[];         // kRows * ld
+    const int b = blockIdx.y, tid = threadIdx.x, C = P.C;
+    const bool vec = (C & 3) == 0;
+    const int ld = vec ? C + 4 : C + 1;                     // C+4: rows stay 16-B aligned
+    const int a0 = blockIdx.x * kRows;
+    const int nr = (P.An - a0) < kRows ? (P.An - a0) : kRows;
+    const float* src = P.cls + ((size_t)b * P.An + a0) * C;
+    const int n = nr * C;
+    if (vec) {                                              // the 64 x C tile is contiguous: 16-B loads, kPrepLoads in flight per lane
+        const float4* src4 = reinterpret_cast<const float4*>(src);
+        const int n4 = n >> 2, c4 = C >> 2;
+        for (int e = tid; e < n4; e += kPrepLoads * 256) {
+            float4 v[kPrepLoads];
+#pragma unroll
+            for (int u = 0; u < kPrepLoads; ++u) v[u] = (e + u * 256) < n4 ? src4[e + u * 256] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < kPrepLoads; ++u) {
+                const int ee = e + u * 256;
+                if (ee < n4) { const int r = fastdiv16(ee, P.magic_c4); *reinterpret_cast<float4*>(&s_tile[r * ld + 4 * (ee - r * c4)]) = v[u]; }
+            }
+        }
+    } else {
+        for (int e = tid; e < n; e += 256) { const int r = fastdiv16(e, P.magic_c); s_tile[r * ld + (e - r * C)] = src[e]; }
+    }
+    __syncthreads();
+    const int r = tid >> 2, q = tid & 3;
+    float best = -1.f; int bi = 0x7fffffff;                 // sigmoid > 0 > -1
+    const float* row = s_tile + (r < nr ? r : 0) * ld;
+    float m = -INFINITY;
+    for (int k = q; k < C; k += 4) m = fmaxf(m, row[k]);                   // fmaxf skips NaNs
+    m = fmaxf(m, __shfl_xor(m, 1, 64)); m = fmaxf(m, __shfl_xor(m, 2, 64));
+    const float thr = prep_threshold(m);
+    unsigned long long need = 0ull;                                         // C <= 236: at most 59 elements per lane
+    int j = 0;
+    for (int k = q; k < C; k += 4, ++j) need |= (unsigned long long)(!(row[k] < thr)) << j;
+    while (need) {
+        const int k = q + 4 * __builtin_ctzll(need);
+        need &= need - 1ull;
+        const float sg = sigmoidf_(row[k]);
+        if (sg > best || (sg != sg && best == best)) { best = sg; bi = k; }
+    }
+    prep_combine_and_store(P, b, a0, r, q, nr, best, bi);
 }
 
 __global__ __launch_bounds__(kImgT) void greedy_nms_image_kernel(const GParams P) {
@@ -755,9 +825,11 @@ extern "C" int odpl_greedy_nms(const odpl_greedy_nms_desc_t* d, void* workspace,
     P.nms_thresh = d->nms_thresh; P.class_thresh = d->class_thresh;
     P.score = (float*)(ws + pl.score); P.label = (int*)(ws + pl.label); P.ckey = (float*)(ws + pl.ckey); P.cidx = (int*)(ws + pl.cidx);
     P.tile_cnt = (int*)(ws + pl.tile_cnt); P.ntiles = pl.ntiles;
+    P.magic_c = fastdiv16_magic((unsigned)d->C); P.magic_c4 = fastdiv16_magic((unsigned)(d->C >> 2));
     P.out = out_dets; P.out_counts = out_counts;
     prof_begin(ODPL_PROF_GREEDY_NMS_PREP, stream);
-    hipLaunchKernelGGL(greedy_nms_prep_kernel, dim3((d->An + kRows - 1) / kRows, d->B), dim3(256), (size_t)kRows * (d->C + 4) * 4, stream, P);
+    if (d->C == 80) hipLaunchKernelGGL(greedy_nms_prep_ct_kernel<80>, dim3((d->An + kRows - 1) / kRows, d->B), dim3(256), (size_t)kRows * 80 * 4, stream, P);
+    else hipLaunchKernelGGL(greedy_nms_prep_kernel, dim3((d->An + kRows - 1) / kRows, d->B), dim3(256), (size_t)kRows * (d->C + 4) * 4, stream, P);
     prof_end(ODPL_PROF_GREEDY_NMS_PREP, stream);
     ODPL_HIP_TRY(hipGetLastError());
     prof_begin(ODPL_PROF_GREEDY_NMS_IMAGE, stream);

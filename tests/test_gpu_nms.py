@@ -153,6 +153,9 @@ def test_greedy_prep_scores_and_labels_equal_the_max_over_sigmoids():
     base = torch.rand(An, generator=g) * 6
     cls[0, 4:, 11] = base[4:]; cls[0, 4:, 60] = base[4:] + (torch.rand(An - 4, generator=g) - 0.5) * 2e-4   # near ties around the max
     cls[0, 4:, 11] += 6.0; cls[0, 4:, 60] += 6.0
+    cls[0, An - 1, :] = -120.0; cls[0, An - 1, 33] = -110.0          # 1 + exp(-l) overflows: every sigmoid is 0 -> label 0
+    cls[0, An - 2, :] = -95.0; cls[0, An - 2, 20] = -85.0            # sigmoid(-85) = 1.2e-37 against zeros -> label 20
+    cls[0, An - 3, 50] = float("nan"); cls[0, An - 3, 70] = float("nan")   # torch.max: NaN wins, the first one
     anchors = torch.cat([torch.rand(An, 2, generator=g) * 500 + 50, torch.rand(An, 2, generator=g) * 40 + 10], 1)
     loc = torch.zeros(1, An, 4)
     score_ref, label_ref = cls[0].cuda().sigmoid().max(1)            # the same device sigmoid family torch would use
@@ -174,13 +177,15 @@ def test_greedy_prep_scores_and_labels_equal_the_max_over_sigmoids():
     label = ws[off:off + An * 4].view(torch.int32)
     cpu_ref_s, cpu_ref_l = cls[0].sigmoid().max(1)
     lab = label.cpu().long()
-    assert torch.allclose(score.cpu(), cpu_ref_s, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(score.cpu(), cpu_ref_s, rtol=1e-6, atol=1e-7, equal_nan=True)
     assert int(lab[0]) == 5 and int(lab[2]) == 0 and int(lab[3]) == 7 and int(lab[1]) in (3, 40)
+    assert int(lab[An - 1]) == 0 and int(lab[An - 2]) == 20 and int(lab[An - 3]) == 50
+    assert float(score[An - 1]) == 0.0 and bool(torch.isnan(score[An - 3])) and torch.equal(lab[-3:], cpu_ref_l[-3:])
     top2 = cls[0].topk(2, dim=1).values
     clear = (top2[:, 0] - top2[:, 1]) > 0.05                          # unambiguous rows: the label is the arg-max of the logits
-    clear[:4] = False
+    clear[:4] = False; clear[-3:] = False
     assert int(clear.sum()) == 0 or torch.equal(lab[clear], cls[0].argmax(1)[clear])
-    near = ~clear; near[:4] = False
+    near = ~clear; near[:4] = False; near[-3:] = False
     picked = cls[0].gather(1, lab[:, None])[:, 0]                       # near ties: the label is one of the contenders within the
     assert bool((torch.sigmoid(picked[near]) >= torch.sigmoid(top2[near, 0]) - 1.2e-7).all())   # ... whose sigmoid ties with the maximum
     assert label_ref.shape == lab.shape
