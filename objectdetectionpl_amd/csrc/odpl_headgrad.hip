@@ -111,6 +111,13 @@ __device__ __forceinline__ void cell_decode(const Head& P, int cell, int& n, int
     if (n >= P.N) n = -1;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence as well, i.e. `s_waitcnt vmcnt(0)`:
+// every X load and every dX store of the wave would have to retire before the barrier.  The two barriers of the stream kernel
+// only publish LDS data (the staged gradient tile, the dW partials), so the global loads and stores stay in flight across them.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+constexpr int kLaneRows = 8;            // rows of X in flight per lane (8 x 16 B)
+
 template <bool BF, int A>
 __global__ __launch_bounds__(kThreads) void headgrad_stream_kernel(const Multi M) {
     constexpr int E = Vec<BF>::N;
@@ -131,43 +138,51 @@ __global__ __launch_bounds__(kThreads) void headgrad_stream_kernel(const Multi M
     const int cv = P.cv;                                 // 16-byte vectors per row of X
     const int q = cs * tpr + lane_c;
     const bool col_ok = q < cv;
-    const bool want_w = P.gw != nullptr, want_x = P.gx != nullptr;
-    // the first four rows of X are requested BEFORE the gd tile is staged: every workgroup of the grid is resident from the
-    // start, so a load-free staging phase would be a chip-wide bubble
-    Vec<BF> xv[4];
-    const bool pre = col_ok && want_w && rl + 3 * rows_par < nrows;
-    if (pre) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) xv[u] = ldv<BF, true>(P.x, (size_t)(n0 + rl + u * rows_par) * cv + q);
-    }
+    const int qc = col_ok ? q : cv - 1;                  // loads are unconditional (clamped): a predicated load ends in register
+    const bool want_w = P.gw != nullptr, want_x = P.gx != nullptr;     // copies that the compiler must wait for on the spot
+    // Addresses: a uniform 64-bit tile base (scalar registers) + a 32-bit byte offset per lane (a tile is < 2^31 bytes).
+    const char* tx = reinterpret_cast<const char*>(P.x) + (size_t)n0 * cv * 16;
+    char* tg = reinterpret_cast<char*>(P.gx) + (size_t)n0 * cv * 16;
+    const unsigned rowb = (unsigned)cv * 16u;
+    // Issue order = retirement order.  (1) the tile's gradient values, (2) the A weight rows, (3) kLaneRows rows of X per lane.
+    // The staging of (1) into LDS then waits for (1) only, the dX arithmetic for (2) only; X is first needed by the dW sums.
+    const int ng = nrows * A;
+    const int i0 = tid < ng ? tid : ng - 1;
+    const float g0 = P.gd[gd_index(P, n0 + i0 / A, i0 % A)];
+    __builtin_amdgcn_sched_barrier(0);                   // keep the instruction scheduler from sinking this load below the X loads
     Vec<BF> wv[A], acc[A];
 #pragma unroll
     for (int a = 0; a < A; ++a) {
 #pragma unroll
-        for (int e = 0; e < E; ++e) { acc[a].v[e] = 0.f; wv[a].v[e] = 0.f; }
-        if (col_ok) wv[a] = ldf<BF>(P.w + (size_t)(a * P.no + P.dc) * P.Cin, q);
+        for (int e = 0; e < E; ++e) acc[a].v[e] = 0.f;
+        wv[a] = ldf<BF>(P.w + (size_t)(a * P.no + P.dc) * P.Cin, qc);
     }
-    for (int i = tid; i < nrows * A; i += kThreads) {
-        const int r = i / A, a = i - r * A;
-        s_g[i] = P.gd[gd_index(P, n0 + r, a)] * f;
-    }
-    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    Vec<BF> xv[kLaneRows];
+    auto load_rows = [&](int base) {
+#pragma unroll
+        for (int u = 0; u < kLaneRows; ++u) {
+            const int r = min(rl + (base + u) * rows_par, nrows - 1);
+            xv[u] = ldv<BF, true>(tx + ((unsigned)r * rowb + (unsigned)qc * 16u), 0);
+        }
+    };
+    load_rows(0);
+    if (tid < ng) s_g[tid] = g0 * f;
+    for (int i = tid + kThreads; i < ng; i += kThreads) s_g[i] = P.gd[gd_index(P, n0 + i / A, i % A)] * f;
+    lds_barrier();
     float* s_red = lds + P.rows_per_tile * A;
     if (cs == 0 && tid < A && P.part_b) {                // db partial of anchor `tid` over this row tile
         float s = 0.f;
         for (int r = 0; r < nrows; ++r) s += s_g[r * A + tid];
         P.part_b[(size_t)tile * A + tid] = s;
     }
-    if (col_ok) {
-        int r = rl;
-        for (; r + 3 * rows_par < nrows; r += 4 * rows_par) {        // four rows in flight
-            if (want_w && !(pre && r == rl)) {
+    const int lane_rows = (P.rows_per_tile + rows_par - 1) / rows_par;
+    for (int base = 0;;) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) xv[u] = ldv<BF, true>(P.x, (size_t)(n0 + r + u * rows_par) * cv + q);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float* g = s_g + (r + u * rows_par) * A;
+        for (int u = 0; u < kLaneRows; ++u) {
+            const int r = rl + (base + u) * rows_par;
+            if (r < nrows && col_ok) {
+                const float* g = s_g + r * A;
                 Vec<BF> o;
 #pragma unroll
                 for (int e = 0; e < E; ++e) o.v[e] = 0.f;
@@ -175,25 +190,14 @@ __global__ __launch_bounds__(kThreads) void headgrad_stream_kernel(const Multi M
                 for (int a = 0; a < A; ++a) {
                     const float ga = g[a];
 #pragma unroll
-                    for (int e = 0; e < E; ++e) { o.v[e] += ga * wv[a].v[e]; if (want_w) acc[a].v[e] += ga * xv[u].v[e]; }
+                    for (int e = 0; e < E; ++e) { o.v[e] = fmaf(ga, wv[a].v[e], o.v[e]); acc[a].v[e] = fmaf(ga, xv[u].v[e], acc[a].v[e]); }
                 }
-                if (want_x) stv<BF, true>(P.gx, (size_t)(n0 + r + u * rows_par) * cv + q, o);
+                if (want_x) stv<BF, false>(tg + ((unsigned)r * rowb + (unsigned)q * 16u), 0, o);   // plain stores: see the header
             }
         }
-        for (; r < nrows; r += rows_par) {
-            const float* g = s_g + r * A;
-            Vec<BF> x1, o;
-#pragma unroll
-            for (int e = 0; e < E; ++e) { o.v[e] = 0.f; x1.v[e] = 0.f; }
-            if (want_w) x1 = ldv<BF, true>(P.x, (size_t)(n0 + r) * cv + q);
-#pragma unroll
-            for (int a = 0; a < A; ++a) {
-                const float ga = g[a];
-#pragma unroll
-                for (int e = 0; e < E; ++e) { o.v[e] += ga * wv[a].v[e]; if (want_w) acc[a].v[e] += ga * x1.v[e]; }
-            }
-            if (want_x) stv<BF, true>(P.gx, (size_t)(n0 + r) * cv + q, o);
-        }
+        base += kLaneRows;
+        if (base >= lane_rows) break;
+        load_rows(base);
     }
     if (want_w) {
         // combine the row lanes (fixed order) and write the tile's dW partial
@@ -201,7 +205,7 @@ __global__ __launch_bounds__(kThreads) void headgrad_stream_kernel(const Multi M
         for (int a = 0; a < A; ++a)
 #pragma unroll
             for (int e = 0; e < E; ++e) s_red[((rl * A + a) * E + e) * tpr + lane_c] = acc[a].v[e];
-        __syncthreads();
+        lds_barrier();
         if (rl == 0 && col_ok) {
 #pragma unroll
             for (int a = 0; a < A; ++a) {
