@@ -15,9 +15,11 @@
 // X is the convolution's input in channels-last memory ([N = B*G2, Cin] row-major, fp32 or bf16); gd / gr / row_cell are
 // the `odpl_sparse_grad_t` of include/odpl_hip.h.  Both streams are HBM bound (X read once, dX written once): this is the
 // kernel the training step's loss-path roofline figure is quoted on.  All heads of a model go through ONE pair of launches.
-//   stream  : workgroup = 64 rows x 64 16-byte vectors (128 KB of traffic: >1000 workgroups at config 2, heaviest head
-//             first); lanes along Cin (coalesced 1-KiB wave accesses); gd of the tile staged in LDS; four rows in flight per
-//             thread; non-temporal dX stores; per-tile dW / db partials (no float atomics)
+//   stream  : workgroup = 32 rows x 64 16-byte vectors (64 KB of traffic: 2368 workgroups at config 2, heaviest head
+//             first); lanes along Cin (coalesced 1-KiB wave accesses); gd of the tile staged in LDS; eight rows of X in flight
+//             per lane; per-tile dW / db partials (no float atomics).  X is loaded non-temporally (dead after this kernel),
+//             dX is written with PLAIN stores: on this chip a non-temporal store stream beside a read stream costs a copy
+//             17 % (tools/probe_copy.hip: 6.08 vs 5.09 TB/s at this size), and the next backward convolution reads dX
 //   finish  : (a) 64 x 4-lane groups per workgroup reduce the partials of the dense channels in a fixed order;
 //             (b) one workgroup per other output channel: the matched rows of its anchor are compacted into LDS in row
 //             order, then summed four X rows at a time; (c) one workgroup per matched cell-row for the dX correction (rows
