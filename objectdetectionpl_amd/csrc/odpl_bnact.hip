@@ -31,22 +31,32 @@ namespace {
 // Mish through ONE exponential: with n = e^z,  tanh(softplus(z)) = n(n+2) / (n(n+2) + 2)  and  sigmoid(z) = n / (1+n).
 // (ATen evaluates tanh(log1p(exp(z))): three transcendentals, which makes the epilogue VALU-bound instead of
 // HBM-bound.)  No cancellation: every term is positive; for z > 20 the ratio is 1 to fp32 precision.
+// Divisions by the hardware reciprocal (v_rcp_f32, 1 ulp; both divisors are >= 1): HIP's `__fdividef` is an IEEE division
+// here -- ten instructions (div_scale x2, rcp, four fma, div_fmas, div_fixup) -- and the backward kernels carry two per element,
+// which is what kept them on the VALU issue limit instead of the HBM one.
+__device__ __forceinline__ float div_rcp(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 __device__ __forceinline__ float mish_t(float z, float& n) {
     n = __expf(fminf(z, 20.0f));
     const float p = n * (n + 2.0f);
-    return __fdividef(p, p + 2.0f);
+    return div_rcp(p, p + 2.0f);
 }
-__device__ __forceinline__ float act_fwd(float z, int act) {
+// ACT is a template parameter of the streaming kernels: a run-time switch costs a scalar compare-and-branch per ELEMENT and cuts the
+// loop body into basic blocks the scheduler cannot interleave.
+template <int ACT>
+__device__ __forceinline__ float act_fwd(float z) {
+    constexpr int act = ACT;
     if (act == ODPL_ACT_MISH) { float n; return z * mish_t(z, n); }            // x * tanh(softplus(x))
     if (act == ODPL_ACT_LEAKY) return z > 0.f ? z : 0.1f * z;
     if (act == ODPL_ACT_RELU) return z > 0.f ? z : 0.f;
     return z;
 }
-__device__ __forceinline__ float act_grad(float z, int act) {
+template <int ACT>
+__device__ __forceinline__ float act_grad(float z) {
+    constexpr int act = ACT;
     if (act == ODPL_ACT_MISH) {                                                 // ts + z * sigmoid(z) * (1 - ts^2)  (ATen mish_backward)
         float n;
         const float ts = mish_t(z, n);
-        const float sg = z > 20.0f ? 1.0f : __fdividef(n, 1.0f + n);
+        const float sg = z > 20.0f ? 1.0f : div_rcp(n, 1.0f + n);
         return ts + z * sg * (1.0f - ts * ts);
     }
     if (act == ODPL_ACT_LEAKY) return z > 0.f ? 1.0f : 0.1f;
@@ -68,9 +78,23 @@ struct BnParams {
     float eps, momentum;
 };
 
-// one pass over a row tile: per-channel sums of (a, b) where (a, b) = f(row, channel-quad)
-template <bool BWD, bool BF>
+// 16 bytes (fp32) / 8 bytes (bf16) of a channels-last row at a byte offset from a workgroup-uniform base: the compiler keeps
+// the base in scalar registers and the offset in ONE vector register (global_load ... v_off, s[base:base+1])
+template <bool BF>
+__device__ __forceinline__ float4 ld_quad_at(const char* base, unsigned byte_off) {
+    if (!BF) return *reinterpret_cast<const float4*>(base + byte_off);
+    const uint2 u = *reinterpret_cast<const uint2*>(base + byte_off);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+
+// one pass over a row tile: per-channel sums of (a, b) where (a, b) = f(row, channel-quad).
+// K rows per lane are requested before any is consumed (forward: 8 x 16 B, backward: 4 x (x, gy)); the loads are unconditional
+// -- rows past the end of the tile are clamped to its last row and ignored by the arithmetic -- so a ragged tile costs no extra
+// trip to memory (a tile of 43 rows over 4 row lanes used to take 2 trips of four rows and 3 of one).
+template <bool BWD, bool BF, int ACT>
 __global__ __launch_bounds__(kT) void bn_reduce_kernel(const BnParams P) {
+    constexpr int K = BWD ? 4 : 8;
+    constexpr unsigned QB = BF ? 8u : 16u;
     extern __shared__ double s_red[];                       // [rows_par][C][2] staged for the cross-row combine
     const int C = P.C, c4n = C >> 2;                        // channel quads
     const int tpr = c4n < kT ? c4n : kT;                    // threads per row
@@ -78,42 +102,44 @@ __global__ __launch_bounds__(kT) void bn_reduce_kernel(const BnParams P) {
     const int tr = threadIdx.x / tpr, tc = threadIdx.x - tr * tpr;
     const long long r0 = (long long)blockIdx.x * P.rows_per_blk;
     long long r1 = r0 + P.rows_per_blk; if (r1 > P.R) r1 = P.R;
+    const int nrows = (int)(r1 - r0);                       // >= 1
+    const int lane_rows = (nrows + rows_par - 1) / rows_par;
+    const char* bx = reinterpret_cast<const char*>(P.x) + (size_t)r0 * c4n * QB;
+    const char* bg = BWD ? reinterpret_cast<const char*>(P.gy) + (size_t)r0 * (size_t)P.gy_rs4 * QB : nullptr;
+    const unsigned xs = (unsigned)c4n * QB, gs = (unsigned)P.gy_rs4 * QB;      // row strides in bytes (a tile spans < 2^31 bytes: plan())
     for (int q0 = 0; q0 < c4n; q0 += tpr) {                 // C > 1024: several channel passes
         const int q = q0 + tc;
+        const bool mine = q < c4n && tr < rows_par;
+        const int qc = q < c4n ? q : c4n - 1, trc = tr < rows_par ? tr : 0;
         double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
-        if (q < c4n && tr < rows_par) {
-            float4 mu, is, ga, be;
-            if (BWD) {
-                mu = reinterpret_cast<const float4*>(P.mean)[q]; is = reinterpret_cast<const float4*>(P.invstd)[q];
-                ga = reinterpret_cast<const float4*>(P.gamma)[q]; be = reinterpret_cast<const float4*>(P.beta)[q];
+        float4 mu, is, ga, be;
+        if (BWD) {
+            mu = reinterpret_cast<const float4*>(P.mean)[qc]; is = reinterpret_cast<const float4*>(P.invstd)[qc];
+            ga = reinterpret_cast<const float4*>(P.gamma)[qc]; be = reinterpret_cast<const float4*>(P.beta)[qc];
+        }
+        auto body = [&](const float4& v, const float4& g) {
+            if (!BWD) {
+                a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w;
+                b[0] = fma((double)v.x, (double)v.x, b[0]); b[1] = fma((double)v.y, (double)v.y, b[1]); b[2] = fma((double)v.z, (double)v.z, b[2]); b[3] = fma((double)v.w, (double)v.w, b[3]);
+            } else {
+                const float xh0 = (v.x - mu.x) * is.x, xh1 = (v.y - mu.y) * is.y, xh2 = (v.z - mu.z) * is.z, xh3 = (v.w - mu.w) * is.w;
+                const float g0 = g.x * act_grad<ACT>(ga.x * xh0 + be.x), g1 = g.y * act_grad<ACT>(ga.y * xh1 + be.y);
+                const float g2 = g.z * act_grad<ACT>(ga.z * xh2 + be.z), g3 = g.w * act_grad<ACT>(ga.w * xh3 + be.w);
+                a[0] += g0; a[1] += g1; a[2] += g2; a[3] += g3;
+                b[0] = fma((double)g0, (double)xh0, b[0]); b[1] = fma((double)g1, (double)xh1, b[1]); b[2] = fma((double)g2, (double)xh2, b[2]); b[3] = fma((double)g3, (double)xh3, b[3]);
             }
-            // 4 rows per iteration: all loads are issued before the arithmetic (8 x 16 B in flight per lane in backward)
-            auto body = [&](const float4& v, const float4& g) {
-                if (!BWD) {
-                    a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w;
-                    b[0] += (double)v.x * v.x; b[1] += (double)v.y * v.y; b[2] += (double)v.z * v.z; b[3] += (double)v.w * v.w;
-                } else {
-                    const float xh0 = (v.x - mu.x) * is.x, xh1 = (v.y - mu.y) * is.y, xh2 = (v.z - mu.z) * is.z, xh3 = (v.w - mu.w) * is.w;
-                    const float g0 = g.x * act_grad(ga.x * xh0 + be.x, P.act), g1 = g.y * act_grad(ga.y * xh1 + be.y, P.act);
-                    const float g2 = g.z * act_grad(ga.z * xh2 + be.z, P.act), g3 = g.w * act_grad(ga.w * xh3 + be.w, P.act);
-                    a[0] += g0; a[1] += g1; a[2] += g2; a[3] += g3;
-                    b[0] += (double)g0 * xh0; b[1] += (double)g1 * xh1; b[2] += (double)g2 * xh2; b[3] += (double)g3 * xh3;
-                }
-            };
-            long long r = r0 + tr;
-            for (; r + 3LL * rows_par < r1; r += 4LL * rows_par) {
-                float4 v[4], g[4];
+        };
+        for (int k0 = 0; k0 < lane_rows; k0 += K) {         // rows trc + k * rows_par, k ascending: the same order as ever
+            float4 v[K], g[K];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { v[u] = ld_quad<BF>(P.x, (r + (long long)u * rows_par) * c4n + q); if (BWD) g[u] = ld_quad<BF>(P.gy, (r + (long long)u * rows_par) * P.gy_rs4 + q); }
+            for (int u = 0; u < K; ++u) {
+                int r = trc + (k0 + u) * rows_par; if (r > nrows - 1) r = nrows - 1;
+                v[u] = ld_quad_at<BF>(bx, (unsigned)r * xs + (unsigned)qc * QB);
+                if (BWD) g[u] = ld_quad_at<BF>(bg, (unsigned)r * gs + (unsigned)qc * QB); else g[u] = v[u];
+            }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) body(v[u], g[u]);
-            }
-            for (; r < r1; r += rows_par) {
-                const float4 v = ld_quad<BF>(P.x, r * c4n + q);
-                float4 g = v;
-                if (BWD) g = ld_quad<BF>(P.gy, r * P.gy_rs4 + q);
-                body(v, g);
-            }
+            for (int u = 0; u < K; ++u)
+                if (mine && trc + (k0 + u) * rows_par < nrows) body(v[u], g[u]);
         }
         // combine the rows_par row-lanes through LDS (fixed order), write the workgroup partial
         __syncthreads();
@@ -172,7 +198,7 @@ __global__ __launch_bounds__(kT) void bn_bwd_finalize_kernel(const BnParams P) {
     P.dgamma[c] = (float)ss;
 }
 
-template <bool BF>
+template <bool BF, int ACT>
 __global__ __launch_bounds__(kT) void bn_apply_kernel(const BnParams P) {
     const int c4n = P.C >> 2;
     const long long n4 = P.R * c4n, stride = (long long)gridDim.x * kT;
@@ -192,8 +218,8 @@ __global__ __launch_bounds__(kT) void bn_apply_kernel(const BnParams P) {
         }
         const float4 ga = reinterpret_cast<const float4*>(P.gamma)[q], be = reinterpret_cast<const float4*>(P.beta)[q];
         float4 o;
-        o.x = act_fwd(ga.x * ((v.x - mu.x) * is.x) + be.x, P.act); o.y = act_fwd(ga.y * ((v.y - mu.y) * is.y) + be.y, P.act);
-        o.z = act_fwd(ga.z * ((v.z - mu.z) * is.z) + be.z, P.act); o.w = act_fwd(ga.w * ((v.w - mu.w) * is.w) + be.w, P.act);
+        o.x = act_fwd<ACT>(ga.x * ((v.x - mu.x) * is.x) + be.x); o.y = act_fwd<ACT>(ga.y * ((v.y - mu.y) * is.y) + be.y);
+        o.z = act_fwd<ACT>(ga.z * ((v.z - mu.z) * is.z) + be.z); o.w = act_fwd<ACT>(ga.w * ((v.w - mu.w) * is.w) + be.w);
         if (P.res) { const float4 t = ld_quad<BF>(P.res, i); o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
         st_quad<BF>(P.y, r * P.y_rs4 + q, o);
         q += sq; r += sr;
@@ -201,7 +227,7 @@ __global__ __launch_bounds__(kT) void bn_apply_kernel(const BnParams P) {
     }
 }
 
-template <bool BF>
+template <bool BF, int ACT>
 __global__ __launch_bounds__(kT) void bn_bwd_dx_kernel(const BnParams P) {
     const int c4n = P.C >> 2;
     const long long n4 = P.R * c4n, stride = (long long)gridDim.x * kT;
@@ -217,7 +243,7 @@ __global__ __launch_bounds__(kT) void bn_bwd_dx_kernel(const BnParams P) {
         const float4 ga = reinterpret_cast<const float4*>(P.gamma)[q], be = reinterpret_cast<const float4*>(P.beta)[q];
         const float4 db = reinterpret_cast<const float4*>(P.dbeta)[q], dg = reinterpret_cast<const float4*>(P.dgamma)[q];
         float4 o;
-#define ODPL_DX(f) { const float xh = (v.f - mu.f) * is.f; const float gz = g.f * act_grad(ga.f * xh + be.f, P.act); \
+#define ODPL_DX(f) { const float xh = (v.f - mu.f) * is.f; const float gz = g.f * act_grad<ACT>(ga.f * xh + be.f); \
                      o.f = ga.f * is.f * (gz - db.f * invR - xh * dg.f * invR); }
         ODPL_DX(x) ODPL_DX(y) ODPL_DX(z) ODPL_DX(w)
 #undef ODPL_DX
@@ -260,10 +286,22 @@ __global__ __launch_bounds__(kT) void bias_grad_nchw_kernel(const void* __restri
     }
 }
 
+
+// launch `KERNEL<..., ACT>` for the run-time activation code (0..3, validated by the callers)
+#define ODPL_BN_LAUNCH(KERNEL, PRE, grid, lds, stream, P)                                                              \
+    switch ((P).act) {                                                                                                \
+        case 0: hipLaunchKernelGGL((KERNEL<PRE, 0>), grid, dim3(kT), lds, stream, P); break;                          \
+        case 1: hipLaunchKernelGGL((KERNEL<PRE, 1>), grid, dim3(kT), lds, stream, P); break;                          \
+        case 2: hipLaunchKernelGGL((KERNEL<PRE, 2>), grid, dim3(kT), lds, stream, P); break;                          \
+        default: hipLaunchKernelGGL((KERNEL<PRE, 3>), grid, dim3(kT), lds, stream, P); break;                         \
+    }
+#define ODPL_COMMA ,
+
 bool plan(long long R, int C, int* rows_per_blk, int* nblk, size_t* lds) {
     if (R < 1 || C < 4 || (C & 3)) return false;
     // ~1024 row tiles; at most 2048 rows each so that the one-workgroup-per-channel finalize stays short on the widest maps
     long long rpb = R / odpl::g_bn_target_blocks; if (rpb < 16) rpb = 16; if (rpb > odpl::g_bn_max_rows_per_tile) rpb = odpl::g_bn_max_rows_per_tile;
+    while (rpb > 16 && rpb * (long long)C * 4 * 2 >= (1LL << 31)) rpb >>= 1;   // 32-bit byte offsets inside a tile (row strides up to 2C: concat slices)
     *rows_per_blk = (int)rpb;
     *nblk = (int)((R + rpb - 1) / rpb);
     const int c4n = C >> 2, tpr = c4n < kT ? c4n : kT, rows_par = kT / tpr;
@@ -317,8 +355,8 @@ extern "C" int odpl_bn_act_forward_strided(const void* x, const void* residual, 
     P.num_batches_tracked = (long long*)num_batches_tracked;
     if (training) {
         if (!workspace || workspace_bytes < odpl_bn_act_workspace_bytes(R, C) || ((uintptr_t)workspace & 15)) return ODPL_EINVAL;
-        if (bf16) hipLaunchKernelGGL((bn_reduce_kernel<false, true>), dim3(nblk), dim3(kT), lds, stream, P);
-        else hipLaunchKernelGGL((bn_reduce_kernel<false, false>), dim3(nblk), dim3(kT), lds, stream, P);
+        if (bf16) hipLaunchKernelGGL((bn_reduce_kernel<false, true, 0>), dim3(nblk), dim3(kT), lds, stream, P);      // statistics: no activation involved
+        else hipLaunchKernelGGL((bn_reduce_kernel<false, false, 0>), dim3(nblk), dim3(kT), lds, stream, P);
         ODPL_HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), dim3(kT), 0, stream, P);
         ODPL_HIP_TRY(hipGetLastError());
@@ -326,8 +364,8 @@ extern "C" int odpl_bn_act_forward_strided(const void* x, const void* residual, 
     const long long n4 = R * (C >> 2);
     long long blocks = (n4 + kT - 1) / kT;
     { const long long cap = odpl::g_bn_stream_max_blocks > 0 ? odpl::g_bn_stream_max_blocks : (n4 >= (8LL << 20) ? 16384 : 4096); if (blocks > cap) blocks = cap; }
-    if (bf16) hipLaunchKernelGGL(bn_apply_kernel<true>, dim3((unsigned)blocks), dim3(kT), 0, stream, P);
-    else hipLaunchKernelGGL(bn_apply_kernel<false>, dim3((unsigned)blocks), dim3(kT), 0, stream, P);
+    if (bf16) { ODPL_BN_LAUNCH(bn_apply_kernel, true, dim3((unsigned)blocks), 0, stream, P) }
+    else { ODPL_BN_LAUNCH(bn_apply_kernel, false, dim3((unsigned)blocks), 0, stream, P) }
     ODPL_HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -357,16 +395,16 @@ extern "C" int odpl_bn_act_backward_strided(const void* x, const void* grad_y, i
     P.R = R; P.C = C; P.act = act; P.nblk = nblk; P.rows_per_blk = rpb; P.training = training; P.part = (double*)workspace;
     P.y_rs4 = C >> 2; P.gy_rs4 = gy_row_stride >> 2;
     P.dgamma = grad_gamma; P.dbeta = grad_beta;
-    if (bf16) hipLaunchKernelGGL((bn_reduce_kernel<true, true>), dim3(nblk), dim3(kT), lds, stream, P);
-    else hipLaunchKernelGGL((bn_reduce_kernel<true, false>), dim3(nblk), dim3(kT), lds, stream, P);
+    if (bf16) { ODPL_BN_LAUNCH(bn_reduce_kernel, true ODPL_COMMA true, dim3(nblk), lds, stream, P) }
+    else { ODPL_BN_LAUNCH(bn_reduce_kernel, true ODPL_COMMA false, dim3(nblk), lds, stream, P) }
     ODPL_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(kT), 0, stream, P);
     ODPL_HIP_TRY(hipGetLastError());
     const long long n4 = R * (C >> 2);
     long long blocks = (n4 + kT - 1) / kT;
     { const long long cap = odpl::g_bn_stream_max_blocks > 0 ? odpl::g_bn_stream_max_blocks : (n4 >= (8LL << 20) ? 16384 : 4096); if (blocks > cap) blocks = cap; }
-    if (bf16) hipLaunchKernelGGL(bn_bwd_dx_kernel<true>, dim3((unsigned)blocks), dim3(kT), 0, stream, P);
-    else hipLaunchKernelGGL(bn_bwd_dx_kernel<false>, dim3((unsigned)blocks), dim3(kT), 0, stream, P);
+    if (bf16) { ODPL_BN_LAUNCH(bn_bwd_dx_kernel, true, dim3((unsigned)blocks), 0, stream, P) }
+    else { ODPL_BN_LAUNCH(bn_bwd_dx_kernel, false, dim3((unsigned)blocks), 0, stream, P) }
     ODPL_HIP_TRY(hipGetLastError());
     return 0;
 }
