@@ -455,7 +455,10 @@ bool plan_one(const odpl_head_conv_t* h, const odpl_sparse_grad_t* g, int rows_p
     int tpr = 1; while (tpr < p->cv && tpr < 64) tpr <<= 1;
     p->tpr = tpr; p->rows_par = kThreads / tpr;
     p->ncs = (p->cv + tpr - 1) / tpr;
-    p->rows_per_tile = rows_per_tile;
+    // `rows_per_tile` is quoted for 4 row lanes (>= 64 vectors per row); narrower rows have more row lanes per workgroup and get
+    // proportionally taller tiles, so that every lane owns the same number of rows (8 at the default: one full set of loads)
+    p->rows_per_tile = rows_per_tile * p->rows_par / 4;
+    if (p->rows_per_tile < p->rows_par) p->rows_per_tile = p->rows_par;
     p->ntiles = (int)((N + p->rows_per_tile - 1) / p->rows_per_tile);
     p->part_w = 0;
     p->part_b = align_up((size_t)p->ntiles * g->A * h->Cin * sizeof(float), 256);
@@ -474,7 +477,8 @@ int pick_rows(int n, const odpl_head_conv_t* heads, const odpl_sparse_grad_t* gr
             const int E = heads[i].bf16 ? 8 : 4, cv = heads[i].Cin / E;
             int tpr = 1; while (tpr < cv && tpr < 64) tpr <<= 1;
             const long long N = (long long)grads[i].B * grads[i].G2;
-            blocks += ((N + r - 1) / r) * ((cv + tpr - 1) / tpr);
+            const long long rh = (long long)r * (kThreads / tpr) / 4;
+            blocks += ((N + rh - 1) / rh) * ((cv + tpr - 1) / tpr);
         }
         if (blocks <= 2048) return r;
     }
