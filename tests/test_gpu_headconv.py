@@ -149,10 +149,12 @@ def _dense_from_sparse(gd, gr, cells, B, G2, A, no, dc, layout):
 
 
 @pytest.mark.parametrize("layout", [0, 1])
-@pytest.mark.parametrize("A,no,Cin,G,nrows", [(3, 9, 64, 13, 7), (5, 25, 1024, 9, 12), (3, 85, 2048, 4, 0), (1, 6, 40, 5, 3)])
+@pytest.mark.parametrize("A,no,Cin,G,nrows", [(3, 9, 64, 13, 7), (5, 25, 1024, 9, 12), (3, 85, 2048, 4, 0), (1, 6, 40, 5, 3),
+                                              (3, 85, 320, 7, 5), (2, 10, 96, 19, 4), (4, 7, 8, 23, 6)])
 def test_c_abi_head_conv_backward_vs_dense_math(layout, A, no, Cin, G, nrows):
     """odpl_head_conv_backward on a synthetic odpl_sparse_grad_t (both cell orders, A = 1..5, Cin beyond one column pass,
-    no rows at all, rows that share a cell-row) against float64 dense math."""
+    a half-empty second column slice (Cin = 320), many row lanes with ragged last tiles (Cin = 96, 8), no rows at all, rows
+    that share a cell-row) against float64 dense math."""
     from objectdetectionpl_amd import _lib
     g = torch.Generator().manual_seed(A * 100 + no)
     B, G2, dc = 2, G * G, 4
@@ -192,6 +194,45 @@ def test_c_abi_head_conv_backward_vs_dense_math(layout, A, no, Cin, G, nrows):
     _lib.check(L.odpl_head_conv_backward(ctypes.byref(h), ctypes.byref(sg), _lib.ptr(ws), nb, _lib.current_stream(torch.device(DEV))), "head")
     torch.cuda.synchronize()
     _close(gx, ref_gx, 1e-4, 1e-5)
+    _close(gw, ref_gw, 1e-4, 1e-5)
+    _close(gb, ref_gb, 1e-4, 1e-5)
+
+
+@pytest.mark.parametrize("Cin,G", [(256, 20), (64, 9), (1024, 5)])
+def test_c_abi_head_conv_backward_bf16_activations(Cin, G):
+    """bf16 X and dX (autocast's Detect convolutions), fp32 weights: against float64 math on the bf16-rounded inputs; dX within bf16
+    rounding, dW / db (fp32 outputs) tight.  Cin = 256 / 64: eight / thirty-two row lanes per workgroup."""
+    from objectdetectionpl_amd import _lib
+    g = torch.Generator().manual_seed(Cin + G)
+    A, no, dc, B, layout = 3, 85, 4, 3, 0
+    G2 = G * G
+    N = B * G2
+    x = torch.randn(N, Cin, generator=g).bfloat16()
+    w = torch.randn(A * no, Cin, generator=g) * 0.1
+    gd = torch.randn(B * A * G2, generator=g)
+    nrows = 9
+    gr = torch.randn(nrows, no, generator=g)
+    cells = torch.randint(0, B * A * G2, (nrows,), generator=g, dtype=torch.int32)
+    cells[0] = (0 * A + 0) * G2 + 2; cells[1] = (0 * A + 2) * G2 + 2          # two anchors of one cell-row
+    dense = _dense_from_sparse(gd, gr, cells, B, G2, A, no, dc, layout)
+    xd = x.double().view(B, G2, Cin)
+    ref_gx = torch.einsum("bos,oc->bsc", dense, w.double()).reshape(N, Cin)
+    ref_gw = torch.einsum("bos,bsc->oc", dense, xd)
+    ref_gb = dense.sum((0, 2))
+    L = _lib.lib()
+    t = {k: v.to(DEV) for k, v in dict(x=x, w=w, gd=gd, gr=gr, cells=cells).items()}
+    gx, gw, gb = torch.empty_like(t["x"]), torch.empty_like(t["w"]), torch.empty(A * no, device=DEV)
+    sg = _lib.SparseGrad(dense=t["gd"].data_ptr(), rows=t["gr"].data_ptr(), row_cell=t["cells"].data_ptr(), n_rows=nrows,
+                         B=B, G2=G2, A=A, no=no, dense_ch=dc, layout=layout)
+    h = _lib.HeadConv(x=t["x"].data_ptr(), w=t["w"].data_ptr(), grad_x=gx.data_ptr(), grad_w=gw.data_ptr(), grad_b=gb.data_ptr(),
+                      upstream=None, Cin=Cin, bf16=1)
+    nb = L.odpl_head_conv_backward_workspace_bytes(ctypes.byref(h), ctypes.byref(sg))
+    assert nb > 0
+    ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    _lib.check(L.odpl_head_conv_backward(ctypes.byref(h), ctypes.byref(sg), _lib.ptr(ws), nb, _lib.current_stream(torch.device(DEV))), "head")
+    torch.cuda.synchronize()
+    assert gx.dtype == torch.bfloat16
+    _close(gx.float(), ref_gx, 1e-2, 1e-2)       # one bf16 rounding of the result
     _close(gw, ref_gw, 1e-4, 1e-5)
     _close(gb, ref_gb, 1e-4, 1e-5)
 
