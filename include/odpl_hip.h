@@ -513,6 +513,7 @@ int odpl_bn_act_backward_strided(const void* x, const void* grad_y, int64_t gy_r
 #define ODPL_TUNE_BN_TARGET_BLOCKS 3      /* row tiles of the BN reduce passes (default 1024) */
 #define ODPL_TUNE_BN_STREAM_MAX_BLOCKS 4  /* grid cap of the BN apply / dx streams (0 = by size: 4096 / 16384) */
 #define ODPL_TUNE_BN_MAX_ROWS_PER_TILE 5  /* rows per reduce tile at most (default 2048) */
+#define ODPL_TUNE_BN_SLICE_FROM_C 6       /* BN reduce passes cut rows into 16-quad channel slices from this C on (default 256) */
 int odpl_tune_set(int32_t key, int32_t value);
 
 /* diagnostic: when non-NULL, every workgroup w of yolo_expand_kernel stores its start / end reading of the

@@ -223,7 +223,7 @@ YOLO_STATE_CLEAN = 1
 RETINA_STATE_CLEAN = 1
 YOLOV5_STATE_CLEAN = 1
 IOU_MODES = {"iou": 0, "giou": 1, "diou": 2, "ciou": 3}
-TUNE_KEYS = {"yolo_fill_f4_per_block": 0, "yolo_fill_nt": 1, "retina_fill_nt": 2, "bn_target_blocks": 3, "bn_stream_max_blocks": 4, "bn_max_rows_per_tile": 5}
+TUNE_KEYS = {"yolo_fill_f4_per_block": 0, "yolo_fill_nt": 1, "retina_fill_nt": 2, "bn_target_blocks": 3, "bn_stream_max_blocks": 4, "bn_max_rows_per_tile": 5, "bn_slice_from_c": 6}
 
 
 def tune_set(name, value):

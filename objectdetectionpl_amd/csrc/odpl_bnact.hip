@@ -25,6 +25,7 @@ namespace odpl {
 int g_bn_target_blocks = 1024;          // row tiles of the two reduce passes (odpl_tune_set)
 int g_bn_stream_max_blocks = 0;         // grid cap of the apply / dx streams; 0 = by size (4096, or 16384 from 8 M quads on)
 int g_bn_max_rows_per_tile = 2048;
+int g_bn_slice_from_c = 256;            // reduce passes cut the row into 16-quad channel slices from this many channels on
 }
 namespace {
 
@@ -74,6 +75,7 @@ struct BnParams {
     float* dgamma; float* dbeta;                 // [C]
     long long* num_batches_tracked;              // nn.BatchNorm2d buffer, +1 per training forward (or null)
     long long R; int C, act, nblk, rows_per_blk, training;
+    int slice_q;                                 // channel quads per workgroup of the reduce passes (grid.y slices of the row), or C/4
     long long y_rs4, gy_rs4;                     // row strides of y / grad_y in float4 units (== C/4 when dense)
     float eps, momentum;
 };
@@ -97,7 +99,10 @@ __global__ __launch_bounds__(kT) void bn_reduce_kernel(const BnParams P) {
     constexpr unsigned QB = BF ? 8u : 16u;
     extern __shared__ double s_red[];                       // [rows_par][C][2] staged for the cross-row combine
     const int C = P.C, c4n = C >> 2;                        // channel quads
-    const int tpr = c4n < kT ? c4n : kT;                    // threads per row
+    const int sq0 = blockIdx.y * P.slice_q;                 // this workgroup's channel slice [sq0, sq1) (the whole row when grid.y == 1)
+    const int sq1 = sq0 + P.slice_q < c4n ? sq0 + P.slice_q : c4n;
+    const int sqn = sq1 - sq0;
+    const int tpr = sqn < kT ? sqn : kT;                    // threads per row
     const int rows_par = kT / tpr;                          // rows handled in parallel by the workgroup
     const int tr = threadIdx.x / tpr, tc = threadIdx.x - tr * tpr;
     const long long r0 = (long long)blockIdx.x * P.rows_per_blk;
@@ -107,10 +112,10 @@ __global__ __launch_bounds__(kT) void bn_reduce_kernel(const BnParams P) {
     const char* bx = reinterpret_cast<const char*>(P.x) + (size_t)r0 * c4n * QB;
     const char* bg = BWD ? reinterpret_cast<const char*>(P.gy) + (size_t)r0 * (size_t)P.gy_rs4 * QB : nullptr;
     const unsigned xs = (unsigned)c4n * QB, gs = (unsigned)P.gy_rs4 * QB;      // row strides in bytes (a tile spans < 2^31 bytes: plan())
-    for (int q0 = 0; q0 < c4n; q0 += tpr) {                 // C > 1024: several channel passes
+    for (int q0 = sq0; q0 < sq1; q0 += tpr) {               // slices wider than the workgroup (C > 1024 unsliced): several channel passes
         const int q = q0 + tc;
-        const bool mine = q < c4n && tr < rows_par;
-        const int qc = q < c4n ? q : c4n - 1, trc = tr < rows_par ? tr : 0;
+        const bool mine = q < sq1 && tr < rows_par;
+        const int qc = q < sq1 ? q : sq1 - 1, trc = tr < rows_par ? tr : 0;
         double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
         float4 mu, is, ga, be;
         if (BWD) {
@@ -143,12 +148,12 @@ __global__ __launch_bounds__(kT) void bn_reduce_kernel(const BnParams P) {
         }
         // combine the rows_par row-lanes through LDS (fixed order), write the workgroup partial
         __syncthreads();
-        if (q < c4n && tr < rows_par) {
+        if (mine) {
             double* d = s_red + ((size_t)tr * tpr + tc) * 8;
             for (int i = 0; i < 4; ++i) { d[i] = a[i]; d[4 + i] = b[i]; }
         }
         __syncthreads();
-        if (tr == 0 && q < c4n) {
+        if (tr == 0 && q < sq1) {
             double sa[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
             for (int t = 0; t < rows_par; ++t) {
                 const double* d = s_red + ((size_t)t * tpr + tc) * 8;
@@ -297,23 +302,35 @@ __global__ __launch_bounds__(kT) void bias_grad_nchw_kernel(const void* __restri
     }
 #define ODPL_COMMA ,
 
-bool plan(long long R, int C, int* rows_per_blk, int* nblk, size_t* lds) {
+// Geometry of the two reduce passes.  Maps of >= kSliceFromC channels (the <= 44 MB maps of the BASELINE networks) are cut along
+// the channels too: a workgroup owns 16 quads (256 B of an fp32 row) of a row tile, so ~1024 workgroups need only 1024 / slices
+// row tiles -- and the partial array [nblk][C][2] that the finalize launch re-reads shrinks with it (22 MB map, C = 512: 676 -> 128
+// partial rows, 5.5 -> 1.0 MB; finalize 9.7 -> 5 us).
+struct RPlan { int rows_per_blk, nblk, slice_q, nslices; size_t lds; };
+bool plan(long long R, int C, RPlan* p) {
     if (R < 1 || C < 4 || (C & 3)) return false;
-    // ~1024 row tiles; at most 2048 rows each so that the one-workgroup-per-channel finalize stays short on the widest maps
-    long long rpb = R / odpl::g_bn_target_blocks; if (rpb < 16) rpb = 16; if (rpb > odpl::g_bn_max_rows_per_tile) rpb = odpl::g_bn_max_rows_per_tile;
+    const int c4n = C >> 2;
+    p->slice_q = c4n; p->nslices = 1;
+    if (C >= odpl::g_bn_slice_from_c && c4n % 16 == 0) { p->slice_q = 16; p->nslices = c4n / 16; }
+    // ~target_blocks workgroups; at most 2048 rows each so that the one-workgroup-per-channel finalize stays short on the widest maps
+    long long tiles = odpl::g_bn_target_blocks / p->nslices; if (tiles < 32) tiles = 32;
+    const int tpr0 = p->slice_q < kT ? p->slice_q : kT, lane_full = 8 * (kT / tpr0);      // rows of a tile that give every lane its 8 rows in flight
+    long long rpb = R / tiles; if (rpb < 16) rpb = 16;
+    if (rpb < lane_full) rpb = lane_full;                   // small maps: fewer, full tiles rather than many with mostly clamped (wasted) loads
+    if (rpb > odpl::g_bn_max_rows_per_tile) rpb = odpl::g_bn_max_rows_per_tile;
     while (rpb > 16 && rpb * (long long)C * 4 * 2 >= (1LL << 31)) rpb >>= 1;   // 32-bit byte offsets inside a tile (row strides up to 2C: concat slices)
-    *rows_per_blk = (int)rpb;
-    *nblk = (int)((R + rpb - 1) / rpb);
-    const int c4n = C >> 2, tpr = c4n < kT ? c4n : kT, rows_par = kT / tpr;
-    *lds = (size_t)rows_par * tpr * 8 * sizeof(double);
+    p->rows_per_blk = (int)rpb;
+    p->nblk = (int)((R + rpb - 1) / rpb);
+    const int tpr = p->slice_q < kT ? p->slice_q : kT, rows_par = kT / tpr;
+    p->lds = (size_t)rows_par * tpr * 8 * sizeof(double);
     return true;
 }
 }  // namespace
 
 extern "C" size_t odpl_bn_act_workspace_bytes(int64_t R, int32_t C) {
-    int rpb, nblk; size_t lds;
-    if (!plan(R, C, &rpb, &nblk, &lds)) return 0;
-    return (size_t)nblk * C * 2 * sizeof(double) + 256;
+    RPlan pl;
+    if (!plan(R, C, &pl)) return 0;
+    return (size_t)pl.nblk * C * 2 * sizeof(double) + 256;
 }
 
 extern "C" int odpl_bn_act_forward(const float* x, int64_t R, int32_t C, const float* gamma, const float* beta,
@@ -338,8 +355,9 @@ extern "C" int odpl_bn_act_forward_strided(const void* x, const void* residual, 
                                            void* workspace, size_t workspace_bytes, int64_t* num_batches_tracked, void* stream_) {
     if (y_row_stride < C || (y_row_stride & 3)) return ODPL_EINVAL;
     if (residual && y_row_stride != C) return ODPL_EINVAL;
-    int rpb, nblk; size_t lds;
-    if (!x || !y || !gamma || !beta || !plan(R, C, &rpb, &nblk, &lds)) return ODPL_EINVAL;
+    RPlan pl;
+    if (!x || !y || !gamma || !beta || !plan(R, C, &pl)) return ODPL_EINVAL;
+    const int rpb = pl.rows_per_blk, nblk = pl.nblk; const size_t lds = pl.lds;
     // save_mean / save_invstd may both be NULL in inference (training == 0): the apply pass then reads running_mean / running_var
     if ((!save_mean || !save_invstd) && (training || save_mean || save_invstd || !running_mean || !running_var)) return ODPL_EINVAL;
     if (((uintptr_t)running_mean | (uintptr_t)running_var) & 15) return ODPL_EINVAL;
@@ -350,13 +368,13 @@ extern "C" int odpl_bn_act_forward_strided(const void* x, const void* residual, 
     BnParams P = {};
     P.x = x; P.y = y; P.res = residual; P.gamma = gamma; P.beta = beta; P.mean = save_mean; P.invstd = save_invstd;
     P.running_mean = running_mean; P.running_var = running_var; P.R = R; P.C = C; P.act = act; P.nblk = nblk;
-    P.rows_per_blk = rpb; P.training = training; P.eps = eps; P.momentum = momentum; P.part = (double*)workspace;
+    P.rows_per_blk = rpb; P.slice_q = pl.slice_q; P.training = training; P.eps = eps; P.momentum = momentum; P.part = (double*)workspace;
     P.y_rs4 = y_row_stride >> 2; P.gy_rs4 = C >> 2;
     P.num_batches_tracked = (long long*)num_batches_tracked;
     if (training) {
         if (!workspace || workspace_bytes < odpl_bn_act_workspace_bytes(R, C) || ((uintptr_t)workspace & 15)) return ODPL_EINVAL;
-        if (bf16) hipLaunchKernelGGL((bn_reduce_kernel<false, true, 0>), dim3(nblk), dim3(kT), lds, stream, P);      // statistics: no activation involved
-        else hipLaunchKernelGGL((bn_reduce_kernel<false, false, 0>), dim3(nblk), dim3(kT), lds, stream, P);
+        if (bf16) hipLaunchKernelGGL((bn_reduce_kernel<false, true, 0>), dim3(nblk, pl.nslices), dim3(kT), lds, stream, P);      // statistics: no activation involved
+        else hipLaunchKernelGGL((bn_reduce_kernel<false, false, 0>), dim3(nblk, pl.nslices), dim3(kT), lds, stream, P);
         ODPL_HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), dim3(kT), 0, stream, P);
         ODPL_HIP_TRY(hipGetLastError());
@@ -383,20 +401,21 @@ extern "C" int odpl_bn_act_backward_strided(const void* x, const void* grad_y, i
                                             int32_t training, int32_t act, void* grad_x, float* grad_gamma, float* grad_beta,
                                             void* workspace, size_t workspace_bytes, void* stream_) {
     if (gy_row_stride < C || (gy_row_stride & 3)) return ODPL_EINVAL;
-    int rpb, nblk; size_t lds;
-    if (!x || !grad_y || !grad_x || !gamma || !beta || !save_mean || !save_invstd || !grad_gamma || !grad_beta || !plan(R, C, &rpb, &nblk, &lds))
+    RPlan pl;
+    if (!x || !grad_y || !grad_x || !gamma || !beta || !save_mean || !save_invstd || !grad_gamma || !grad_beta || !plan(R, C, &pl))
         return ODPL_EINVAL;
+    const int rpb = pl.rows_per_blk, nblk = pl.nblk; const size_t lds = pl.lds;
     if (!workspace || workspace_bytes < odpl_bn_act_workspace_bytes(R, C) || act < 0 || act > 3) return ODPL_EINVAL;
     if (((uintptr_t)x | (uintptr_t)grad_y | (uintptr_t)grad_x) & (bf16 ? 7 : 15)) return ODPL_EINVAL;
     if (((uintptr_t)grad_gamma | (uintptr_t)grad_beta | (uintptr_t)workspace) & 15) return ODPL_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
     BnParams P = {};
     P.x = x; P.gy = grad_y; P.gx = grad_x; P.gamma = gamma; P.beta = beta; P.mean = (float*)save_mean; P.invstd = (float*)save_invstd;
-    P.R = R; P.C = C; P.act = act; P.nblk = nblk; P.rows_per_blk = rpb; P.training = training; P.part = (double*)workspace;
+    P.R = R; P.C = C; P.act = act; P.nblk = nblk; P.rows_per_blk = rpb; P.slice_q = pl.slice_q; P.training = training; P.part = (double*)workspace;
     P.y_rs4 = C >> 2; P.gy_rs4 = gy_row_stride >> 2;
     P.dgamma = grad_gamma; P.dbeta = grad_beta;
-    if (bf16) { ODPL_BN_LAUNCH(bn_reduce_kernel, true ODPL_COMMA true, dim3(nblk), lds, stream, P) }
-    else { ODPL_BN_LAUNCH(bn_reduce_kernel, true ODPL_COMMA false, dim3(nblk), lds, stream, P) }
+    if (bf16) { ODPL_BN_LAUNCH(bn_reduce_kernel, true ODPL_COMMA true, dim3(nblk, pl.nslices), lds, stream, P) }
+    else { ODPL_BN_LAUNCH(bn_reduce_kernel, true ODPL_COMMA false, dim3(nblk, pl.nslices), lds, stream, P) }
     ODPL_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(kT), 0, stream, P);
     ODPL_HIP_TRY(hipGetLastError());
