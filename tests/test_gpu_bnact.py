@@ -7,7 +7,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("shape", [(4, 64, 26, 26), (2, 32, 52, 52), (3, 1024, 13, 13), (1, 12, 5, 7), (2, 2048, 4, 4),
-                                   (16, 512, 13, 13), (16, 16, 16, 16), (5, 48, 25, 24), (4, 16, 3, 3)])
+                                   (16, 512, 13, 13), (16, 16, 16, 16), (5, 48, 25, 24), (4, 16, 3, 3),
+                                   (2, 320, 9, 11), (3, 272, 7, 5), (1, 256, 40, 37)])     # 5 channel slices; 68 quads unsliced; ragged tiles
 @pytest.mark.parametrize("act", ["mish", "leaky", "linear", "relu"])
 @pytest.mark.parametrize("training", [True, False])
 def test_bn_act_matches_torch(shape, act, training):
