@@ -157,7 +157,9 @@ int odpl_head_conv_backward(const odpl_head_conv_t* head, const odpl_sparse_grad
 size_t odpl_head_conv_backward_multi_workspace_bytes(int32_t n, const odpl_head_conv_t* heads, const odpl_sparse_grad_t* grads);
 int odpl_head_conv_backward_multi(int32_t n, const odpl_head_conv_t* heads, const odpl_sparse_grad_t* grads, void* workspace,
                                   size_t workspace_bytes, void* stream);
-/* launch geometry of the streaming kernel: rows of X per workgroup (default 32); 0 = the smallest height whose grid is one resident wave */
+/* launch geometry of the streaming kernel: rows of X per workgroup, quoted for heads of >= 64 16-byte vectors per row (4 row lanes per
+ * workgroup; narrower heads get proportionally taller tiles: every lane owns rows_per_tile / 4 rows); default 32;
+ * 0 = the smallest height whose grid is one resident wave */
 int odpl_head_conv_tune(int32_t rows_per_tile);
 
 /*
