@@ -467,6 +467,16 @@ int odpl_focus(const float* src, float* dst, int32_t B, int32_t C, int32_t H, in
 int odpl_reorg(const float* src, float* dst, int32_t B, int32_t C, int32_t H, int32_t W,
                const int64_t* host_y_strides, int32_t inverse, void* stream);
 
+/* Nearest-neighbour 2x upsampling of the necks on DENSE channels-last tensors: utils/YoloV4Utils.py:191-206 (`Upsample`,
+ * F.interpolate(size, 'nearest') in training), nn.Upsample(scale_factor=2) of model/YOLOV3.py, utils/YoloV5Utils.py's neck.
+ * The small tensor is [B,C,H,W] (channels-last, dense), the large one [B,*,2H,2W] channels-last with `big_pixel_stride` elements
+ * per pixel and the C channels starting at `big_channel_offset` (stride == C and offset 0 for a plain result; a channel slice of a
+ * `torch.cat` buffer otherwise).  fp32 (C % 4 == 0) or bf16 (C % 8 == 0), 16-byte aligned pointers, B*H <= 65535.
+ * inverse = 0: src = x (small), dst = y (large).  inverse = 1: src = grad_y (large), dst = grad_x (small) = the sum of the four
+ * replicas, accumulated in fp32 in the order (0,0) (0,1) (1,0) (1,1). */
+int odpl_upsample2x_nearest(const void* src, void* dst, int32_t B, int32_t C, int32_t H, int32_t W, int32_t bf16,
+                            int64_t big_pixel_stride, int64_t big_channel_offset, int32_t inverse, void* stream);
+
 /* ---- fused BatchNorm2d + activation on channels-last fp32: utils/YoloV4Utils.py:208-236 ---- */
 #define ODPL_ACT_LINEAR 0
 #define ODPL_ACT_MISH 1

@@ -1,0 +1,49 @@
+"""Nearest-neighbour 2x upsampling of the YOLO necks (`utils/YoloV4Utils.py:191-206`, `model/YOLOV3.py` nn.Upsample(scale_factor=2),
+`utils/YoloV5Utils.py`) on channels-last device tensors: one copy-shaped HIP launch each way instead of ATen's element-per-thread
+kernels.  Anything else (CPU, NCHW memory, other sizes, odd channel counts) goes to F.interpolate unchanged."""
+import torch
+import torch.nn.functional as F
+
+from ... import _lib
+
+
+def _native(x, size):
+    if not (x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16)):
+        return False
+    B, C, H, W = x.shape
+    if tuple(size) != (2 * H, 2 * W) or B * H > 65535 or C % (8 if x.dtype == torch.bfloat16 else 4):
+        return False
+    return x.is_contiguous(memory_format=torch.channels_last) and not (x.is_contiguous() and C > 1 and H * W > 1)
+
+
+class _Up2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        B, C, H, W = x.shape
+        y = torch.empty((B, C, 2 * H, 2 * W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        _lib.check(_lib.lib().odpl_upsample2x_nearest(_lib.ptr(x), _lib.ptr(y), B, C, H, W, 1 if x.dtype == torch.bfloat16 else 0,
+                                                      C, 0, 0, _lib.current_stream(x.device)), "odpl_upsample2x_nearest")
+        ctx.shape = (B, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        B, C, H, W = ctx.shape
+        if not (gy.is_contiguous(memory_format=torch.channels_last) and gy.dtype in (torch.float32, torch.bfloat16)
+                and C % (8 if gy.dtype == torch.bfloat16 else 4) == 0):
+            gy = gy.contiguous(memory_format=torch.channels_last)
+            if gy.dtype not in (torch.float32, torch.bfloat16) or C % (8 if gy.dtype == torch.bfloat16 else 4):
+                gy = gy.float()
+        gx = torch.empty((B, C, H, W), dtype=gy.dtype, device=gy.device, memory_format=torch.channels_last)
+        _lib.check(_lib.lib().odpl_upsample2x_nearest(_lib.ptr(gy), _lib.ptr(gx), B, C, H, W, 1 if gy.dtype == torch.bfloat16 else 0,
+                                                      C, 0, 1, _lib.current_stream(gy.device)), "odpl_upsample2x_nearest")
+        return gx
+
+
+def upsample_nearest(x, size):
+    """F.interpolate(x, size=size, mode="nearest"); the HIP kernels when `size` is exactly twice x's and x is a dense
+    channels-last fp32 / bf16 device tensor."""
+    size = (int(size[0]), int(size[1]))
+    if _native(x, size):
+        return _Up2Fn.apply(x)
+    return F.interpolate(x, size=size, mode="nearest")

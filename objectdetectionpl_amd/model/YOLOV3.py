@@ -17,12 +17,21 @@ from ..LightningFunc.losses import configure_loss
 from ..LightningFunc.nms import yolo_non_max_suppression
 from ..LightningFunc.utils import bnact as _bnact
 from ..LightningFunc.utils.headconv import HeadConv2d
+from ..LightningFunc.utils.upsample import upsample_nearest
 
 try:
     import pytorch_lightning as pl
     _Base = pl.LightningModule
 except Exception:  # noqa: BLE001
     _Base = nn.Module
+
+
+class _Upsample2x(nn.Upsample):
+    """nn.Upsample(scale_factor=2, mode="nearest") (`model/YOLOV3.py:119-121` of the reference); channels-last device tensors take
+    the HIP copy kernels of utils/upsample.py."""
+
+    def forward(self, x):
+        return upsample_nearest(x, (x.shape[2] * 2, x.shape[3] * 2))
 
 
 class Conv2dBatchReLU(nn.Module):
@@ -116,9 +125,9 @@ class YOLOv3(_Base):
         self.extractor = SelectiveSequential(["k_residual", "s_residual"], _darknet53())
         self.detector = nn.ModuleList([
             SelectiveSequential(["57_convbatch"], _head(53, 1024, 512, no, "59_conv")),
-            nn.Sequential(OrderedDict([("60_convbatch", Conv2dBatchReLU(512, 256, 1, 1, 0)), ("61_upsample", nn.Upsample(scale_factor=2, mode="nearest"))])),
+            nn.Sequential(OrderedDict([("60_convbatch", Conv2dBatchReLU(512, 256, 1, 1, 0)), ("61_upsample", _Upsample2x(scale_factor=2, mode="nearest"))])),
             SelectiveSequential(["66_convbatch"], _head(62, 256 + 512, 256, no, "68_conv")),
-            nn.Sequential(OrderedDict([("69_convbatch", Conv2dBatchReLU(256, 128, 1, 1, 0)), ("70_upsample", nn.Upsample(scale_factor=2, mode="nearest"))])),
+            nn.Sequential(OrderedDict([("69_convbatch", Conv2dBatchReLU(256, 128, 1, 1, 0)), ("70_upsample", _Upsample2x(scale_factor=2, mode="nearest"))])),
             nn.Sequential(_head(71, 128 + 256, 128, no, "77_conv")),
         ])
         self.sample = (1, 3, self.img_size, self.img_size)

@@ -24,6 +24,7 @@ from ..LightningFunc.utils import bnact as _bnact
 from ..LightningFunc.utils import convsplit as _cs
 from ..LightningFunc.utils.headconv import HeadConv2d
 from ..LightningFunc.utils.spp import spp_cat
+from ..LightningFunc.utils.upsample import upsample_nearest
 
 try:                                    # PL is optional: the reference derives from pl.LightningModule
     import pytorch_lightning as pl
@@ -166,9 +167,9 @@ class PANNeck(nn.Module):
         else:
             spp = torch.cat([F.max_pool2d(x3, 13, 1, 6), F.max_pool2d(x3, 9, 1, 4), F.max_pool2d(x3, 5, 1, 2), x3], 1)
         x6 = self._seq(spp, 4, 6)
-        up = F.interpolate(self.conv7(x6), size=d4.shape[2:], mode="nearest")
+        up = upsample_nearest(self.conv7(x6), d4.shape[2:])
         x13 = self._seq(torch.cat([self.conv8(d4), up], 1), 9, 13)
-        up = F.interpolate(self.conv14(x13), size=d3.shape[2:], mode="nearest")
+        up = upsample_nearest(self.conv14(x13), d3.shape[2:])
         x20 = self._seq(torch.cat([self.conv15(d3), up], 1), 16, 20)
         return x20, x13, x6
 

@@ -19,6 +19,7 @@ from ..LightningFunc.utils.headconv import HeadConv2d
 from ..LightningFunc.utils.s2d import focus as _focus
 from ..LightningFunc.utils.spp import spp_cat
 from ..LightningFunc.utils.spp import tile_path as _spp_tile_path
+from ..LightningFunc.utils.upsample import upsample_nearest
 
 try:
     import pytorch_lightning as pl
@@ -145,7 +146,7 @@ class backbone_head(nn.Module):
 
     @staticmethod
     def _up2(x):
-        return F.interpolate(x, size=(x.shape[2] * 2, x.shape[3] * 2), mode="nearest")
+        return upsample_nearest(x, (x.shape[2] * 2, x.shape[3] * 2))
 
     def forward(self, x):
         x = self.seq3_Conv(self.seq2_Bottleneck(self.seq1_Conv(self.seq0_Focus(x))))
