@@ -5,7 +5,9 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import bench  # noqa: F401  (stages the MIOpen find-db)
+import bench
+
+bench._stage_miopen_db()      # before torch initialises MIOpen
 import torch
 import torch.nn.functional as F
 

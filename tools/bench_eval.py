@@ -6,8 +6,12 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import bench as B          # stages the MIOpen find-db before torch initialises it
+import bench as B
+
+B._stage_miopen_db()        # before torch initialises MIOpen
 import torch
+
+B.torch = torch            # bench.py imports torch lazily (its --gpus parent must never touch the GPU)
 from objectdetectionpl_amd.model.YOLOV4 import YOLOv4
 
 
