@@ -366,6 +366,7 @@ def main():
             v = sbuf.view(-1, 2)
             v = v[v[:, 0] != 0]
             stamps.append(float(v[:, 1].max() - v[:, 0].min()) / 100.0)      # us: first workgroup start -> last end
+    t_enq = time.perf_counter() - t0      # the host has issued every launch of the K steps (the GPU may still be running them)
     fence()
     dt = time.perf_counter() - t0
     prof = {}
@@ -433,6 +434,7 @@ def main():
             "value": round(a.batch * world * a.steps / dt, 2), "unit": "img/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(1e3 * dt / a.steps, 3),
+            "host_enqueue_ms_per_step": round(1e3 * t_enq / a.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"YOLOv4 COCO-synthetic {a.img}x{a.img} bs={a.batch}/GPU training step "
