@@ -42,6 +42,31 @@ def test_bn_act_matches_torch(shape, act, training):
     assert int(b1.num_batches_tracked) == int(b2.num_batches_tracked)
 
 
+@pytest.mark.parametrize("shape", [(16, 64, 208, 208), (16, 256, 52, 52), (16, 1024, 13, 13)])
+def test_bn_act_at_baseline_config2_sizes(shape):
+    """The stage shapes of the BASELINE config-2 step themselves (177 / 44 / 11 MB maps: unsliced, 4 and 16 channel slices, ~1000
+    row tiles): statistics against float64 sums, output and gradients against the torch modules."""
+    from objectdetectionpl_amd.LightningFunc.utils.bnact import bn_act
+    g = torch.Generator().manual_seed(shape[1])
+    C = shape[1]
+    x = (torch.randn(*shape, generator=g) * 1.3 - 0.2).cuda().contiguous(memory_format=torch.channels_last)
+    b1, b2 = nn.BatchNorm2d(C).cuda().train(), nn.BatchNorm2d(C).cuda().train()
+    x1, x2 = x.clone().requires_grad_(), x.clone().requires_grad_()
+    y1 = bn_act(x1, b1, "mish")
+    y2 = F.mish(b2(x2))
+    assert torch.allclose(y1, y2, rtol=1e-4, atol=2e-5), float((y1 - y2).abs().max())
+    mean64 = x.double().mean((0, 2, 3))
+    var64 = x.double().var((0, 2, 3), unbiased=True)
+    assert torch.allclose(b1.running_mean.double(), 0.1 * mean64, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(b1.running_var.double(), 0.9 + 0.1 * var64, rtol=1e-6, atol=1e-7)
+    w = torch.randn(y2.shape, generator=torch.Generator().manual_seed(5)).cuda().contiguous(memory_format=torch.channels_last)
+    (y1 * w).sum().backward(); (y2 * w).sum().backward()
+    sc = float(x2.grad.abs().max())
+    assert torch.allclose(x1.grad, x2.grad, rtol=1e-3, atol=2e-5 * sc), float((x1.grad - x2.grad).abs().max())
+    assert torch.allclose(b1.weight.grad, b2.weight.grad, rtol=2e-3, atol=2e-4 * float(b2.weight.grad.abs().max()))
+    assert torch.allclose(b1.bias.grad, b2.bias.grad, rtol=2e-3, atol=2e-4 * float(b2.bias.grad.abs().max()))
+
+
 @pytest.mark.parametrize("shape", [(16, 255, 13, 13), (2, 255, 52, 52), (3, 7, 5, 9), (1, 1, 1, 1)])
 def test_conv_bias_head(shape):
     """Linear head conv through conv_bias: same output and same weight / bias / input gradients as nn.Conv2d."""
