@@ -208,6 +208,25 @@ def rocprof_row(kernel):
     return None
 
 
+def conv_portion(batch):
+    """MFMA utilisation of the convolution portion, reported separately -- from the committed steady-state table of
+    this command under rocprofv3 (profiles/r02_bench_steady_state.csv): MIOpen / CK / Tensile kernel time per step against
+    3 x 2 x 30.05 GMAC per image (forward + two backward products, SURVEY a-21) and the 157.3 TFLOP/s fp32 MFMA peak."""
+    import csv
+    path = os.path.join(REPO, "profiles", "r02_bench_steady_state.csv")
+    try:
+        with open(path) as f:
+            head = f.readline()
+            steps = int(head.split("last ")[1].split(" steps")[0])
+            us = sum(float(r["total_us"]) for r in csv.DictReader(f) if r["kernel"].startswith(("igemm", "ck::", "Cijk")))
+        ms = us / steps / 1e3
+        tf = 3 * 2 * 30.05e9 * batch / (ms * 1e-3) / 1e12
+        return {"ms_per_step": round(ms, 3), "tflops": round(tf, 1), "frac_of_fp32_mfma_peak": round(tf / 157.3, 3),
+                "source": "profiles/r02_bench_steady_state.csv (committed rocprofv3 pass of this command at bs 16; not re-measured in this run)"}
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def dryrun_rank(json_fd):
     """ODPL_BENCH_DRYRUN=1 (tests/test_bench_launcher.py, no GPU): the rank processes only rendezvous over gloo, sum their
     ranks and rank 0 prints one line -- exercises the launcher / env plumbing / exit-code relay without a device."""
@@ -460,6 +479,10 @@ def main():
         }
         if allreduce is not None:
             res["allreduce"] = allreduce
+        if a.batch == 16 and a.img == 416:
+            cp = conv_portion(a.batch)
+            if cp is not None:
+                res["conv_portion"] = cp
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a.cpu_sample_batch, a.classes, a.img, a.cpu_sample_steps)
         sys.stdout.flush()
