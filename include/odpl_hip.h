@@ -467,6 +467,16 @@ int odpl_focus(const float* src, float* dst, int32_t B, int32_t C, int32_t H, in
 int odpl_reorg(const float* src, float* dst, int32_t B, int32_t C, int32_t H, int32_t W,
                const int64_t* host_y_strides, int32_t inverse, void* stream);
 
+/* Convolution + bias + activation units without a BatchNorm (RetinaNet's heads, model/RetinaNet.py:93-99: Conv2d(256,256,3) + ReLU):
+ * the bias-free convolution stays on MIOpen; y = act(x + bias) on the channels-last fp32 [R = N*H*W, C] view, in place when y == x.
+ * `ones` / `zeros`: device vectors of C ones / zeros (caller-owned constants). */
+int odpl_bias_act_forward(const float* x, int64_t R, int32_t C, const float* bias, const float* ones, const float* zeros,
+                          int32_t act, float* y, void* stream);
+/* grad_x = grad_y * act'(y) and grad_bias = its sum over the rows, from the saved OUTPUT y in one pass + a finalize launch
+ * (act: ODPL_ACT_LINEAR / _LEAKY / _RELU).  workspace: odpl_bn_act_workspace_bytes(R, C) + 4*C bytes; grad_x may alias grad_y. */
+int odpl_bias_act_backward(const float* y, const float* grad_y, int64_t R, int32_t C, int32_t act, float* grad_x, float* grad_bias,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
 /* Nearest-neighbour 2x upsampling of the necks on DENSE channels-last tensors: utils/YoloV4Utils.py:191-206 (`Upsample`,
  * F.interpolate(size, 'nearest') in training), nn.Upsample(scale_factor=2) of model/YOLOV3.py, utils/YoloV5Utils.py's neck.
  * The small tensor is [B,C,H,W] (channels-last, dense), the large one [B,*,2H,2W] channels-last with `big_pixel_stride` elements
@@ -498,6 +508,13 @@ int odpl_bn_act_forward_residual(const float* x, const float* residual, int64_t 
                                  float* running_mean, float* running_var, int32_t training, float momentum, float eps,
                                  int32_t act, float* save_mean, float* save_invstd, float* y, void* workspace,
                                  size_t workspace_bytes, int64_t* num_batches_tracked, void* stream);
+/* The tail of a ResNet bottleneck (RetinaNet's backbone, model/backbone/RetinaNetbone.py: `F.relu(bn3(conv3(out)) + shortcut(x))`):
+ * y = act(bn(x) + residual) in one write.  Backward: gu = grad_y * act'(y) (also the shortcut's gradient), then
+ * odpl_bn_act_backward with ODPL_ACT_LINEAR on gu. */
+int odpl_bn_add_act_forward(const float* x, const float* residual, int64_t R, int32_t C, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, int32_t training, float momentum, float eps,
+                            int32_t act, float* save_mean, float* save_invstd, float* y, void* workspace,
+                            size_t workspace_bytes, int64_t* num_batches_tracked, void* stream);
 int odpl_bn_act_backward(const float* x, const float* grad_y, int64_t R, int32_t C, const float* gamma, const float* beta,
                          const float* save_mean, const float* save_invstd, int32_t training, int32_t act,
                          float* grad_x, float* grad_gamma, float* grad_beta, void* workspace, size_t workspace_bytes,

@@ -112,6 +112,126 @@ def conv_bias(x, conv):
     return _BiasAddFn.apply(z, conv.bias)          # under bf16 autocast z is bf16, the bias and its gradient stay fp32
 
 
+class _BnAddActFn(torch.autograd.Function):
+    """y = act(bn(x) + s) in one write; backward: gu = gy * act'(y) (also the gradient of s), then the BN backward on gu."""
+
+    @staticmethod
+    def forward(ctx, x, s, weight, bias, running_mean, running_var, training, momentum, eps, act, nbt):
+        N, C, H, W = x.shape
+        R = N * H * W
+        dev = x.device
+        L = _lib.lib()
+        y = torch.empty_like(x)
+        if training:
+            mean = torch.empty(C, dtype=torch.float32, device=dev)
+            invstd = torch.empty(C, dtype=torch.float32, device=dev)
+        else:
+            mean = running_mean.clone()
+            invstd = torch.rsqrt(running_var + eps)
+        need = L.odpl_bn_act_workspace_bytes(R, C)
+        ws = _workspace(dev, need)
+        _lib.check(L.odpl_bn_add_act_forward(_lib.ptr(x), _lib.ptr(s), R, C, _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(running_mean),
+                                             _lib.ptr(running_var), 1 if training else 0, float(momentum), float(eps), act, _lib.ptr(mean),
+                                             _lib.ptr(invstd), _lib.ptr(y), _lib.ptr(ws), ws.numel(), _lib.ptr(nbt) if training else None,
+                                             _lib.current_stream(dev)), "odpl_bn_add_act_forward")
+        ctx.save_for_backward(x, weight, bias, mean, invstd, y)
+        ctx.training, ctx.act = training, act
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, bias, mean, invstd, y = ctx.saved_tensors
+        N, C, H, W = x.shape
+        R = N * H * W
+        dev = x.device
+        L = _lib.lib()
+        if ctx.act == ACT["relu"]:
+            gu = torch.ops.aten.threshold_backward(gy, y, 0)
+        elif ctx.act == ACT["linear"]:
+            gu = gy
+        else:
+            gu = torch.where(y > 0, gy, 0.1 * gy)                  # leaky: the sign of y is the sign of the pre-activation
+        if not gu.is_contiguous(memory_format=torch.channels_last) or gu.dtype != torch.float32:
+            gu = gu.float().contiguous(memory_format=torch.channels_last)
+        gx = torch.empty_like(x)
+        dg = torch.empty(C, dtype=torch.float32, device=dev)
+        db = torch.empty(C, dtype=torch.float32, device=dev)
+        need = L.odpl_bn_act_workspace_bytes(R, C)
+        ws = _workspace(dev, need)
+        _lib.check(L.odpl_bn_act_backward(_lib.ptr(x), _lib.ptr(gu), R, C, _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(mean), _lib.ptr(invstd),
+                                          1 if ctx.training else 0, ACT["linear"], _lib.ptr(gx), _lib.ptr(dg), _lib.ptr(db), _lib.ptr(ws),
+                                          ws.numel(), _lib.current_stream(dev)), "odpl_bn_act_backward")
+        return gx, gu, dg, db, None, None, None, None, None, None, None
+
+
+def bn_add_act(x, bn, s, act="relu"):
+    """act(bn(x) + s): the tail of a ResNet bottleneck (`model/backbone/RetinaNetbone.py`), fp32 channels-last on the device
+    (mish is not supported: its derivative is not a function of the output)."""
+    if not (fusable(x, bn) and x.dtype == torch.float32 and s.shape == x.shape and s.dtype == torch.float32 and act in ("relu", "leaky", "linear")
+            and s.is_contiguous(memory_format=torch.channels_last) and not (s.is_contiguous() and x.shape[1] > 1 and x.shape[2] * x.shape[3] > 1)):
+        y = bn(x) + s
+        return torch.relu(y) if act == "relu" else (torch.nn.functional.leaky_relu(y, 0.1) if act == "leaky" else y)
+    return _BnAddActFn.apply(x, s, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.momentum, bn.eps, ACT[act],
+                             bn.num_batches_tracked)
+
+
+_consts = {}
+
+
+def _ones_zeros(dev, C):
+    k = (dev, C)
+    v = _consts.get(k)
+    if v is None:
+        v = (torch.ones(C, dtype=torch.float32, device=dev), torch.zeros(C, dtype=torch.float32, device=dev))
+        _consts[k] = v
+    return v
+
+
+class _BiasActFn(torch.autograd.Function):
+    """y = act(z + bias) written over z (the bias-free convolution's output, which no backward needs); backward from the saved y."""
+
+    @staticmethod
+    def forward(ctx, z, bias, act):
+        N, C, H, W = z.shape
+        ones, zeros = _ones_zeros(z.device, C)
+        _lib.check(_lib.lib().odpl_bias_act_forward(_lib.ptr(z), N * H * W, C, _lib.ptr(bias), _lib.ptr(ones), _lib.ptr(zeros), act, _lib.ptr(z),
+                                                    _lib.current_stream(z.device)), "odpl_bias_act_forward")
+        ctx.mark_dirty(z)
+        ctx.save_for_backward(z)
+        ctx.act = act
+        return z
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        N, C, H, W = y.shape
+        R = N * H * W
+        L = _lib.lib()
+        if gy.dtype != torch.float32 or not gy.is_contiguous(memory_format=torch.channels_last):
+            gy = gy.float().contiguous(memory_format=torch.channels_last)
+        gx = torch.empty_like(y)
+        gb = torch.empty(C, dtype=torch.float32, device=y.device)
+        need = L.odpl_bn_act_workspace_bytes(R, C) + 4 * C
+        ws = _workspace(y.device, need)
+        _lib.check(L.odpl_bias_act_backward(_lib.ptr(y), _lib.ptr(gy), R, C, ctx.act, _lib.ptr(gx), _lib.ptr(gb), _lib.ptr(ws), ws.numel(),
+                                            _lib.current_stream(y.device)), "odpl_bias_act_backward")
+        return gx, gb, None
+
+
+def conv_bias_act(x, conv, act="relu"):
+    """`act(conv(x))` for an nn.Conv2d WITH a bias and no BatchNorm (RetinaNet's head units, `model/RetinaNet.py:93-99`): the
+    bias-free convolution on MIOpen, bias + activation as one in-place epilogue, ReLU's backward and the bias gradient as one
+    pass.  act: "relu" | "leaky" | "linear".  Falls back to the torch ops off the device / off channels-last fp32."""
+    z = torch.nn.functional.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+    ok = (z.is_cuda and z.dtype == torch.float32 and z.dim() == 4 and z.shape[1] % 4 == 0 and conv.bias is not None
+          and conv.bias.dtype == torch.float32 and z.is_contiguous(memory_format=torch.channels_last) and not z.is_contiguous())
+    if not ok:
+        if conv.bias is not None:
+            z = z + conv.bias.view(1, -1, 1, 1)
+        return torch.relu(z) if act == "relu" else (torch.nn.functional.leaky_relu(z, 0.1) if act == "leaky" else z)
+    return _BiasActFn.apply(z, conv.bias, ACT[act])
+
+
 def bn_act_cat(x1, bn1, act1, x2, bn2, act2):
     """`torch.cat((act1(bn1(x1)), act2(bn2(x2))), 1)` with both epilogues writing their column slice of the result (no cat
     copy forward, no slice copies backward).  Returns None when the C++ binding is absent or the layout is not fusable."""

@@ -150,6 +150,8 @@ SIGNATURES = {
     "odpl_bias_grad_nchw": (c_int32, [c_void_p, c_int32, c_int32, c_int32, ctypes.c_int64, c_void_p, c_void_p]),
     "odpl_focus": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, POINTER(ctypes.c_int64), POINTER(ctypes.c_int64), c_int32, c_void_p]),
     "odpl_reorg": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, POINTER(ctypes.c_int64), c_int32, c_void_p]),
+    "odpl_bias_act_forward": (c_int32, [c_void_p, ctypes.c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
+    "odpl_bias_act_backward": (c_int32, [c_void_p, c_void_p, ctypes.c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_void_p]),
     "odpl_upsample2x_nearest": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, ctypes.c_int64, ctypes.c_int64, c_int32, c_void_p]),
     "odpl_spp_forward": (c_int32, [c_void_p, POINTER(ctypes.c_int64), c_int32, c_int32, c_int32, c_int32, c_void_p, POINTER(ctypes.c_int64), c_void_p]),
     "odpl_spp_backward": (c_int32, [c_void_p, POINTER(ctypes.c_int64), c_int32, c_int32, c_int32, c_int32, c_void_p, POINTER(ctypes.c_int64), c_void_p, c_void_p]),
@@ -160,6 +162,8 @@ SIGNATURES = {
                                       c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "odpl_bn_act_forward_residual": (c_int32, [c_void_p, c_void_p, ctypes.c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_float, c_float,
                                                c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "odpl_bn_add_act_forward": (c_int32, [c_void_p, c_void_p, ctypes.c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_float, c_float,
+                                          c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "odpl_bn_act_forward_strided": (c_int32, [c_void_p, c_void_p, c_int32, ctypes.c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_float, c_float,
                                               c_int32, c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_void_p, c_size_t, c_void_p, c_void_p]),
     "odpl_bn_act_backward_strided": (c_int32, [c_void_p, c_void_p, ctypes.c_int64, c_int32, ctypes.c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,

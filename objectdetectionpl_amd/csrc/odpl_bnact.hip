@@ -75,6 +75,7 @@ struct BnParams {
     float* dgamma; float* dbeta;                 // [C]
     long long* num_batches_tracked;              // nn.BatchNorm2d buffer, +1 per training forward (or null)
     long long R; int C, act, nblk, rows_per_blk, training;
+    int res_pre;                                 // residual added BEFORE the activation (ResNet: relu(bn(x) + s)) instead of after it
     int slice_q;                                 // channel quads per workgroup of the reduce passes (grid.y slices of the row), or C/4
     long long y_rs4, gy_rs4;                     // row strides of y / grad_y in float4 units (== C/4 when dense)
     float eps, momentum;
@@ -223,9 +224,15 @@ __global__ __launch_bounds__(kT) void bn_apply_kernel(const BnParams P) {
         }
         const float4 ga = reinterpret_cast<const float4*>(P.gamma)[q], be = reinterpret_cast<const float4*>(P.beta)[q];
         float4 o;
-        o.x = act_fwd<ACT>(ga.x * ((v.x - mu.x) * is.x) + be.x); o.y = act_fwd<ACT>(ga.y * ((v.y - mu.y) * is.y) + be.y);
-        o.z = act_fwd<ACT>(ga.z * ((v.z - mu.z) * is.z) + be.z); o.w = act_fwd<ACT>(ga.w * ((v.w - mu.w) * is.w) + be.w);
-        if (P.res) { const float4 t = ld_quad<BF>(P.res, i); o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
+        if (P.res && P.res_pre) {                            // ResNet bottleneck: act(bn(x) + s)
+            const float4 t = ld_quad<BF>(P.res, i);
+            o.x = act_fwd<ACT>((ga.x * ((v.x - mu.x) * is.x) + be.x) + t.x); o.y = act_fwd<ACT>((ga.y * ((v.y - mu.y) * is.y) + be.y) + t.y);
+            o.z = act_fwd<ACT>((ga.z * ((v.z - mu.z) * is.z) + be.z) + t.z); o.w = act_fwd<ACT>((ga.w * ((v.w - mu.w) * is.w) + be.w) + t.w);
+        } else {
+            o.x = act_fwd<ACT>(ga.x * ((v.x - mu.x) * is.x) + be.x); o.y = act_fwd<ACT>(ga.y * ((v.y - mu.y) * is.y) + be.y);
+            o.z = act_fwd<ACT>(ga.z * ((v.z - mu.z) * is.z) + be.z); o.w = act_fwd<ACT>(ga.w * ((v.w - mu.w) * is.w) + be.w);
+            if (P.res) { const float4 t = ld_quad<BF>(P.res, i); o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
+        }
         st_quad<BF>(P.y, r * P.y_rs4 + q, o);
         q += sq; r += sr;
         if (q >= (unsigned)c4n) { q -= c4n; ++r; }
@@ -255,6 +262,75 @@ __global__ __launch_bounds__(kT) void bn_bwd_dx_kernel(const BnParams P) {
         st_quad<BF>(P.gx, i, o);
         q += sq; r += sr;
         if (q >= (unsigned)c4n) { q -= c4n; ++r; }
+    }
+}
+
+// Backward of y = act(x + bias) (the conv + bias + ReLU units of RetinaNet's heads, model/RetinaNet.py:93-99) from the saved OUTPUT:
+// gx = gy * act'(y) and per-row-tile partial sums of gx per channel (-> grad_bias by bn_bwd_finalize_kernel) in one pass: reads gy
+// and y, writes gx (3 streams; ATen: threshold_backward 3 + a channel reduction 1).  ReLU / LeakyReLU(0.1) / linear -- the
+// activations whose derivative is a function of the output's sign.  Geometry and partial layout of the reduce passes.
+template <int ACT>
+__global__ __launch_bounds__(kT) void bias_act_bwd_kernel(const BnParams P) {
+    constexpr int K = 4;
+    extern __shared__ double s_red[];
+    const int C = P.C, c4n = C >> 2;
+    const int sq0 = blockIdx.y * P.slice_q;
+    const int sq1 = sq0 + P.slice_q < c4n ? sq0 + P.slice_q : c4n;
+    const int sqn = sq1 - sq0;
+    const int tpr = sqn < kT ? sqn : kT, rows_par = kT / tpr;
+    const int tr = threadIdx.x / tpr, tc = threadIdx.x - tr * tpr;
+    const long long r0 = (long long)blockIdx.x * P.rows_per_blk;
+    long long r1 = r0 + P.rows_per_blk; if (r1 > P.R) r1 = P.R;
+    const int nrows = (int)(r1 - r0);
+    const int lane_rows = (nrows + rows_par - 1) / rows_par;
+    const char* by = reinterpret_cast<const char*>(P.x) + (size_t)r0 * c4n * 16;       // P.x: the saved output y
+    const char* bg = reinterpret_cast<const char*>(P.gy) + (size_t)r0 * c4n * 16;
+    char* bo = reinterpret_cast<char*>(P.gx) + (size_t)r0 * c4n * 16;
+    const unsigned rs = (unsigned)c4n * 16u;
+    for (int q0 = sq0; q0 < sq1; q0 += tpr) {
+        const int q = q0 + tc;
+        const bool mine = q < sq1 && tr < rows_par;
+        const int qc = q < sq1 ? q : sq1 - 1, trc = tr < rows_par ? tr : 0;
+        double a[4] = {0, 0, 0, 0};
+        for (int k0 = 0; k0 < lane_rows; k0 += K) {
+            float4 v[K], g[K];
+#pragma unroll
+            for (int u = 0; u < K; ++u) {
+                int r = trc + (k0 + u) * rows_par; if (r > nrows - 1) r = nrows - 1;
+                const unsigned o = (unsigned)r * rs + (unsigned)qc * 16u;
+                v[u] = ld_quad_at<false>(by, o); g[u] = ld_quad_at<false>(bg, o);
+            }
+#pragma unroll
+            for (int u = 0; u < K; ++u) {
+                const int r = trc + (k0 + u) * rows_par;
+                if (mine && r < nrows) {
+                    float4 o;
+                    if (ACT == ODPL_ACT_LINEAR) o = g[u];
+                    else {
+                        const float neg = ACT == ODPL_ACT_LEAKY ? 0.1f : 0.0f;
+                        o.x = v[u].x > 0.f ? g[u].x : neg * g[u].x; o.y = v[u].y > 0.f ? g[u].y : neg * g[u].y;
+                        o.z = v[u].z > 0.f ? g[u].z : neg * g[u].z; o.w = v[u].w > 0.f ? g[u].w : neg * g[u].w;
+                    }
+                    *reinterpret_cast<float4*>(bo + ((unsigned)r * rs + (unsigned)q * 16u)) = o;
+                    a[0] += o.x; a[1] += o.y; a[2] += o.z; a[3] += o.w;
+                }
+            }
+        }
+        __syncthreads();
+        if (mine) {
+            double* d = s_red + ((size_t)tr * tpr + tc) * 8;
+            for (int i = 0; i < 4; ++i) { d[i] = a[i]; d[4 + i] = 0.0; }
+        }
+        __syncthreads();
+        if (tr == 0 && q < sq1) {
+            double sa[4] = {0, 0, 0, 0};
+            for (int t = 0; t < rows_par; ++t) {
+                const double* d = s_red + ((size_t)t * tpr + tc) * 8;
+                for (int i = 0; i < 4; ++i) sa[i] += d[i];
+            }
+            double* o = P.part + ((size_t)blockIdx.x * C + 4 * q) * 2;
+            for (int i = 0; i < 4; ++i) { o[2 * i] = sa[i]; o[2 * i + 1] = 0.0; }
+        }
     }
 }
 
@@ -349,10 +425,34 @@ extern "C" int odpl_bn_act_forward_residual(const float* x, const float* residua
                                        save_mean, save_invstd, y, C, workspace, workspace_bytes, num_batches_tracked, stream_);
 }
 
+static int bn_forward_impl(const void* x, const void* residual, int32_t res_pre, int32_t bf16, int64_t R, int32_t C, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, int32_t training, float momentum, float eps,
+                           int32_t act, float* save_mean, float* save_invstd, void* y, int64_t y_row_stride,
+                           void* workspace, size_t workspace_bytes, int64_t* num_batches_tracked, void* stream_);
+
 extern "C" int odpl_bn_act_forward_strided(const void* x, const void* residual, int32_t bf16, int64_t R, int32_t C, const float* gamma, const float* beta,
                                            float* running_mean, float* running_var, int32_t training, float momentum, float eps,
                                            int32_t act, float* save_mean, float* save_invstd, void* y, int64_t y_row_stride,
                                            void* workspace, size_t workspace_bytes, int64_t* num_batches_tracked, void* stream_) {
+    return bn_forward_impl(x, residual, 0, bf16, R, C, gamma, beta, running_mean, running_var, training, momentum, eps, act, save_mean, save_invstd,
+                           y, y_row_stride, workspace, workspace_bytes, num_batches_tracked, stream_);
+}
+
+// y = act(bn(x) + residual): the tail of a ResNet bottleneck (model/backbone/RetinaNetbone.py: `out = F.relu(bn3(conv3(out)) + shortcut(x))`).
+// Backward: gu = grad_y * act'(y) first (the shortcut's gradient), then odpl_bn_act_backward(act = linear) on gu.
+extern "C" int odpl_bn_add_act_forward(const float* x, const float* residual, int64_t R, int32_t C, const float* gamma, const float* beta,
+                                       float* running_mean, float* running_var, int32_t training, float momentum, float eps,
+                                       int32_t act, float* save_mean, float* save_invstd, float* y, void* workspace,
+                                       size_t workspace_bytes, int64_t* num_batches_tracked, void* stream_) {
+    if (!residual) return ODPL_EINVAL;
+    return bn_forward_impl(x, residual, 1, 0, R, C, gamma, beta, running_mean, running_var, training, momentum, eps, act, save_mean, save_invstd,
+                           y, C, workspace, workspace_bytes, num_batches_tracked, stream_);
+}
+
+static int bn_forward_impl(const void* x, const void* residual, int32_t res_pre, int32_t bf16, int64_t R, int32_t C, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, int32_t training, float momentum, float eps,
+                           int32_t act, float* save_mean, float* save_invstd, void* y, int64_t y_row_stride,
+                           void* workspace, size_t workspace_bytes, int64_t* num_batches_tracked, void* stream_) {
     if (y_row_stride < C || (y_row_stride & 3)) return ODPL_EINVAL;
     if (residual && y_row_stride != C) return ODPL_EINVAL;
     RPlan pl;
@@ -366,7 +466,7 @@ extern "C" int odpl_bn_act_forward_strided(const void* x, const void* residual, 
     if (((uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)save_mean | (uintptr_t)save_invstd) & 15) return ODPL_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
     BnParams P = {};
-    P.x = x; P.y = y; P.res = residual; P.gamma = gamma; P.beta = beta; P.mean = save_mean; P.invstd = save_invstd;
+    P.x = x; P.y = y; P.res = residual; P.res_pre = res_pre; P.gamma = gamma; P.beta = beta; P.mean = save_mean; P.invstd = save_invstd;
     P.running_mean = running_mean; P.running_var = running_var; P.R = R; P.C = C; P.act = act; P.nblk = nblk;
     P.rows_per_blk = rpb; P.slice_q = pl.slice_q; P.training = training; P.eps = eps; P.momentum = momentum; P.part = (double*)workspace;
     P.y_rs4 = y_row_stride >> 2; P.gy_rs4 = C >> 2;
@@ -424,6 +524,47 @@ extern "C" int odpl_bn_act_backward_strided(const void* x, const void* grad_y, i
     { const long long cap = odpl::g_bn_stream_max_blocks > 0 ? odpl::g_bn_stream_max_blocks : (n4 >= (8LL << 20) ? 16384 : 4096); if (blocks > cap) blocks = cap; }
     if (bf16) { ODPL_BN_LAUNCH(bn_bwd_dx_kernel, true, dim3((unsigned)blocks), 0, stream, P) }
     else { ODPL_BN_LAUNCH(bn_bwd_dx_kernel, false, dim3((unsigned)blocks), 0, stream, P) }
+    ODPL_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// y = act(x + bias) on a channels-last fp32 [R, C] matrix (in place when y == x): the apply pass with identity statistics
+// ((x - 0) * 1 * 1 + bias is exact).  `ones` / `zeros`: device vectors of C ones / zeros supplied by the caller.
+extern "C" int odpl_bias_act_forward(const float* x, int64_t R, int32_t C, const float* bias, const float* ones, const float* zeros,
+                                     int32_t act, float* y, void* stream_) {
+    if (!x || !y || !bias || !ones || !zeros || R < 1 || C < 4 || (C & 3) || act < 0 || act > 3) return ODPL_EINVAL;
+    if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)bias | (uintptr_t)ones | (uintptr_t)zeros) & 15)) return ODPL_EINVAL;
+    BnParams P = {};
+    P.x = x; P.y = y; P.gamma = ones; P.beta = bias; P.mean = (float*)zeros; P.invstd = (float*)ones;
+    P.R = R; P.C = C; P.act = act; P.training = 0; P.y_rs4 = C >> 2; P.gy_rs4 = C >> 2;
+    const long long n4 = R * (C >> 2);
+    long long blocks = (n4 + kT - 1) / kT;
+    { const long long cap = odpl::g_bn_stream_max_blocks > 0 ? odpl::g_bn_stream_max_blocks : (n4 >= (8LL << 20) ? 16384 : 4096); if (blocks > cap) blocks = cap; }
+    hipStream_t stream = (hipStream_t)stream_;
+    ODPL_BN_LAUNCH(bn_apply_kernel, false, dim3((unsigned)blocks), 0, stream, P)
+    ODPL_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// grad_x = grad_y * act'(y), grad_bias = sum over rows of grad_x; `y` is the forward's OUTPUT; act: linear / leaky / relu.
+// workspace: odpl_bn_act_workspace_bytes(R, C) + 4 * C bytes.  grad_x may alias grad_y.
+extern "C" int odpl_bias_act_backward(const float* y, const float* grad_y, int64_t R, int32_t C, int32_t act, float* grad_x, float* grad_bias,
+                                      void* workspace, size_t workspace_bytes, void* stream_) {
+    RPlan pl;
+    if (!y || !grad_y || !grad_x || !grad_bias || !plan(R, C, &pl)) return ODPL_EINVAL;
+    if (act != ODPL_ACT_LINEAR && act != ODPL_ACT_LEAKY && act != ODPL_ACT_RELU) return ODPL_EINVAL;
+    const size_t part_bytes = odpl_bn_act_workspace_bytes(R, C);
+    if (!workspace || workspace_bytes < part_bytes + (size_t)C * 4 || (((uintptr_t)workspace | (uintptr_t)y | (uintptr_t)grad_y | (uintptr_t)grad_x) & 15)) return ODPL_EINVAL;
+    BnParams P = {};
+    P.x = y; P.gy = grad_y; P.gx = grad_x; P.R = R; P.C = C; P.act = act; P.nblk = pl.nblk; P.rows_per_blk = pl.rows_per_blk; P.slice_q = pl.slice_q;
+    P.part = (double*)workspace; P.dbeta = grad_bias; P.dgamma = (float*)((char*)workspace + part_bytes);     // dgamma: scratch (all zeros)
+    hipStream_t stream = (hipStream_t)stream_;
+    const dim3 grid(pl.nblk, pl.nslices);
+    if (act == ODPL_ACT_RELU) hipLaunchKernelGGL(bias_act_bwd_kernel<ODPL_ACT_RELU>, grid, dim3(kT), pl.lds, stream, P);
+    else if (act == ODPL_ACT_LEAKY) hipLaunchKernelGGL(bias_act_bwd_kernel<ODPL_ACT_LEAKY>, grid, dim3(kT), pl.lds, stream, P);
+    else hipLaunchKernelGGL(bias_act_bwd_kernel<ODPL_ACT_LINEAR>, grid, dim3(kT), pl.lds, stream, P);
+    ODPL_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(kT), 0, stream, P);
     ODPL_HIP_TRY(hipGetLastError());
     return 0;
 }

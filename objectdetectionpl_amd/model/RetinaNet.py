@@ -46,9 +46,11 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         y = _bn(self.conv1(x), self.bn1, "relu")
         y = _bn(self.conv2(y), self.bn2, "relu")
-        y = _bn(self.conv3(y), self.bn3, "linear")
         s = _bn(self.downsample[0](x), self.downsample[1], "linear") if len(self.downsample) else x
-        return F.relu(y + s)
+        z = self.conv3(y)
+        if _bnact.fusable(z, self.bn3) and z.dtype == torch.float32:
+            return _bnact.bn_add_act(z, self.bn3, s, "relu")          # relu(bn3(z) + s) in one write
+        return F.relu(_bn(z, self.bn3, "linear") + s)
 
 
 class FPN(nn.Module):
@@ -131,13 +133,24 @@ class RetinaNet(_Base):
         layers.append(nn.Conv2d(256, out_planes, 3, 1, 1))
         return nn.Sequential(*layers)
 
+    @staticmethod
+    def _run_head(head, fm):
+        """[Conv2d(256,256,3,1,1), ReLU] x 4 + Conv2d (RetinaNet.py:93-99); on the device each conv + bias + ReLU unit runs as the
+        MIOpen convolution + one fused epilogue (utils/bnact.py:conv_bias_act)."""
+        if not fm.is_cuda:
+            return head(fm)
+        mods = list(head)
+        for i in range(0, len(mods) - 1, 2):
+            fm = _bnact.conv_bias_act(fm, mods[i], "relu")
+        return mods[-1](fm)
+
     def forward(self, x):
         if x.is_cuda and (self.iou_boxes is None or self.iou_boxes.device != x.device):
             self._build_anchors(x.device)          # the anchor table (criterion / NMS side) lives on the HIP device only
         loc, cls = [], []
         for fm in self.fpn(x):
-            loc.append(self.loc_head(fm).permute(0, 2, 3, 1).contiguous().view(x.size(0), -1, 4))
-            cls.append(self.cls_head(fm).permute(0, 2, 3, 1).contiguous().view(x.size(0), -1, self.num_classes))
+            loc.append(self._run_head(self.loc_head, fm).permute(0, 2, 3, 1).contiguous().view(x.size(0), -1, 4))
+            cls.append(self._run_head(self.cls_head, fm).permute(0, 2, 3, 1).contiguous().view(x.size(0), -1, self.num_classes))
         return torch.cat(loc, 1), torch.cat(cls, 1)
 
     def freeze_bn(self):

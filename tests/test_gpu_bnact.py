@@ -254,3 +254,58 @@ def test_conv_bias_bf16_autocast():
     (y1.float() * w).sum().backward()
     assert conv.bias.grad.dtype == torch.float32
     assert torch.allclose(conv.bias.grad, ref_b, rtol=2e-2, atol=2e-2 * float(ref_b.abs().max()))
+
+
+@pytest.mark.parametrize("act", ["relu", "leaky", "linear"])
+@pytest.mark.parametrize("shape", [(2, 256, 25, 42), (3, 16, 7, 5), (1, 512, 13, 13)])
+def test_conv_bias_act_matches_torch(shape, act):
+    """Conv2d(bias) + activation units without BN (RetinaNet heads): output, input / weight / bias gradients vs the torch ops."""
+    from objectdetectionpl_amd.LightningFunc.utils.bnact import conv_bias_act
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(C + H)
+    conv1 = nn.Conv2d(C, C, 3, 1, 1).cuda().to(memory_format=torch.channels_last)
+    conv2 = nn.Conv2d(C, C, 3, 1, 1).cuda().to(memory_format=torch.channels_last)
+    conv2.load_state_dict(conv1.state_dict())
+    x = torch.randn(B, C, H, W, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    x1, x2 = x.clone().requires_grad_(), x.clone().requires_grad_()
+    y1 = conv_bias_act(x1, conv1, act)
+    z = conv2(x2)
+    y2 = F.relu(z) if act == "relu" else (F.leaky_relu(z, 0.1) if act == "leaky" else z)
+    assert torch.allclose(y1, y2, rtol=1e-5, atol=1e-6), float((y1 - y2).abs().max())
+    w = torch.randn(y2.shape, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    (y1 * w).sum().backward(); (y2 * w).sum().backward()
+    assert torch.allclose(x1.grad, x2.grad, rtol=1e-4, atol=1e-5 * float(x2.grad.abs().max()))
+    assert torch.allclose(conv1.weight.grad, conv2.weight.grad, rtol=1e-4, atol=1e-5 * float(conv2.weight.grad.abs().max()))
+    assert torch.allclose(conv1.bias.grad, conv2.bias.grad, rtol=1e-4, atol=1e-5 * float(conv2.bias.grad.abs().max()))
+
+
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("shape", [(2, 256, 25, 42), (3, 64, 7, 5)])
+def test_bn_add_act_matches_torch(shape, training):
+    """relu(bn(x) + s), the tail of a ResNet bottleneck: output, both input gradients, BN parameter gradients, running stats."""
+    from objectdetectionpl_amd.LightningFunc.utils.bnact import bn_add_act
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(*shape, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    s = torch.randn(*shape, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    b1, b2 = nn.BatchNorm2d(C).cuda().train(training), nn.BatchNorm2d(C).cuda().train(training)
+    with torch.no_grad():
+        for b in (b1, b2):
+            b.weight.copy_(torch.rand(C, generator=torch.Generator().manual_seed(1)) + 0.5)
+            b.bias.copy_(torch.randn(C, generator=torch.Generator().manual_seed(2)) * 0.2)
+            b.running_var.copy_(torch.rand(C, generator=torch.Generator().manual_seed(4)) + 0.5)
+    x1, x2, s1, s2 = x.clone().requires_grad_(), x.clone().requires_grad_(), s.clone().requires_grad_(), s.clone().requires_grad_()
+    y1 = bn_add_act(x1, b1, s1, "relu")
+    y2 = F.relu(b2(x2) + s2)
+    assert torch.allclose(y1, y2, rtol=1e-4, atol=1e-5), float((y1 - y2).abs().max())
+    w = torch.randn(y2.shape, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    (y1 * w).sum().backward(); (y2 * w).sum().backward()
+    # cells whose pre-activation is within rounding of zero may fall on either side of the ReLU: compare away from them
+    far = ((b2(x2.detach()) + s2.detach()).abs() > 1e-4) if not training else torch.ones_like(y2, dtype=torch.bool)
+    assert torch.allclose(s1.grad[far], s2.grad[far], rtol=1e-5, atol=1e-6)
+    sc = float(x2.grad.abs().max())
+    assert torch.allclose(x1.grad, x2.grad, rtol=1e-3, atol=5e-5 * sc), float((x1.grad - x2.grad).abs().max())
+    assert torch.allclose(b1.weight.grad, b2.weight.grad, rtol=1e-3, atol=1e-4 * float(b2.weight.grad.abs().max()))
+    assert torch.allclose(b1.bias.grad, b2.bias.grad, rtol=1e-3, atol=1e-4 * float(b2.bias.grad.abs().max()))
+    assert torch.allclose(b1.running_mean, b2.running_mean, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(b1.running_var, b2.running_var, rtol=1e-5, atol=1e-6)
