@@ -63,6 +63,11 @@ __device__ __forceinline__ float sigmoid_fast(float z) { return __builtin_amdgcn
 __device__ __forceinline__ int fastdiv16(int e, unsigned magic) { return magic ? (int)__umulhi((unsigned)e, magic) : e; }
 inline unsigned fastdiv16_magic(unsigned d) { return d <= 1 ? 0u : (unsigned)((0xffffffffull + d) / d); }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence as well, i.e. `s_waitcnt vmcnt(0)`:
+// every X load and every dX store of the wave would have to retire before the barrier.  Use it where a barrier
+// only publishes LDS data: the wave's global loads and stores then stay in flight across it.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // nn.BCELoss element (log clamped at -100; ATen uses log1p(-p) for the negative branch).
 __device__ __forceinline__ float bce_elem(float p, float t) {
     return -(t * fmaxf(logf(p), -100.0f) + (1.0f - t) * fmaxf(log1pf(-p), -100.0f));

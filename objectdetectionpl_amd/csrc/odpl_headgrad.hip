@@ -113,11 +113,6 @@ __device__ __forceinline__ void cell_decode(const Head& P, int cell, int& n, int
     if (n >= P.N) n = -1;
 }
 
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence as well, i.e. `s_waitcnt vmcnt(0)`:
-// every X load and every dX store of the wave would have to retire before the barrier.  The two barriers of the stream kernel
-// only publish LDS data (the staged gradient tile, the dW partials), so the global loads and stores stay in flight across them.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 constexpr int kLaneRows = 8;            // rows of X in flight per lane (8 x 16 B)
 
 template <bool BF, int A>

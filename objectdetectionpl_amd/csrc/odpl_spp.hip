@@ -153,7 +153,7 @@ __device__ __forceinline__ void pool5_stage(const float* sv, const unsigned shor
         tv[p * CT + ch] = m; if (IDX) ti[p * CT + ch] = (unsigned short)mi;
         if (SB >= 0) sel[p * CT + ch] |= (unsigned)mt << (SB < 0 ? 0 : SB);
     }
-    __syncthreads();
+    lds_barrier();
     for (int p = pl; p < HW; p += PL) {                           // columns
         const int py = fastdiv16(p, mw), px = p - py * W;
         float v[5]; int ix[5]; bool ok[5];
@@ -169,7 +169,7 @@ __device__ __forceinline__ void pool5_stage(const float* sv, const unsigned shor
         dv[p * CT + ch] = m; if (IDX) di[p * CT + ch] = (unsigned short)mi;
         if (SB >= 0) sel[p * CT + ch] |= (unsigned)mt << (SB < 0 ? 0 : SB + 3);
     }
-    __syncthreads();
+    lds_barrier();
 }
 
 // Backward of one 1-D five-tap pass: input position p collects the gradient of every output q = p + (2 - t) whose recorded
@@ -192,7 +192,7 @@ __device__ __forceinline__ void back5_pass(const float* gin, float* gout, const 
         }
         gout[p * CT + ch] = a;
     }
-    __syncthreads();
+    lds_barrier();
 }
 
 // global <-> LDS tile moves; `e0` = element offset of the tile's first channel, row_stride in elements (both multiples of 4);
@@ -237,17 +237,17 @@ __global__ __launch_bounds__(kTileT) void spp_fwd_nhwc_kernel(const SppParams P)
     extern __shared__ float lds[];
     const int HW = P.H * P.W;
     const long long C = P.C;
-    float* A = lds; float* Bf = lds + HW * CT; float* T = lds + 2 * HW * CT;
+    float* A = lds; float* T = lds + HW * CT;                                     // a stage is row pass A -> T, column pass T -> A (in place)
     const long long x0 = blockIdx.y * P.xs[0] + blockIdx.x * CT, y0 = blockIdx.y * P.ys[0] + blockIdx.x * CT;
     tile_load<CT, BF>(A, P.x, x0, C, HW);
-    __syncthreads();
+    lds_barrier();
     tile_store<CT, BF>(A, P.y, y0 + P.blk[0] * C, 4 * C, HW);                     // v4: [m13 | m9 | m5 | x]; v5: [x | m5 | m9 | m13]
-    pool5_stage<CT, false>(A, nullptr, T, nullptr, Bf, nullptr, P.H, P.W, P.magic_w);
-    tile_store<CT, BF>(Bf, P.y, y0 + P.blk[1] * C, 4 * C, HW);
-    pool5_stage<CT, false>(Bf, nullptr, T, nullptr, A, nullptr, P.H, P.W, P.magic_w);
+    pool5_stage<CT, false>(A, nullptr, T, nullptr, A, nullptr, P.H, P.W, P.magic_w);
+    tile_store<CT, BF>(A, P.y, y0 + P.blk[1] * C, 4 * C, HW);
+    pool5_stage<CT, false>(A, nullptr, T, nullptr, A, nullptr, P.H, P.W, P.magic_w);
     tile_store<CT, BF>(A, P.y, y0 + P.blk[2] * C, 4 * C, HW);
-    pool5_stage<CT, false>(A, nullptr, T, nullptr, Bf, nullptr, P.H, P.W, P.magic_w);
-    tile_store<CT, BF>(Bf, P.y, y0 + P.blk[3] * C, 4 * C, HW);
+    pool5_stage<CT, false>(A, nullptr, T, nullptr, A, nullptr, P.H, P.W, P.magic_w);
+    tile_store<CT, BF>(A, P.y, y0 + P.blk[3] * C, 4 * C, HW);
 }
 
 // Backward along the cascade.  m5 = S(x), m9 = S(m5), m13 = S(m9) with S = (column five-tap max) o (row five-tap max); the forward
@@ -262,33 +262,33 @@ __global__ __launch_bounds__(kTileT) void spp_bwd_nhwc_kernel(const SppParams P)
     extern __shared__ float lds[];
     const int HW = P.H * P.W, n = HW * CT;
     const long long C = P.C;
-    float* V0 = lds; float* V1 = lds + n; float* TV = lds + 2 * n;
-    unsigned* SEL = reinterpret_cast<unsigned*>(lds + 3 * n);
-    unsigned short* I0 = reinterpret_cast<unsigned short*>(lds + 4 * n); unsigned short* I1 = I0 + n; unsigned short* TI = I0 + 2 * n;
+    float* V0 = lds; float* V1 = lds + n;                                      // a stage: row pass (V0, I0) -> (V1, I1), column pass back into (V0, I0)
+    unsigned* SEL = reinterpret_cast<unsigned*>(lds + 2 * n);
+    unsigned short* I0 = reinterpret_cast<unsigned short*>(lds + 3 * n); unsigned short* I1 = I0 + n;
     const int ch = threadIdx.x % CT, pl = threadIdx.x / CT;
     constexpr int PL = kTileT / CT;
     const long long x0 = blockIdx.y * P.xs[0] + blockIdx.x * CT, g0 = blockIdx.y * P.ys[0] + blockIdx.x * CT;
     tile_load<CT, BF>(V0, P.x, x0, C, HW);
     for (int p = pl; p < HW; p += PL) { I0[p * CT + ch] = (unsigned short)p; SEL[p * CT + ch] = 0u; }
-    __syncthreads();
-    pool5_stage<CT, true, 0>(V0, I0, TV, TI, V1, I1, P.H, P.W, P.magic_w, SEL);          // m5: row winner in bits 0-2, column winner in 3-5
-    pool5_stage<CT, true, 6>(V1, I1, TV, TI, V0, I0, P.H, P.W, P.magic_w, SEL);          // m9: bits 6-8, 9-11
-    pool5_stage<CT, true, 12>(V0, I0, TV, TI, V1, I1, P.H, P.W, P.magic_w, SEL);         // m13: bits 12-14, 15-17
+    lds_barrier();
+    pool5_stage<CT, true, 0>(V0, I0, V1, I1, V0, I0, P.H, P.W, P.magic_w, SEL);          // m5: row winner in bits 0-2, column winner in 3-5
+    pool5_stage<CT, true, 6>(V0, I0, V1, I1, V0, I0, P.H, P.W, P.magic_w, SEL);          // m9: bits 6-8, 9-11
+    pool5_stage<CT, true, 12>(V0, I0, V1, I1, V0, I0, P.H, P.W, P.magic_w, SEL);         // m13: bits 12-14, 15-17
     float* Ga = V0; float* Gb = V1;                                            // the value tiles are dead: gradient ping-pong
     tile_load<CT, BF>(Ga, P.gy, g0 + P.blk[3] * C, 4 * C, HW);                 // d m13
-    __syncthreads();
+    lds_barrier();
     back5_pass<CT, 15, false>(Ga, Gb, SEL, P.H, P.W, P.magic_w);
     back5_pass<CT, 12, true>(Gb, Ga, SEL, P.H, P.W, P.magic_w);                           // = d m9 through the third stage
     tile_load_add<CT, BF>(Ga, P.gy, g0 + P.blk[2] * C, 4 * C, HW);             // + d m9
-    __syncthreads();
+    lds_barrier();
     back5_pass<CT, 9, false>(Ga, Gb, SEL, P.H, P.W, P.magic_w);
     back5_pass<CT, 6, true>(Gb, Ga, SEL, P.H, P.W, P.magic_w);
     tile_load_add<CT, BF>(Ga, P.gy, g0 + P.blk[1] * C, 4 * C, HW);             // + d m5
-    __syncthreads();
+    lds_barrier();
     back5_pass<CT, 3, false>(Ga, Gb, SEL, P.H, P.W, P.magic_w);
     back5_pass<CT, 0, true>(Gb, Ga, SEL, P.H, P.W, P.magic_w);
     tile_load_add<CT, BF>(Ga, P.gy, g0 + P.blk[0] * C, 4 * C, HW);             // + the identity branch
-    __syncthreads();
+    lds_barrier();
     tile_store<CT, BF>(Ga, P.gx, x0, C, HW);
 }
 
@@ -336,13 +336,13 @@ extern "C" int odpl_spp_forward_ex(const void* x, const int64_t* x_strides, int3
     hipStream_t stream = (hipStream_t)stream_;
     const int ct = (((uintptr_t)x | (uintptr_t)y) & (bf16 ? 7 : 15)) ? 0 : nhwc_tile(P);
     if (ct) {
-        const size_t lds = (size_t)3 * H * W * ct * sizeof(float);
+        const size_t lds = (size_t)2 * H * W * ct * sizeof(float);
         static bool done[4] = {false, false, false, false};
         const dim3 grid(C / ct, B);
-        if (ct == 32) return bf16 ? launch_tile(spp_fwd_nhwc_kernel<32, true>, 3 * 176 * 32 * 4, lds, grid, stream, P, &done[0])
-                                  : launch_tile(spp_fwd_nhwc_kernel<32, false>, 3 * 176 * 32 * 4, lds, grid, stream, P, &done[1]);
-        return bf16 ? launch_tile(spp_fwd_nhwc_kernel<16, true>, 3 * 400 * 16 * 4, lds, grid, stream, P, &done[2])
-                    : launch_tile(spp_fwd_nhwc_kernel<16, false>, 3 * 400 * 16 * 4, lds, grid, stream, P, &done[3]);
+        if (ct == 32) return bf16 ? launch_tile(spp_fwd_nhwc_kernel<32, true>, 2 * 176 * 32 * 4, lds, grid, stream, P, &done[0])
+                                  : launch_tile(spp_fwd_nhwc_kernel<32, false>, 2 * 176 * 32 * 4, lds, grid, stream, P, &done[1]);
+        return bf16 ? launch_tile(spp_fwd_nhwc_kernel<16, true>, 2 * 400 * 16 * 4, lds, grid, stream, P, &done[2])
+                    : launch_tile(spp_fwd_nhwc_kernel<16, false>, 2 * 400 * 16 * 4, lds, grid, stream, P, &done[3]);
     }
     if (bf16) return ODPL_EINVAL;                            // bf16 only on the channels-last tile path
     hipLaunchKernelGGL(spp_fwd_kernel, dim3(C, B), dim3(256), 0, stream, P);
@@ -358,13 +358,13 @@ extern "C" int odpl_spp_backward_ex(const void* x, const int64_t* x_strides, int
     hipStream_t stream = (hipStream_t)stream_;
     const int ct = (((uintptr_t)x | (uintptr_t)grad_y | (uintptr_t)grad_x) & (bf16 ? 7 : 15)) ? 0 : nhwc_tile(P);
     if (ct) {
-        const size_t lds = (size_t)H * W * ct * (4 * sizeof(float) + 3 * sizeof(unsigned short));
+        const size_t lds = (size_t)H * W * ct * (3 * sizeof(float) + 2 * sizeof(unsigned short));
         static bool done[4] = {false, false, false, false};
         const dim3 grid(C / ct, B);
-        if (ct == 32) return bf16 ? launch_tile(spp_bwd_nhwc_kernel<32, 6, true>, 176 * 32 * 22, lds, grid, stream, P, &done[0])
-                                  : launch_tile(spp_bwd_nhwc_kernel<32, 6, false>, 176 * 32 * 22, lds, grid, stream, P, &done[1]);
-        return bf16 ? launch_tile(spp_bwd_nhwc_kernel<16, 7, true>, 400 * 16 * 22, lds, grid, stream, P, &done[2])
-                    : launch_tile(spp_bwd_nhwc_kernel<16, 7, false>, 400 * 16 * 22, lds, grid, stream, P, &done[3]);
+        if (ct == 32) return bf16 ? launch_tile(spp_bwd_nhwc_kernel<32, 6, true>, 176 * 32 * 16, lds, grid, stream, P, &done[0])
+                                  : launch_tile(spp_bwd_nhwc_kernel<32, 6, false>, 176 * 32 * 16, lds, grid, stream, P, &done[1]);
+        return bf16 ? launch_tile(spp_bwd_nhwc_kernel<16, 7, true>, 400 * 16 * 16, lds, grid, stream, P, &done[2])
+                    : launch_tile(spp_bwd_nhwc_kernel<16, 7, false>, 400 * 16 * 16, lds, grid, stream, P, &done[3]);
     }
     if (bf16) return ODPL_EINVAL;
     hipLaunchKernelGGL(spp_bwd_kernel, dim3(C, B), dim3(256), 0, stream, P);
