@@ -108,89 +108,121 @@ __global__ __launch_bounds__(256) void spp_bwd_kernel(const SppParams P) {
 // owns a [H*W positions] x [CT channels] tile: loads and stores are 16-B, 4*CT-byte contiguous per position, lanes run along
 // the channels in LDS (bank-conflict free), and the three pools are a CASCADE of separable 5x5 pools
 // (maxpool9 = maxpool5 o maxpool5, maxpool13 = maxpool5 o maxpool9 for stride 1 / same padding): 30 LDS reads per output
-// instead of 169.  Backward carries (value, ORIGINAL position) pairs through the same cascade with the order
-// "NaN (later position) > larger value > smaller position", which is associative and commutative, so the arg-max of every
-// window is exactly ATen's `if (val > maxval || isnan(val))` row-major scan (first maximum; the last NaN); then the same
-// deterministic gather as above.
+// instead of 169.  Backward recomputes the cascade on 64-bit winner keys ("NaN (later position) > larger value > smaller
+// position" as one unsigned number, see winner_key), records the winning tap of each 1-D pass and routes the gradient back
+// along them -- exactly ATen's `if (val > maxval || isnan(val))` row-major arg-max, deterministic, no atomics.
 constexpr int kTileT = 1024;           // 16 waves per workgroup: the tile fills the LDS (one workgroup per CU), waves hide its latency
 
-__device__ __forceinline__ bool better(float av, int ai, float mv, int mi) {
-    const bool an = av != av, mn = mv != mv;
-    if (an) return !mn || ai > mi;                 // a NaN beats any number; among NaNs the LAST position wins (ATen's scan order)
-    return !mn && (av > mv || (av == mv && ai < mi));
-}
-
-// One separable 5x5 stage.  The five taps are loaded UNCONDITIONALLY (clamped address + validity select) so that they are
-// independent LDS reads in flight together; the combine then runs on registers.  SB >= 0: the winning tap of the row pass is
-// recorded in bits [SB, SB+3) of sel[] and the winning tap of the column pass in bits [SB+3, SB+6) (backward routes along them).
-template <int CT, bool IDX, int SB = -1>
-__device__ __forceinline__ void pool5_stage(const float* sv, const unsigned short* si, float* tv, unsigned short* ti,
-                                            float* dv, unsigned short* di, int H, int W, unsigned mw, unsigned* sel = nullptr) {
+// ---- lean 1-D five-tap passes -------------------------------------------------------------------------------------
+// A thread owns the elements (position p_k = pl + k * PL, channel ch), k < KMAX, for the whole kernel: the LDS index of each
+// and the validity of its +-2 neighbours along x and y are computed ONCE (the first version re-derived them, with a division,
+// in every pass and spent ~150 instructions per element and pass on it and on branchy winner logic).  Taps are loaded
+// unconditionally from a clamped address and neutralised by a select, so five independent LDS reads are in flight.
+template <int KMAX>
+struct Lanes {
+    int base[KMAX];           // p * CT + ch, or -1 beyond the tile
+    unsigned mask[KMAX];      // bit t: x-tap t (px + t - 2) inside the row; bit 8 + t: y-tap t inside the column
+};
+template <int CT, int KMAX>
+__device__ __forceinline__ void lanes_init(Lanes<KMAX>& L, int H, int W, unsigned mw) {
     const int ch = threadIdx.x % CT, pl = threadIdx.x / CT, HW = H * W;
     constexpr int PL = kTileT / CT;
-    auto combine = [](const float (&v)[5], const int (&ix)[5], const bool (&ok)[5], float& m, int& mi, int& mt) {
-        m = v[2]; mi = ix[2]; mt = 2;                             // the centre tap is always valid
-        bool started = false;
 #pragma unroll
-        for (int t = 0; t < 5; ++t) {                             // ascending position: same visiting order as a scan
-            if (!ok[t]) continue;
-            if (!started) { m = v[t]; mi = ix[t]; mt = t; started = true; continue; }
-            if (IDX ? better(v[t], ix[t], m, mi) : (m == m && (v[t] > m || v[t] != v[t]))) { m = v[t]; mi = ix[t]; mt = t; }
-        }
-    };
-    for (int p = pl; p < HW; p += PL) {                           // rows
-        const int py = fastdiv16(p, mw), px = p - py * W;
-        float v[5]; int ix[5]; bool ok[5];
+    for (int k = 0; k < KMAX; ++k) {
+        const int p = pl + k * PL;
+        L.base[k] = -1; L.mask[k] = 0u;
+        if (p < HW) {
+            const int py = fastdiv16(p, mw), px = p - py * W;
+            unsigned m = 0u;
 #pragma unroll
-        for (int t = 0; t < 5; ++t) {
-            const int xx = px + t - 2;
-            ok[t] = xx >= 0 && xx < W;
-            const int q = (py * W + (ok[t] ? xx : px)) * CT + ch;
-            v[t] = sv[q]; ix[t] = IDX ? si[q] : 0;
+            for (int t = 0; t < 5; ++t) {
+                m |= (unsigned)(px + t - 2 >= 0 && px + t - 2 < W) << t;
+                m |= (unsigned)(py + t - 2 >= 0 && py + t - 2 < H) << (8 + t);
+            }
+            L.base[k] = p * CT + ch; L.mask[k] = m;
         }
-        float m; int mi, mt;
-        combine(v, ix, ok, m, mi, mt);
-        tv[p * CT + ch] = m; if (IDX) ti[p * CT + ch] = (unsigned short)mi;
-        if (SB >= 0) sel[p * CT + ch] |= (unsigned)mt << (SB < 0 ? 0 : SB);
     }
-    lds_barrier();
-    for (int p = pl; p < HW; p += PL) {                           // columns
-        const int py = fastdiv16(p, mw), px = p - py * W;
-        float v[5]; int ix[5]; bool ok[5];
+}
+
+// forward values: max over the valid taps, any NaN wins (ATen: `val > maxval || isnan(val)`); ties are irrelevant for the VALUE
+template <int KMAX, bool ALONG_X>
+__device__ __forceinline__ void max5_pass(const float* src, float* dst, const Lanes<KMAX>& L, int stride) {
 #pragma unroll
-        for (int t = 0; t < 5; ++t) {
-            const int yy = py + t - 2;
-            ok[t] = yy >= 0 && yy < H;
-            const int q = ((ok[t] ? yy : py) * W + px) * CT + ch;
-            v[t] = tv[q]; ix[t] = IDX ? ti[q] : 0;
+    for (int k = 0; k < KMAX; ++k) {
+        const int b = L.base[k];
+        if (b >= 0) {
+            const unsigned m = L.mask[k] >> (ALONG_X ? 0 : 8);
+            float v[5];
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                const bool ok = (m >> t) & 1u;
+                const float x = src[ok ? b + (t - 2) * stride : b];
+                v[t] = ok ? x : -INFINITY;
+            }
+            const float r = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[3], v[4])), v[2]);         // fmaxf skips NaNs ...
+            const bool nan = (v[0] != v[0]) | (v[1] != v[1]) | (v[2] != v[2]) | (v[3] != v[3]) | (v[4] != v[4]);
+            dst[b] = nan ? __uint_as_float(0x7fc00000u) : r;                                   // ... which win
         }
-        float m; int mi, mt;
-        combine(v, ix, ok, m, mi, mt);
-        dv[p * CT + ch] = m; if (IDX) di[p * CT + ch] = (unsigned short)mi;
-        if (SB >= 0) sel[p * CT + ch] |= (unsigned)mt << (SB < 0 ? 0 : SB + 3);
     }
     lds_barrier();
 }
 
-// Backward of one 1-D five-tap pass: input position p collects the gradient of every output q = p + (2 - t) whose recorded
-// winner is tap t (i.e. position p).  Five (selection, gradient) pairs per element, unconditional loads, fixed order.
-template <int CT, int SHIFT, bool ALONG_X>
-__device__ __forceinline__ void back5_pass(const float* gin, float* gout, const unsigned* sel, int H, int W, unsigned mw) {
-    const int ch = threadIdx.x % CT, pl = threadIdx.x / CT, HW = H * W;
-    constexpr int PL = kTileT / CT;
-    for (int p = pl; p < HW; p += PL) {
-        const int py = fastdiv16(p, mw), px = p - py * W;
-        float a = 0.f;
+// Winner keys of the backward recomputation: (ordered value, tie-break) as ONE 64-bit number whose maximum is ATen's winner --
+// NaN above every number, then the larger value, then the SMALLER original position; among NaNs the LARGER position (the last
+// NaN of the row-major scan).  -0 and +0 compare equal (`val > maxval`), so -0 is keyed as +0.  0 = "no tap".
+__device__ __forceinline__ unsigned long long winner_key(float x, int pos) {
+    unsigned u = __float_as_uint(x);
+    const bool nan = x != x;
+    if (u == 0x80000000u) u = 0u;
+    const unsigned ord = nan ? 0xffffffffu : ((u & 0x80000000u) ? ~u : (u | 0x80000000u));
+    return ((unsigned long long)ord << 32) | (unsigned)(nan ? pos : 0xffff - pos);
+}
+template <int KMAX, bool ALONG_X, int SHIFT>
+__device__ __forceinline__ void key5_pass(const unsigned long long* src, unsigned long long* dst, unsigned* sel, const Lanes<KMAX>& L, int stride) {
 #pragma unroll
-        for (int t = 0; t < 5; ++t) {
-            const int c = (ALONG_X ? px : py) + 2 - t;
-            const bool ok = c >= 0 && c < (ALONG_X ? W : H);
-            const int q = (ok ? (ALONG_X ? py * W + c : c * W + px) : p) * CT + ch;
-            const unsigned sv = sel[q];
-            const float gv = gin[q];
-            a += (ok && ((sv >> SHIFT) & 7u) == (unsigned)t) ? gv : 0.0f;
+    for (int k = 0; k < KMAX; ++k) {
+        const int b = L.base[k];
+        if (b >= 0) {
+            const unsigned m = L.mask[k] >> (ALONG_X ? 0 : 8);
+            unsigned long long kk[5];
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                const bool ok = (m >> t) & 1u;
+                const unsigned long long x = src[ok ? b + (t - 2) * stride : b];
+                kk[t] = ok ? x : 0ull;
+            }
+            unsigned long long best = kk[2]; unsigned mt = 2u;                 // the centre tap is always valid
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                if (t == 2) continue;
+                const bool c = kk[t] > best;
+                best = c ? kk[t] : best; mt = c ? (unsigned)t : mt;
+            }
+            dst[b] = best; sel[b] |= mt << SHIFT;
         }
-        gout[p * CT + ch] = a;
+    }
+    lds_barrier();
+}
+
+// Backward of one 1-D pass: element p collects the gradient of every output q = p + (2 - t) whose recorded winner is tap t.
+template <int KMAX, bool ALONG_X, int SHIFT>
+__device__ __forceinline__ void back5_pass(const float* gin, float* gout, const unsigned* sel, const Lanes<KMAX>& L, int stride) {
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int b = L.base[k];
+        if (b >= 0) {
+            const unsigned m = L.mask[k] >> (ALONG_X ? 0 : 8);
+            float a = 0.f;
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                const bool ok = (m >> (4 - t)) & 1u;                           // neighbour p + (2 - t) exists
+                const int q = ok ? b + (2 - t) * stride : b;
+                const unsigned sv = sel[q];
+                const float gv = gin[q];
+                a += (ok && ((sv >> SHIFT) & 7u) == (unsigned)t) ? gv : 0.0f;
+            }
+            gout[b] = a;
+        }
     }
     lds_barrier();
 }
@@ -232,7 +264,7 @@ __device__ __forceinline__ void st_elem(void* g, long long e, float v) {
     if (BF) reinterpret_cast<unsigned short*>(g)[e] = (unsigned short)bf16_rne(v); else reinterpret_cast<float*>(g)[e] = v;
 }
 
-template <int CT, bool BF>
+template <int CT, int KMAX, bool BF>
 __global__ __launch_bounds__(kTileT) void spp_fwd_nhwc_kernel(const SppParams P) {
     extern __shared__ float lds[];
     const int HW = P.H * P.W;
@@ -240,14 +272,16 @@ __global__ __launch_bounds__(kTileT) void spp_fwd_nhwc_kernel(const SppParams P)
     float* A = lds; float* T = lds + HW * CT;                                     // a stage is row pass A -> T, column pass T -> A (in place)
     const long long x0 = blockIdx.y * P.xs[0] + blockIdx.x * CT, y0 = blockIdx.y * P.ys[0] + blockIdx.x * CT;
     tile_load<CT, BF>(A, P.x, x0, C, HW);
+    Lanes<KMAX> L;
+    lanes_init<CT, KMAX>(L, P.H, P.W, P.magic_w);
     lds_barrier();
     tile_store<CT, BF>(A, P.y, y0 + P.blk[0] * C, 4 * C, HW);                     // v4: [m13 | m9 | m5 | x]; v5: [x | m5 | m9 | m13]
-    pool5_stage<CT, false>(A, nullptr, T, nullptr, A, nullptr, P.H, P.W, P.magic_w);
-    tile_store<CT, BF>(A, P.y, y0 + P.blk[1] * C, 4 * C, HW);
-    pool5_stage<CT, false>(A, nullptr, T, nullptr, A, nullptr, P.H, P.W, P.magic_w);
-    tile_store<CT, BF>(A, P.y, y0 + P.blk[2] * C, 4 * C, HW);
-    pool5_stage<CT, false>(A, nullptr, T, nullptr, A, nullptr, P.H, P.W, P.magic_w);
-    tile_store<CT, BF>(A, P.y, y0 + P.blk[3] * C, 4 * C, HW);
+#pragma unroll
+    for (int stage = 1; stage <= 3; ++stage) {
+        max5_pass<KMAX, true>(A, T, L, CT);
+        max5_pass<KMAX, false>(T, A, L, P.W * CT);
+        tile_store<CT, BF>(A, P.y, y0 + P.blk[stage] * C, 4 * C, HW);
+    }
 }
 
 // Backward along the cascade.  m5 = S(x), m9 = S(m5), m13 = S(m9) with S = (column five-tap max) o (row five-tap max); the forward
@@ -262,31 +296,38 @@ __global__ __launch_bounds__(kTileT) void spp_bwd_nhwc_kernel(const SppParams P)
     extern __shared__ float lds[];
     const int HW = P.H * P.W, n = HW * CT;
     const long long C = P.C;
-    float* V0 = lds; float* V1 = lds + n;                                      // a stage: row pass (V0, I0) -> (V1, I1), column pass back into (V0, I0)
-    unsigned* SEL = reinterpret_cast<unsigned*>(lds + 2 * n);
-    unsigned short* I0 = reinterpret_cast<unsigned short*>(lds + 3 * n); unsigned short* I1 = I0 + n;
-    const int ch = threadIdx.x % CT, pl = threadIdx.x / CT;
-    constexpr int PL = kTileT / CT;
+    unsigned long long* K0 = reinterpret_cast<unsigned long long*>(lds);       // a stage: row pass K0 -> K1, column pass back into K0
+    unsigned long long* K1 = K0 + n;
+    unsigned* SEL = reinterpret_cast<unsigned*>(K1 + n);
+    float* X = reinterpret_cast<float*>(K1);                                   // the x tile lands in K1's space, keys are built into K0
     const long long x0 = blockIdx.y * P.xs[0] + blockIdx.x * CT, g0 = blockIdx.y * P.ys[0] + blockIdx.x * CT;
-    tile_load<CT, BF>(V0, P.x, x0, C, HW);
-    for (int p = pl; p < HW; p += PL) { I0[p * CT + ch] = (unsigned short)p; SEL[p * CT + ch] = 0u; }
+    tile_load<CT, BF>(X, P.x, x0, C, HW);
+    Lanes<KMAX> L;
+    lanes_init<CT, KMAX>(L, P.H, P.W, P.magic_w);
     lds_barrier();
-    pool5_stage<CT, true, 0>(V0, I0, V1, I1, V0, I0, P.H, P.W, P.magic_w, SEL);          // m5: row winner in bits 0-2, column winner in 3-5
-    pool5_stage<CT, true, 6>(V0, I0, V1, I1, V0, I0, P.H, P.W, P.magic_w, SEL);          // m9: bits 6-8, 9-11
-    pool5_stage<CT, true, 12>(V0, I0, V1, I1, V0, I0, P.H, P.W, P.magic_w, SEL);         // m13: bits 12-14, 15-17
-    float* Ga = V0; float* Gb = V1;                                            // the value tiles are dead: gradient ping-pong
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int b = L.base[k];
+        if (b >= 0) { K0[b] = winner_key(X[b], b / CT); SEL[b] = 0u; }
+    }
+    lds_barrier();
+    const int sx = CT, sy = P.W * CT;
+    key5_pass<KMAX, true, 0>(K0, K1, SEL, L, sx);   key5_pass<KMAX, false, 3>(K1, K0, SEL, L, sy);      // m5: row winner in bits 0-2, column in 3-5
+    key5_pass<KMAX, true, 6>(K0, K1, SEL, L, sx);   key5_pass<KMAX, false, 9>(K1, K0, SEL, L, sy);      // m9
+    key5_pass<KMAX, true, 12>(K0, K1, SEL, L, sx);  key5_pass<KMAX, false, 15>(K1, K0, SEL, L, sy);     // m13
+    float* Ga = reinterpret_cast<float*>(K0); float* Gb = reinterpret_cast<float*>(K1);                 // the keys are dead: gradient ping-pong
     tile_load<CT, BF>(Ga, P.gy, g0 + P.blk[3] * C, 4 * C, HW);                 // d m13
     lds_barrier();
-    back5_pass<CT, 15, false>(Ga, Gb, SEL, P.H, P.W, P.magic_w);
-    back5_pass<CT, 12, true>(Gb, Ga, SEL, P.H, P.W, P.magic_w);                           // = d m9 through the third stage
+    back5_pass<KMAX, false, 15>(Ga, Gb, SEL, L, sy);
+    back5_pass<KMAX, true, 12>(Gb, Ga, SEL, L, sx);                            // = d m9 through the third stage
     tile_load_add<CT, BF>(Ga, P.gy, g0 + P.blk[2] * C, 4 * C, HW);             // + d m9
     lds_barrier();
-    back5_pass<CT, 9, false>(Ga, Gb, SEL, P.H, P.W, P.magic_w);
-    back5_pass<CT, 6, true>(Gb, Ga, SEL, P.H, P.W, P.magic_w);
+    back5_pass<KMAX, false, 9>(Ga, Gb, SEL, L, sy);
+    back5_pass<KMAX, true, 6>(Gb, Ga, SEL, L, sx);
     tile_load_add<CT, BF>(Ga, P.gy, g0 + P.blk[1] * C, 4 * C, HW);             // + d m5
     lds_barrier();
-    back5_pass<CT, 3, false>(Ga, Gb, SEL, P.H, P.W, P.magic_w);
-    back5_pass<CT, 0, true>(Gb, Ga, SEL, P.H, P.W, P.magic_w);
+    back5_pass<KMAX, false, 3>(Ga, Gb, SEL, L, sy);
+    back5_pass<KMAX, true, 0>(Gb, Ga, SEL, L, sx);
     tile_load_add<CT, BF>(Ga, P.gy, g0 + P.blk[0] * C, 4 * C, HW);             // + the identity branch
     lds_barrier();
     tile_store<CT, BF>(Ga, P.gx, x0, C, HW);
@@ -339,10 +380,10 @@ extern "C" int odpl_spp_forward_ex(const void* x, const int64_t* x_strides, int3
         const size_t lds = (size_t)2 * H * W * ct * sizeof(float);
         static bool done[4] = {false, false, false, false};
         const dim3 grid(C / ct, B);
-        if (ct == 32) return bf16 ? launch_tile(spp_fwd_nhwc_kernel<32, true>, 2 * 176 * 32 * 4, lds, grid, stream, P, &done[0])
-                                  : launch_tile(spp_fwd_nhwc_kernel<32, false>, 2 * 176 * 32 * 4, lds, grid, stream, P, &done[1]);
-        return bf16 ? launch_tile(spp_fwd_nhwc_kernel<16, true>, 2 * 400 * 16 * 4, lds, grid, stream, P, &done[2])
-                    : launch_tile(spp_fwd_nhwc_kernel<16, false>, 2 * 400 * 16 * 4, lds, grid, stream, P, &done[3]);
+        if (ct == 32) return bf16 ? launch_tile(spp_fwd_nhwc_kernel<32, 6, true>, 2 * 176 * 32 * 4, lds, grid, stream, P, &done[0])
+                                  : launch_tile(spp_fwd_nhwc_kernel<32, 6, false>, 2 * 176 * 32 * 4, lds, grid, stream, P, &done[1]);
+        return bf16 ? launch_tile(spp_fwd_nhwc_kernel<16, 7, true>, 2 * 400 * 16 * 4, lds, grid, stream, P, &done[2])
+                    : launch_tile(spp_fwd_nhwc_kernel<16, 7, false>, 2 * 400 * 16 * 4, lds, grid, stream, P, &done[3]);
     }
     if (bf16) return ODPL_EINVAL;                            // bf16 only on the channels-last tile path
     hipLaunchKernelGGL(spp_fwd_kernel, dim3(C, B), dim3(256), 0, stream, P);
@@ -358,13 +399,13 @@ extern "C" int odpl_spp_backward_ex(const void* x, const int64_t* x_strides, int
     hipStream_t stream = (hipStream_t)stream_;
     const int ct = (((uintptr_t)x | (uintptr_t)grad_y | (uintptr_t)grad_x) & (bf16 ? 7 : 15)) ? 0 : nhwc_tile(P);
     if (ct) {
-        const size_t lds = (size_t)H * W * ct * (3 * sizeof(float) + 2 * sizeof(unsigned short));
+        const size_t lds = (size_t)H * W * ct * (2 * sizeof(unsigned long long) + sizeof(unsigned));
         static bool done[4] = {false, false, false, false};
         const dim3 grid(C / ct, B);
-        if (ct == 32) return bf16 ? launch_tile(spp_bwd_nhwc_kernel<32, 6, true>, 176 * 32 * 16, lds, grid, stream, P, &done[0])
-                                  : launch_tile(spp_bwd_nhwc_kernel<32, 6, false>, 176 * 32 * 16, lds, grid, stream, P, &done[1]);
-        return bf16 ? launch_tile(spp_bwd_nhwc_kernel<16, 7, true>, 400 * 16 * 16, lds, grid, stream, P, &done[2])
-                    : launch_tile(spp_bwd_nhwc_kernel<16, 7, false>, 400 * 16 * 16, lds, grid, stream, P, &done[3]);
+        if (ct == 32) return bf16 ? launch_tile(spp_bwd_nhwc_kernel<32, 6, true>, 176 * 32 * 20, lds, grid, stream, P, &done[0])
+                                  : launch_tile(spp_bwd_nhwc_kernel<32, 6, false>, 176 * 32 * 20, lds, grid, stream, P, &done[1]);
+        return bf16 ? launch_tile(spp_bwd_nhwc_kernel<16, 7, true>, 400 * 16 * 20, lds, grid, stream, P, &done[2])
+                    : launch_tile(spp_bwd_nhwc_kernel<16, 7, false>, 400 * 16 * 20, lds, grid, stream, P, &done[3]);
     }
     if (bf16) return ODPL_EINVAL;
     hipLaunchKernelGGL(spp_bwd_kernel, dim3(C, B), dim3(256), 0, stream, P);
