@@ -204,8 +204,13 @@ __global__ __launch_bounds__(kT) void bn_bwd_finalize_kernel(const BnParams P) {
     P.dgamma[c] = (float)ss;
 }
 
+// The two stream passes walk the [R, C/4] quads grid-stride.  A bf16 quad is 8 bytes: with one quad per lane and trip the
+// apply pass has 8 B and the dx pass 16 B of loads in flight per lane -- half of what the fp32 kernels have, and below what the
+// chip needs to cover its latency (config 5's largest map: 3.7 TB/s against 6 for fp32).  bf16 therefore issues the loads of TWO
+// consecutive trips before the arithmetic of the first (U = 2; the second trip's index is clamped at the end of the tensor).
 template <bool BF, int ACT>
 __global__ __launch_bounds__(kT) void bn_apply_kernel(const BnParams P) {
+    constexpr int U = BF ? 2 : 1;
     const int c4n = P.C >> 2;
     const long long n4 = P.R * c4n, stride = (long long)gridDim.x * kT;
     const unsigned sq = (unsigned)(stride % c4n);            // the channel quad advances by a constant per iteration
@@ -213,34 +218,58 @@ __global__ __launch_bounds__(kT) void bn_apply_kernel(const BnParams P) {
     long long i = (long long)blockIdx.x * kT + threadIdx.x;
     unsigned q = (unsigned)(i % c4n);
     long long r = i / c4n;
-    for (; i < n4; i += stride) {
-        const float4 v = ld_quad<BF>(P.x, i);
-        float4 mu, is;
-        if (P.mean) { mu = reinterpret_cast<const float4*>(P.mean)[q]; is = reinterpret_cast<const float4*>(P.invstd)[q]; }
-        else {                                               // inference: statistics straight from the running buffers
-            mu = reinterpret_cast<const float4*>(P.running_mean)[q];
-            const float4 rv = reinterpret_cast<const float4*>(P.running_var)[q];
-            is = make_float4(rsqrtf(rv.x + P.eps), rsqrtf(rv.y + P.eps), rsqrtf(rv.z + P.eps), rsqrtf(rv.w + P.eps));
+    const bool has_res = P.res != nullptr;
+    // per-channel parameters: reloaded only when the lane's channel quad changes -- never, when the grid stride is a multiple of
+    // C/4 (every power-of-two channel count): four L1 requests per trip less, which is what bounded the bf16 stream
+    unsigned qcur = 0xffffffffu;
+    float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), is = mu, ga = mu, be = mu;
+    for (; i < n4; i += U * stride) {
+        long long ii[U], rr[U]; unsigned qq[U]; bool ok[U];
+        ii[0] = i; qq[0] = q; rr[0] = r; ok[0] = true;
+#pragma unroll
+        for (int u = 1; u < U; ++u) {
+            ii[u] = ii[u - 1] + stride; qq[u] = qq[u - 1] + sq; rr[u] = rr[u - 1] + sr;
+            if (qq[u] >= (unsigned)c4n) { qq[u] -= c4n; ++rr[u]; }
+            ok[u] = ii[u] < n4;
+            if (!ok[u]) { ii[u] = i; qq[u] = q; rr[u] = r; }                       // clamped: the loads stay unconditional
         }
-        const float4 ga = reinterpret_cast<const float4*>(P.gamma)[q], be = reinterpret_cast<const float4*>(P.beta)[q];
-        float4 o;
-        if (P.res && P.res_pre) {                            // ResNet bottleneck: act(bn(x) + s)
-            const float4 t = ld_quad<BF>(P.res, i);
-            o.x = act_fwd<ACT>((ga.x * ((v.x - mu.x) * is.x) + be.x) + t.x); o.y = act_fwd<ACT>((ga.y * ((v.y - mu.y) * is.y) + be.y) + t.y);
-            o.z = act_fwd<ACT>((ga.z * ((v.z - mu.z) * is.z) + be.z) + t.z); o.w = act_fwd<ACT>((ga.w * ((v.w - mu.w) * is.w) + be.w) + t.w);
-        } else {
-            o.x = act_fwd<ACT>(ga.x * ((v.x - mu.x) * is.x) + be.x); o.y = act_fwd<ACT>(ga.y * ((v.y - mu.y) * is.y) + be.y);
-            o.z = act_fwd<ACT>(ga.z * ((v.z - mu.z) * is.z) + be.z); o.w = act_fwd<ACT>(ga.w * ((v.w - mu.w) * is.w) + be.w);
-            if (P.res) { const float4 t = ld_quad<BF>(P.res, i); o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
+        float4 v[U], t[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { v[u] = ld_quad<BF>(P.x, ii[u]); if (has_res) t[u] = ld_quad<BF>(P.res, ii[u]); else t[u] = make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!ok[u]) continue;
+            const unsigned qu = qq[u];
+            if (qu != qcur) {
+                qcur = qu;
+                if (P.mean) { mu = reinterpret_cast<const float4*>(P.mean)[qu]; is = reinterpret_cast<const float4*>(P.invstd)[qu]; }
+                else {                                           // inference: statistics straight from the running buffers
+                    mu = reinterpret_cast<const float4*>(P.running_mean)[qu];
+                    const float4 rv = reinterpret_cast<const float4*>(P.running_var)[qu];
+                    is = make_float4(rsqrtf(rv.x + P.eps), rsqrtf(rv.y + P.eps), rsqrtf(rv.z + P.eps), rsqrtf(rv.w + P.eps));
+                }
+                ga = reinterpret_cast<const float4*>(P.gamma)[qu]; be = reinterpret_cast<const float4*>(P.beta)[qu];
+            }
+            const float4 vv = v[u], tt = t[u];
+            float4 o;
+            if (has_res && P.res_pre) {                          // ResNet bottleneck: act(bn(x) + s)
+                o.x = act_fwd<ACT>((ga.x * ((vv.x - mu.x) * is.x) + be.x) + tt.x); o.y = act_fwd<ACT>((ga.y * ((vv.y - mu.y) * is.y) + be.y) + tt.y);
+                o.z = act_fwd<ACT>((ga.z * ((vv.z - mu.z) * is.z) + be.z) + tt.z); o.w = act_fwd<ACT>((ga.w * ((vv.w - mu.w) * is.w) + be.w) + tt.w);
+            } else {
+                o.x = act_fwd<ACT>(ga.x * ((vv.x - mu.x) * is.x) + be.x); o.y = act_fwd<ACT>(ga.y * ((vv.y - mu.y) * is.y) + be.y);
+                o.z = act_fwd<ACT>(ga.z * ((vv.z - mu.z) * is.z) + be.z); o.w = act_fwd<ACT>(ga.w * ((vv.w - mu.w) * is.w) + be.w);
+                if (has_res) { o.x += tt.x; o.y += tt.y; o.z += tt.z; o.w += tt.w; }
+            }
+            st_quad<BF>(P.y, rr[u] * P.y_rs4 + qu, o);
         }
-        st_quad<BF>(P.y, r * P.y_rs4 + q, o);
-        q += sq; r += sr;
+        q = qq[U - 1] + sq; r = rr[U - 1] + sr;                  // (a clamped last trip ends the loop anyway)
         if (q >= (unsigned)c4n) { q -= c4n; ++r; }
     }
 }
 
 template <bool BF, int ACT>
 __global__ __launch_bounds__(kT) void bn_bwd_dx_kernel(const BnParams P) {
+    constexpr int U = BF ? 2 : 1;
     const int c4n = P.C >> 2;
     const long long n4 = P.R * c4n, stride = (long long)gridDim.x * kT;
     const float invR = P.training ? (float)(1.0 / (double)P.R) : 0.0f;     // eval mode: statistics are constants
@@ -249,18 +278,40 @@ __global__ __launch_bounds__(kT) void bn_bwd_dx_kernel(const BnParams P) {
     long long i = (long long)blockIdx.x * kT + threadIdx.x;
     unsigned q = (unsigned)(i % c4n);
     long long r = i / c4n;
-    for (; i < n4; i += stride) {
-        const float4 v = ld_quad<BF>(P.x, i), g = ld_quad<BF>(P.gy, r * P.gy_rs4 + q);
-        const float4 mu = reinterpret_cast<const float4*>(P.mean)[q], is = reinterpret_cast<const float4*>(P.invstd)[q];
-        const float4 ga = reinterpret_cast<const float4*>(P.gamma)[q], be = reinterpret_cast<const float4*>(P.beta)[q];
-        const float4 db = reinterpret_cast<const float4*>(P.dbeta)[q], dg = reinterpret_cast<const float4*>(P.dgamma)[q];
-        float4 o;
+    unsigned qcur = 0xffffffffu;                             // per-channel parameters: reloaded only when the channel quad changes
+    float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), is = mu, ga = mu, be = mu, db = mu, dg = mu;
+    for (; i < n4; i += U * stride) {
+        long long ii[U], rr[U]; unsigned qq[U]; bool ok[U];
+        ii[0] = i; qq[0] = q; rr[0] = r; ok[0] = true;
+#pragma unroll
+        for (int u = 1; u < U; ++u) {
+            ii[u] = ii[u - 1] + stride; qq[u] = qq[u - 1] + sq; rr[u] = rr[u - 1] + sr;
+            if (qq[u] >= (unsigned)c4n) { qq[u] -= c4n; ++rr[u]; }
+            ok[u] = ii[u] < n4;
+            if (!ok[u]) { ii[u] = i; qq[u] = q; rr[u] = r; }
+        }
+        float4 vv[U], gg[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { vv[u] = ld_quad<BF>(P.x, ii[u]); gg[u] = ld_quad<BF>(P.gy, rr[u] * P.gy_rs4 + qq[u]); }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!ok[u]) continue;
+            const unsigned qu = qq[u];
+            const float4 v = vv[u], g = gg[u];
+            if (qu != qcur) {
+                qcur = qu;
+                mu = reinterpret_cast<const float4*>(P.mean)[qu]; is = reinterpret_cast<const float4*>(P.invstd)[qu];
+                ga = reinterpret_cast<const float4*>(P.gamma)[qu]; be = reinterpret_cast<const float4*>(P.beta)[qu];
+                db = reinterpret_cast<const float4*>(P.dbeta)[qu]; dg = reinterpret_cast<const float4*>(P.dgamma)[qu];
+            }
+            float4 o;
 #define ODPL_DX(f) { const float xh = (v.f - mu.f) * is.f; const float gz = g.f * act_grad<ACT>(ga.f * xh + be.f); \
                      o.f = ga.f * is.f * (gz - db.f * invR - xh * dg.f * invR); }
-        ODPL_DX(x) ODPL_DX(y) ODPL_DX(z) ODPL_DX(w)
+            ODPL_DX(x) ODPL_DX(y) ODPL_DX(z) ODPL_DX(w)
 #undef ODPL_DX
-        st_quad<BF>(P.gx, i, o);
-        q += sq; r += sr;
+            st_quad<BF>(P.gx, ii[u], o);
+        }
+        q = qq[U - 1] + sq; r = rr[U - 1] + sr;
         if (q >= (unsigned)c4n) { q -= c4n; ++r; }
     }
 }
