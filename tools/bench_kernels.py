@@ -180,11 +180,16 @@ def caller_side(g):
     b = torch.randn(256, generator=g).to(dev)
     nb = z.numel() * 4
     timed_events("conv bias + ReLU epilogue forward (config4 P3 head unit)", lambda: _BiasActFn.apply(z, b, 3), 2 * nb, "in place: 1 read + 1 write")
-    zz = z.clone().requires_grad_()
-    y = _BiasActFn.apply(zz * 1.0, b, 3)
-    gy = torch.randn_like(y)
-    timed_events("conv bias + ReLU epilogue backward (config4 P3 head unit)", lambda: torch.autograd.grad(y, zz, gy, retain_graph=True), 3 * nb,
-                 "gy + y read, grad written, bias-gradient partials (+ the multiply of the test harness)")
+    y = _BiasActFn.apply(z.clone(), b, 3)
+    gy, gx, gb = torch.randn_like(y), torch.empty_like(y), torch.empty(256, device=dev)
+    L = _lib.lib()
+    R = z.shape[0] * z.shape[2] * z.shape[3]
+    need = L.odpl_bn_act_workspace_bytes(R, 256) + 4 * 256
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    timed_events("conv bias + ReLU epilogue backward (config4 P3 head unit)",
+                 lambda: _lib.check(L.odpl_bias_act_backward(_lib.ptr(y), _lib.ptr(gy), R, 256, 3, _lib.ptr(gx), _lib.ptr(gb), _lib.ptr(ws), need,
+                                                             _lib.current_stream(dev)), "odpl_bias_act_backward"),
+                 3 * nb, "gy + y read, grad written, bias-gradient partials + finalize launch")
 
 
 if __name__ == "__main__":
