@@ -81,6 +81,28 @@ __global__ __launch_bounds__(kT) void focus_nhwc3_kernel(const S2dParams P) {
     }
 }
 
+// Forward, even W/2: one thread moves TWO output pixels -- 48 contiguous bytes per input row as three 16-byte loads, 96 contiguous
+// output bytes as six 16-byte stores.
+__global__ __launch_bounds__(kT) void focus_nhwc3x2_kernel(const S2dParams P) {
+    const int H2 = P.H >> 1, W4 = P.W >> 2;
+    const int row = blockIdx.y;
+    const int b = row / H2, i = row - b * H2;
+    const size_t x0 = ((size_t)(b * P.H + 2 * i) * P.W) * 3, x1 = x0 + (size_t)P.W * 3, y0 = ((size_t)row * (P.W >> 1)) * 12;
+    for (int j = blockIdx.x * kT + threadIdx.x; j < W4; j += gridDim.x * kT) {
+        const float4* r0 = reinterpret_cast<const float4*>(P.src + x0 + 12 * (size_t)j);
+        const float4* r1 = reinterpret_cast<const float4*>(P.src + x1 + 12 * (size_t)j);
+        const float4 a0 = r0[0], a1 = r0[1], a2 = r0[2], b0 = r1[0], b1 = r1[1], b2 = r1[2];
+        float4* o = reinterpret_cast<float4*>(P.dst + y0 + 24 * (size_t)j);
+        // row floats 0..11 = pixels 4j .. 4j+3 (3 channels each): a0 = (0,1,2,3) a1 = (4,5,6,7) a2 = (8,9,10,11)
+        o[0] = make_float4(a0.x, a0.y, a0.z, b0.x);          // pixel 2j:   [p0 row0 | p0 row1 | p1 row0 | p1 row1]
+        o[1] = make_float4(b0.y, b0.z, a0.w, a1.x);
+        o[2] = make_float4(a1.y, b0.w, b1.x, b1.y);
+        o[3] = make_float4(a1.z, a1.w, a2.x, b1.z);          // pixel 2j+1: [p2 row0 | p2 row1 | p3 row0 | p3 row1]
+        o[4] = make_float4(b1.w, b2.x, a2.y, a2.z);
+        o[5] = make_float4(a2.w, b2.y, b2.z, b2.w);
+    }
+}
+
 template <bool INV>
 __global__ __launch_bounds__(kT) void reorg_kernel(const S2dParams P) {
     // x side is the contiguous NCHW block (the reference's .contiguous().view()), y side strided [B, 4C, H/2, W/2]
@@ -128,6 +150,12 @@ extern "C" int odpl_focus(const float* src, float* dst, int32_t B, int32_t C, in
     const bool y_cl = P.ys[1] == 1 && P.ys[3] == 12 && P.ys[2] == 12 * W2 && P.ys[0] == 12 * W2 * H2;
     const void* xp = inverse ? (const void*)dst : (const void*)src; const void* yp = inverse ? (const void*)src : (const void*)dst;
     if (x_cl && y_cl && (long long)B * H2 <= 65535 && !((uintptr_t)xp & 7) && !((uintptr_t)yp & 15)) {
+        if (!inverse && (W2 & 1) == 0 && !((uintptr_t)xp & 15)) {
+            int bx2 = (int)((W2 / 2 + kT - 1) / kT); if (bx2 > 64) bx2 = 64;
+            hipLaunchKernelGGL(focus_nhwc3x2_kernel, dim3(bx2, (unsigned)(B * H2)), dim3(kT), 0, (hipStream_t)stream_, P);
+            ODPL_HIP_TRY(hipGetLastError());
+            return 0;
+        }
         int bx = (int)((W2 + kT - 1) / kT); if (bx > 64) bx = 64;
         const dim3 grid(bx, (unsigned)(B * H2));
         if (inverse) hipLaunchKernelGGL(focus_nhwc3_kernel<true>, grid, dim3(kT), 0, (hipStream_t)stream_, P);
