@@ -241,3 +241,25 @@ def bn_act_cat(x1, bn1, act1, x2, bn2, act2):
     return ext.bn_act_cat(x1, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, bn1.num_batches_tracked, bn1.momentum, bn1.eps, ACT[act1],
                           x2, bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var, bn2.num_batches_tracked, bn2.momentum, bn2.eps, ACT[act2],
                           bn1.training)
+
+
+_nbt_scratch = {}
+
+
+def bn_act_of_cat(x1, x2, bn, act):
+    """`act(bn(torch.cat((x1, x2), 1)))` for ONE nn.BatchNorm2d over the concatenated channels (YOLOv5's BottleneckCSP,
+    `utils/YoloV5Utils.py:76-93`: `self.act(self.bn(torch.cat((y1, y2), dim=1)))`) without the cat: BatchNorm is per channel, so the
+    two halves are two independent epilogues over slices of the module's parameters and buffers, each writing its column slice of the
+    result; backward hands each convolution a dense gradient.  None when the C++ binding is absent or the layout is not fusable."""
+    ext = _lib.torch_ext()
+    c1 = x1.shape[1]
+    if ext is None or c1 % 4 or x2.shape[1] % 4 or bn.num_features != c1 + x2.shape[1] or not bn.affine or not bn.track_running_stats:
+        return None
+    scratch = _nbt_scratch.get(x1.device)
+    if scratch is None:
+        scratch = torch.zeros(1, dtype=torch.int64, device=x1.device)
+        _nbt_scratch[x1.device] = scratch
+    w, b, rm, rv = bn.weight, bn.bias, bn.running_mean, bn.running_var
+    return ext.bn_act_cat(x1, w[:c1], b[:c1], rm[:c1], rv[:c1], bn.num_batches_tracked, bn.momentum, bn.eps, ACT[act],
+                          x2, w[c1:], b[c1:], rm[c1:], rv[c1:], scratch, bn.momentum, bn.eps, ACT[act], bn.training)
+

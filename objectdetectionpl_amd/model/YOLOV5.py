@@ -85,8 +85,11 @@ class BottleneckCSP(nn.Module):
         self.m = nn.Sequential(*[Bottleneck(c_, c_, shortcut, g, e=1.0) for _ in range(n)])
 
     def forward(self, x):
-        y = torch.cat((self.cv3(self.m(self.cv1(x))), self.cv2(x)), 1)
-        return self.cv4(_bn_act(y, self.bn, True))
+        y1, y2 = self.cv3(self.m(self.cv1(x))), self.cv2(x)
+        y = _bnact.bn_act_of_cat(y1, y2, self.bn, "leaky") if (y1.is_cuda and self.bn.momentum is not None) else None
+        if y is None:
+            y = _bn_act(torch.cat((y1, y2), 1), self.bn, True)
+        return self.cv4(y)
 
 
 class SPP(nn.Module):
