@@ -243,7 +243,7 @@ def bn_act_cat(x1, bn1, act1, x2, bn2, act2):
                           bn1.training)
 
 
-_nbt_scratch = {}
+bn_of_cat_enabled = True        # A/B switch (tools/bench_v5.py --no-bn-of-cat): False = torch.cat followed by the BN epilogue
 
 
 def bn_act_of_cat(x1, x2, bn, act):
@@ -253,13 +253,8 @@ def bn_act_of_cat(x1, x2, bn, act):
     result; backward hands each convolution a dense gradient.  None when the C++ binding is absent or the layout is not fusable."""
     ext = _lib.torch_ext()
     c1 = x1.shape[1]
-    if ext is None or c1 % 4 or x2.shape[1] % 4 or bn.num_features != c1 + x2.shape[1] or not bn.affine or not bn.track_running_stats:
+    if not bn_of_cat_enabled or ext is None or c1 % 4 or x2.shape[1] % 4 or bn.num_features != c1 + x2.shape[1] or not bn.affine or not bn.track_running_stats:
         return None
-    scratch = _nbt_scratch.get(x1.device)
-    if scratch is None:
-        scratch = torch.zeros(1, dtype=torch.int64, device=x1.device)
-        _nbt_scratch[x1.device] = scratch
-    w, b, rm, rv = bn.weight, bn.bias, bn.running_mean, bn.running_var
-    return ext.bn_act_cat(x1, w[:c1], b[:c1], rm[:c1], rv[:c1], bn.num_batches_tracked, bn.momentum, bn.eps, ACT[act],
-                          x2, w[c1:], b[c1:], rm[c1:], rv[c1:], scratch, bn.momentum, bn.eps, ACT[act], bn.training)
+    return ext.bn_act_of_cat(x1, x2, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.training,
+                             bn.momentum, bn.eps, ACT[act])
 

@@ -30,10 +30,13 @@ struct Stats { Tensor mean, invstd; };
 
 // one forward launch group: y (row stride y_rs, column offset already applied) = act(bn(x)) [+ residual]
 Stats launch_forward(const Tensor& x, const Tensor& residual, const Tensor& weight, const Tensor& bias, const Tensor& running_mean,
-                     const Tensor& running_var, const Tensor& nbt, bool training, double momentum, double eps, int64_t act, void* y, int64_t y_rs) {
+                     const Tensor& running_var, const Tensor& nbt, bool training, double momentum, double eps, int64_t act, void* y, int64_t y_rs,
+                     const Stats* stats_out = nullptr) {
     const int64_t C = x.size(1), R = x.numel() / C;
     Stats s;
-    if (training) {
+    if (training && stats_out != nullptr && stats_out->mean.defined()) {
+        s = *stats_out;
+    } else if (training) {
         s.mean = at::empty({C}, weight.options());
         s.invstd = at::empty({C}, weight.options());
     } else {
@@ -54,9 +57,10 @@ Stats launch_forward(const Tensor& x, const Tensor& residual, const Tensor& weig
 struct Grads { Tensor gx, dgamma, dbeta; };
 
 Grads launch_backward(const Tensor& x, const void* gy, int64_t gy_rs, const Tensor& weight, const Tensor& bias, const Tensor& mean,
-                      const Tensor& invstd, bool training, int64_t act) {
+                      const Tensor& invstd, bool training, int64_t act, const Tensor& dgamma_out = Tensor(), const Tensor& dbeta_out = Tensor()) {
     const int64_t C = x.size(1), R = x.numel() / C;
-    Grads g{at::empty_like(x), at::empty({C}, weight.options()), at::empty({C}, weight.options())};
+    Grads g{at::empty_like(x), dgamma_out.defined() ? dgamma_out : at::empty({C}, weight.options()),
+            dbeta_out.defined() ? dbeta_out : at::empty({C}, weight.options())};
     const size_t need = odpl_bn_act_workspace_bytes(R, (int32_t)C);
     auto ws = at::empty({(int64_t)need}, x.options().dtype(at::kByte));
     check(odpl_bn_act_backward_strided(x.data_ptr(), gy, gy_rs, x.scalar_type() == at::kBFloat16 ? 1 : 0, R, (int32_t)C, weight.data_ptr<float>(),
@@ -131,6 +135,64 @@ Tensor bn_act_cat(Tensor x1, Tensor w1, Tensor b1, Tensor rm1, Tensor rv1, Tenso
     return BnActCatFn::apply(x1, w1, b1, rm1, rv1, nbt1, x2, w2, b2, rm2, rv2, nbt2, training, mom1, eps1, act1, mom2, eps2, act2);
 }
 
+// act(bn(cat((x1, x2), 1))) for ONE BatchNorm over the concatenated channels (YOLOv5 BottleneckCSP, utils/YoloV5Utils.py:76-93):
+// per-channel statistics make it two independent epilogues over the halves of the module's parameters and buffers.  The halves
+// are narrow() views taken HERE (inside the Function: no autograd nodes, no slice_backward launches), the parameter gradients are
+// written straight into the halves of one [C1+C2] buffer.
+struct BnOfCatFn : public torch::autograd::Function<BnOfCatFn> {
+    static Tensor forward(AutogradContext* ctx, Tensor x1, Tensor x2, Tensor w, Tensor b, Tensor rm, Tensor rv, Tensor nbt,
+                          bool training, double mom, double eps, int64_t act) {
+        const int64_t C1 = x1.size(1), C2 = x2.size(1), CT = C1 + C2;
+        auto y = at::empty({x1.size(0), CT, x1.size(2), x1.size(3)}, x1.options().memory_format(at::MemoryFormat::ChannelsLast));
+        Stats full;
+        if (training) { full.mean = at::empty({CT}, w.options()); full.invstd = at::empty({CT}, w.options()); }
+        else { full.mean = rm.clone(); full.invstd = at::rsqrt(rv + eps); }
+        const Stats h1{full.mean.narrow(0, 0, C1), full.invstd.narrow(0, 0, C1)}, h2{full.mean.narrow(0, C1, C2), full.invstd.narrow(0, C1, C2)};
+        if (training) {
+            launch_forward(x1, Tensor(), w.narrow(0, 0, C1), b.narrow(0, 0, C1), rm.narrow(0, 0, C1), rv.narrow(0, 0, C1), nbt, true, mom, eps, act,
+                           at_channel(y, 0), CT, &h1);
+            launch_forward(x2, Tensor(), w.narrow(0, C1, C2), b.narrow(0, C1, C2), rm.narrow(0, C1, C2), rv.narrow(0, C1, C2), Tensor(), true, mom, eps, act,
+                           at_channel(y, C1), CT, &h2);                            // num_batches_tracked counts the module once
+        } else {
+            const Tensor halves[2][5] = {{x1, w.narrow(0, 0, C1), b.narrow(0, 0, C1), h1.mean, h1.invstd}, {x2, w.narrow(0, C1, C2), b.narrow(0, C1, C2), h2.mean, h2.invstd}};
+            for (int k = 0; k < 2; ++k) {
+                const Tensor& x = halves[k][0];
+                const int64_t C = x.size(1), R = x.numel() / C;
+                check(odpl_bn_act_forward_strided(x.data_ptr(), nullptr, x.scalar_type() == at::kBFloat16 ? 1 : 0, R, (int32_t)C,
+                                                  halves[k][1].data_ptr<float>(), halves[k][2].data_ptr<float>(), nullptr, nullptr, 0, 0.f, (float)eps, (int32_t)act,
+                                                  halves[k][3].data_ptr<float>(), halves[k][4].data_ptr<float>(), at_channel(y, k == 0 ? 0 : C1), CT, nullptr, 0, nullptr,
+                                                  stream_of(x)), "odpl_bn_act_forward_strided");
+            }
+        }
+        ctx->save_for_backward({x1, x2, w, b, full.mean, full.invstd});
+        ctx->saved_data["training"] = training;
+        ctx->saved_data["act"] = act;
+        return y;
+    }
+
+    static tensor_list backward(AutogradContext* ctx, tensor_list grads) {
+        auto sv = ctx->get_saved_variables();
+        const bool training = ctx->saved_data["training"].toBool();
+        const int64_t act = ctx->saved_data["act"].toInt();
+        const Tensor &x1 = sv[0], &x2 = sv[1], &w = sv[2], &b = sv[3], &mean = sv[4], &invstd = sv[5];
+        const Tensor gy = as_grad_layout(grads[0], x1);
+        const int64_t C1 = x1.size(1), C2 = x2.size(1), CT = C1 + C2;
+        auto dg = at::empty({CT}, w.options()), db = at::empty({CT}, w.options());
+        const Grads g1 = launch_backward(x1, at_channel(gy, 0), CT, w.narrow(0, 0, C1), b.narrow(0, 0, C1), mean.narrow(0, 0, C1), invstd.narrow(0, 0, C1),
+                                         training, act, dg.narrow(0, 0, C1), db.narrow(0, 0, C1));
+        const Grads g2 = launch_backward(x2, at_channel(gy, C1), CT, w.narrow(0, C1, C2), b.narrow(0, C1, C2), mean.narrow(0, C1, C2), invstd.narrow(0, C1, C2),
+                                         training, act, dg.narrow(0, C1, C2), db.narrow(0, C1, C2));
+        return {g1.gx, g2.gx, dg, db, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+    }
+};
+
+Tensor bn_act_of_cat(Tensor x1, Tensor x2, Tensor w, Tensor b, Tensor rm, Tensor rv, Tensor nbt, bool training, double mom, double eps, int64_t act) {
+    if (!fusable(x1, w) || !fusable(x2, w) || x1.scalar_type() != x2.scalar_type() || x1.size(0) != x2.size(0) || x1.size(2) != x2.size(2) ||
+        x1.size(3) != x2.size(3) || w.numel() != x1.size(1) + x2.size(1))
+        return Tensor();
+    return BnOfCatFn::apply(x1, x2, w, b, rm, rv, nbt, training, mom, eps, act);
+}
+
 // inference (eval mode, no gradient wanted): one launch, statistics read from the running buffers inside the kernel
 Tensor bn_act_infer(const Tensor& x, const Tensor& weight, const Tensor& bias, const Tensor& running_mean, const Tensor& running_var,
                     double eps, int64_t act, const Tensor& residual) {
@@ -161,6 +223,7 @@ Tensor bn_act(Tensor x, Tensor weight, Tensor bias, Tensor running_mean, Tensor 
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+    m.def("bn_act_of_cat", &bn_act_of_cat, "act(bn(cat((x1, x2), 1))) for one BatchNorm over the concatenated channels, without the cat; None when not fusable");
     m.def("bn_act_cat", &bn_act_cat, "cat((act1(bn1(x1)), act2(bn2(x2))), 1) written in place by the two epilogues; None when not fusable");
     m.def("bn_act", &bn_act, "fused BatchNorm2d + activation [+ residual] (channels-last fp32 / bf16); returns None when not fusable",
           pybind11::arg("x"), pybind11::arg("weight"), pybind11::arg("bias"), pybind11::arg("running_mean"), pybind11::arg("running_var"),
