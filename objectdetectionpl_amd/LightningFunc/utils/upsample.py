@@ -47,3 +47,45 @@ def upsample_nearest(x, size):
     if _native(x, size):
         return _Up2Fn.apply(x)
     return F.interpolate(x, size=size, mode="nearest")
+
+
+class _UpCatFn(torch.autograd.Function):
+    """torch.cat([upsample2x(x), lateral], 1) in one buffer: the upsampling kernel writes its channel slice directly (pixel stride =
+    all channels), the lateral half is one strided copy; backward reads the upsampled half's gradient in place."""
+
+    @staticmethod
+    def forward(ctx, x, lateral):
+        B, C, H, W = x.shape
+        C2 = lateral.shape[1]
+        out = torch.empty((B, C + C2, 2 * H, 2 * W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        _lib.check(_lib.lib().odpl_upsample2x_nearest(_lib.ptr(x), _lib.ptr(out), B, C, H, W, 1 if x.dtype == torch.bfloat16 else 0,
+                                                      C + C2, 0, 0, _lib.current_stream(x.device)), "odpl_upsample2x_nearest")
+        out[:, C:].copy_(lateral)
+        ctx.shape = (B, C, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, H, W = ctx.shape
+        if not (g.is_contiguous(memory_format=torch.channels_last) and g.dtype in (torch.float32, torch.bfloat16)
+                and C % (8 if g.dtype == torch.bfloat16 else 4) == 0 and g.shape[1] % (8 if g.dtype == torch.bfloat16 else 4) == 0):
+            g = g.float().contiguous(memory_format=torch.channels_last)
+        gx = torch.empty((B, C, H, W), dtype=g.dtype, device=g.device, memory_format=torch.channels_last)
+        _lib.check(_lib.lib().odpl_upsample2x_nearest(_lib.ptr(g), _lib.ptr(gx), B, C, H, W, 1 if g.dtype == torch.bfloat16 else 0,
+                                                      g.shape[1], 0, 1, _lib.current_stream(g.device)), "odpl_upsample2x_nearest")
+        return gx, g[:, C:]
+
+
+cat_enabled = True          # A/B switch (tools/bench_v5.py --no-upsample-cat): False = upsample, then torch.cat
+
+
+def upsample_cat(x, lateral):
+    """torch.cat([F.interpolate(x, scale_factor=2, mode="nearest"), lateral], 1) -- the top-down merges of the YOLOv4 / YOLOv5 necks
+    (`utils/YoloV4Utils.py:444-462`, `utils/YoloV5Utils.py`) -- without materialising the upsampled tensor."""
+    size = (2 * x.shape[2], 2 * x.shape[3])
+    per = 8 if x.dtype == torch.bfloat16 else 4
+    if (cat_enabled and _native(x, size) and lateral.dim() == 4 and lateral.dtype == x.dtype and lateral.device == x.device and tuple(lateral.shape[2:]) == size
+            and lateral.shape[0] == x.shape[0] and lateral.shape[1] % per == 0):
+        return _UpCatFn.apply(x, lateral)
+    return torch.cat([upsample_nearest(x, size), lateral], 1)
+

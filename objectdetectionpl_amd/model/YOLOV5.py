@@ -19,7 +19,7 @@ from ..LightningFunc.utils.headconv import HeadConv2d
 from ..LightningFunc.utils.s2d import focus as _focus
 from ..LightningFunc.utils.spp import spp_cat
 from ..LightningFunc.utils.spp import tile_path as _spp_tile_path
-from ..LightningFunc.utils.upsample import upsample_nearest
+from ..LightningFunc.utils.upsample import upsample_cat, upsample_nearest
 
 try:
     import pytorch_lightning as pl
@@ -159,9 +159,9 @@ class backbone_head(nn.Module):
         route = self.seq10_BottleneckCSP(x)
         head = lambda conv, t: conv(t)                                         # noqa: E731  (HeadConv2d on the device, plain conv on the CPU)
         out0 = head(self.seq11_Conv2d, route)
-        route = self.seq15_BottleneckCSP(self.seq14_Conv(torch.cat([self._up2(route), r1], 1)))
+        route = self.seq15_BottleneckCSP(self.seq14_Conv(upsample_cat(route, r1)))
         out1 = head(self.seq16_Conv2d, route)
-        x = self.seq20_BottleneckCSP(self.seq19_Conv(torch.cat([self._up2(route), r0], 1)))
+        x = self.seq20_BottleneckCSP(self.seq19_Conv(upsample_cat(route, r0)))
         return head(self.seq21_Conv2d, x), out1, out0
 
 

@@ -78,3 +78,23 @@ def test_focus_rgb_channels_last_fast_path(B, H, W):
     (gx,) = torch.autograd.grad(y, x, gy)
     (gr,) = torch.autograd.grad(ref, x, gy)
     assert torch.equal(gx, gr)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_upsample_cat_matches_cat_of_interpolate(dtype):
+    """cat([upsample2x(x), lateral], 1) in one buffer (the YOLOv5 neck merges): values and both gradients."""
+    from objectdetectionpl_amd.LightningFunc.utils.upsample import upsample_cat
+    g = torch.Generator().manual_seed(11)
+    B, C, H, W, C2 = 2, 64, 7, 9, 32
+    x = torch.randn(B, C, H, W, generator=g).to(DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+    lat = torch.randn(B, C2, 2 * H, 2 * W, generator=g).to(DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+    x1, l1, x2, l2 = (t.clone().requires_grad_() for t in (x, lat, x, lat))
+    y1 = upsample_cat(x1, l1)
+    y2 = torch.cat([F.interpolate(x2, scale_factor=2, mode="nearest"), l2], 1)
+    assert y1.shape == y2.shape and y1.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(y1, y2)
+    gy = torch.randn(*y2.shape, generator=g).to(DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+    y1.backward(gy); y2.backward(gy)
+    assert torch.equal(l1.grad, l2.grad)
+    tol = dict(rtol=1e-6, atol=1e-6) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    assert torch.allclose(x1.grad.float(), x2.grad.float(), **tol)

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--no-fused-head", action="store_true", help="A/B: dense d loss/d p instead of the structured Detect backward")
     ap.add_argument("--contiguous-heads", action="store_true", help="A/B: Yolo_Layers copies to [B,na,G,G,no] like the reference")
     ap.add_argument("--no-head-gemm", action="store_true", help="A/B: Detect convolutions on MIOpen")
+    ap.add_argument("--no-upsample-cat", action="store_true", help="A/B: neck merges as upsample followed by torch.cat")
     ap.add_argument("--no-bn-of-cat", action="store_true", help="A/B: BottleneckCSP with torch.cat before its BatchNorm (the reference's op sequence)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -43,6 +44,8 @@ def main():
     HeadConv2d.enabled = not a.no_head_gemm
     from objectdetectionpl_amd.LightningFunc.utils import bnact as _bnact_mod
     _bnact_mod.bn_of_cat_enabled = not a.no_bn_of_cat
+    from objectdetectionpl_amd.LightningFunc.utils import upsample as _up_mod
+    _up_mod.cat_enabled = not a.no_upsample_cat
     torch.backends.cudnn.benchmark = bool(a.miopen_find)
     torch.manual_seed(0)
     Args.type = a.type
