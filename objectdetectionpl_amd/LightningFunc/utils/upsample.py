@@ -50,42 +50,46 @@ def upsample_nearest(x, size):
 
 
 class _UpCatFn(torch.autograd.Function):
-    """torch.cat([upsample2x(x), lateral], 1) in one buffer: the upsampling kernel writes its channel slice directly (pixel stride =
-    all channels), the lateral half is one strided copy; backward reads the upsampled half's gradient in place."""
+    """torch.cat([upsample2x(x), lateral], 1) (or [lateral, upsample2x(x)]) in one buffer: the upsampling kernel writes its channel
+    slice directly (pixel stride = all channels), the lateral half is one strided copy; backward reads the upsampled half's gradient
+    in place."""
 
     @staticmethod
-    def forward(ctx, x, lateral):
+    def forward(ctx, x, lateral, up_first):
         B, C, H, W = x.shape
         C2 = lateral.shape[1]
+        off_up, off_lat = (0, C) if up_first else (C2, 0)
         out = torch.empty((B, C + C2, 2 * H, 2 * W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         _lib.check(_lib.lib().odpl_upsample2x_nearest(_lib.ptr(x), _lib.ptr(out), B, C, H, W, 1 if x.dtype == torch.bfloat16 else 0,
-                                                      C + C2, 0, 0, _lib.current_stream(x.device)), "odpl_upsample2x_nearest")
-        out[:, C:].copy_(lateral)
-        ctx.shape = (B, C, H, W)
+                                                      C + C2, off_up, 0, _lib.current_stream(x.device)), "odpl_upsample2x_nearest")
+        out[:, off_lat:off_lat + C2].copy_(lateral)
+        ctx.meta = (B, C, H, W, C2, off_up, off_lat)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        B, C, H, W = ctx.shape
+        B, C, H, W, C2, off_up, off_lat = ctx.meta
+        per = 8 if g.dtype == torch.bfloat16 else 4
         if not (g.is_contiguous(memory_format=torch.channels_last) and g.dtype in (torch.float32, torch.bfloat16)
-                and C % (8 if g.dtype == torch.bfloat16 else 4) == 0 and g.shape[1] % (8 if g.dtype == torch.bfloat16 else 4) == 0):
+                and C % per == 0 and C2 % per == 0):
             g = g.float().contiguous(memory_format=torch.channels_last)
         gx = torch.empty((B, C, H, W), dtype=g.dtype, device=g.device, memory_format=torch.channels_last)
         _lib.check(_lib.lib().odpl_upsample2x_nearest(_lib.ptr(g), _lib.ptr(gx), B, C, H, W, 1 if g.dtype == torch.bfloat16 else 0,
-                                                      g.shape[1], 0, 1, _lib.current_stream(g.device)), "odpl_upsample2x_nearest")
-        return gx, g[:, C:]
+                                                      g.shape[1], off_up, 1, _lib.current_stream(g.device)), "odpl_upsample2x_nearest")
+        return gx, g[:, off_lat:off_lat + C2], None
 
 
 cat_enabled = True          # A/B switch (tools/bench_v5.py --no-upsample-cat): False = upsample, then torch.cat
 
 
-def upsample_cat(x, lateral):
-    """torch.cat([F.interpolate(x, scale_factor=2, mode="nearest"), lateral], 1) -- the top-down merges of the YOLOv4 / YOLOv5 necks
-    (`utils/YoloV4Utils.py:444-462`, `utils/YoloV5Utils.py`) -- without materialising the upsampled tensor."""
+def upsample_cat(x, lateral, up_first=True):
+    """torch.cat([F.interpolate(x, scale_factor=2, mode="nearest"), lateral], 1) (YOLOv5 neck) or, with up_first=False,
+    torch.cat([lateral, upsampled], 1) (YOLOv4 neck, `utils/YoloV4Utils.py:444-462`) without materialising the upsampled tensor."""
     size = (2 * x.shape[2], 2 * x.shape[3])
     per = 8 if x.dtype == torch.bfloat16 else 4
     if (cat_enabled and _native(x, size) and lateral.dim() == 4 and lateral.dtype == x.dtype and lateral.device == x.device and tuple(lateral.shape[2:]) == size
             and lateral.shape[0] == x.shape[0] and lateral.shape[1] % per == 0):
-        return _UpCatFn.apply(x, lateral)
-    return torch.cat([upsample_nearest(x, size), lateral], 1)
+        return _UpCatFn.apply(x, lateral, bool(up_first))
+    up = upsample_nearest(x, size)
+    return torch.cat([up, lateral] if up_first else [lateral, up], 1)
 

@@ -24,7 +24,7 @@ from ..LightningFunc.utils import bnact as _bnact
 from ..LightningFunc.utils import convsplit as _cs
 from ..LightningFunc.utils.headconv import HeadConv2d
 from ..LightningFunc.utils.spp import spp_cat
-from ..LightningFunc.utils.upsample import upsample_nearest
+from ..LightningFunc.utils.upsample import upsample_cat, upsample_nearest
 
 try:                                    # PL is optional: the reference derives from pl.LightningModule
     import pytorch_lightning as pl
@@ -160,6 +160,13 @@ class PANNeck(nn.Module):
             x = getattr(self, f"conv{i}")(x)
         return x
 
+    @staticmethod
+    def _merge(lateral, small):
+        """torch.cat([lateral, Upsample(small)], 1) (YoloV4Utils.py:444-462); one buffer when `small` is exactly half the size."""
+        if small.shape[2] * 2 == lateral.shape[2] and small.shape[3] * 2 == lateral.shape[3]:
+            return upsample_cat(small, lateral, up_first=False)
+        return torch.cat([lateral, upsample_nearest(small, lateral.shape[2:])], 1)
+
     def forward(self, d5, d4, d3):
         x3 = self._seq(d5, 1, 3)
         if x3.is_cuda and x3.dtype == torch.float32 and x3.shape[2] * x3.shape[3] <= 1024:
@@ -167,10 +174,8 @@ class PANNeck(nn.Module):
         else:
             spp = torch.cat([F.max_pool2d(x3, 13, 1, 6), F.max_pool2d(x3, 9, 1, 4), F.max_pool2d(x3, 5, 1, 2), x3], 1)
         x6 = self._seq(spp, 4, 6)
-        up = upsample_nearest(self.conv7(x6), d4.shape[2:])
-        x13 = self._seq(torch.cat([self.conv8(d4), up], 1), 9, 13)
-        up = upsample_nearest(self.conv14(x13), d3.shape[2:])
-        x20 = self._seq(torch.cat([self.conv15(d3), up], 1), 16, 20)
+        x13 = self._seq(self._merge(self.conv8(d4), self.conv7(x6)), 9, 13)
+        x20 = self._seq(self._merge(self.conv15(d3), self.conv14(x13)), 16, 20)
         return x20, x13, x6
 
 

@@ -80,8 +80,9 @@ def test_focus_rgb_channels_last_fast_path(B, H, W):
     assert torch.equal(gx, gr)
 
 
+@pytest.mark.parametrize("up_first", [True, False])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_upsample_cat_matches_cat_of_interpolate(dtype):
+def test_upsample_cat_matches_cat_of_interpolate(dtype, up_first):
     """cat([upsample2x(x), lateral], 1) in one buffer (the YOLOv5 neck merges): values and both gradients."""
     from objectdetectionpl_amd.LightningFunc.utils.upsample import upsample_cat
     g = torch.Generator().manual_seed(11)
@@ -89,8 +90,9 @@ def test_upsample_cat_matches_cat_of_interpolate(dtype):
     x = torch.randn(B, C, H, W, generator=g).to(DEV).to(dtype).contiguous(memory_format=torch.channels_last)
     lat = torch.randn(B, C2, 2 * H, 2 * W, generator=g).to(DEV).to(dtype).contiguous(memory_format=torch.channels_last)
     x1, l1, x2, l2 = (t.clone().requires_grad_() for t in (x, lat, x, lat))
-    y1 = upsample_cat(x1, l1)
-    y2 = torch.cat([F.interpolate(x2, scale_factor=2, mode="nearest"), l2], 1)
+    y1 = upsample_cat(x1, l1, up_first)
+    u2 = F.interpolate(x2, scale_factor=2, mode="nearest")
+    y2 = torch.cat([u2, l2] if up_first else [l2, u2], 1)
     assert y1.shape == y2.shape and y1.is_contiguous(memory_format=torch.channels_last)
     assert torch.equal(y1, y2)
     gy = torch.randn(*y2.shape, generator=g).to(DEV).to(dtype).contiguous(memory_format=torch.channels_last)
