@@ -14,7 +14,7 @@ import torch.nn as nn
 
 from .. import _lib
 from .._lib import OdplError
-from .utils.headconv import fusable_source
+from .utils.headconv import fusable_source, structured_backward_supported
 
 KEYS = ("loss", "Localization", "Size", "Conf", "Classification", "Conf_obj", "Conf_noobj")
 
@@ -96,11 +96,13 @@ class _RegionLossHeadFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, owner, target, scale_anchors, average, n, *args):
         heads, srcs = args[:n], args[n:]
-        xs, ws, bs = srcs[0::3], srcs[1::3], srcs[2::3]
         d, keep = owner._describe(list(heads), [(0, 0, 0, 0)] * n, target, scale_anchors, average)
         out7, counts, compact = owner._forward(d, heads[0].device, True)
         ctx.desc, ctx.keep, ctx.compact, ctx.n = d, keep, compact, n
-        ctx.srcs = (xs, ws, bs)
+        # (x, w, b) per head through save_for_backward: autograd's version counters then refuse a backward after an in-place
+        # edit of an activation or a parameter (a bias may be absent)
+        ctx.has = [t is not None for t in srcs]
+        ctx.save_for_backward(*[t for t in srcs if t is not None])
         ctx.used = False
         loss = out7[0]
         metrics = out7[1:]
@@ -115,8 +117,10 @@ class _RegionLossHeadFn(torch.autograd.Function):
                                "(call backward once per forward)")
         ctx.used = True
         d, compact, n = ctx.desc, ctx.compact, ctx.n
-        xs, ws, bs = ctx.srcs
-        ctx.desc = ctx.compact = ctx.srcs = ctx.keep = None
+        saved = iter(ctx.saved_tensors)
+        srcs = [next(saved) if h else None for h in ctx.has]
+        xs, ws, bs = srcs[0::3], srcs[1::3], srcs[2::3]
+        ctx.desc = ctx.compact = ctx.keep = None
         up = g_loss.contiguous().float()
         L = _lib.lib()
         need_all = ctx.needs_input_grad[5 + n:]
@@ -230,7 +234,13 @@ class _RegionLossBase(nn.Module):
         # half-precision heads (a bf16 / fp16 autocast network): the reference computes this loss in fp32, so widen once;
         # autograd narrows the gradients back (YOLOv5's criterion consumes bf16 heads natively instead)
         srcs = [fusable_source(h) for h in heads] if self.fuse_head_backward else [None]
-        if all(s is not None for s in srcs) and all(h.dtype == torch.float32 and h.is_contiguous() for h in heads):
+        fuse = all(s is not None for s in srcs) and all(h.dtype == torch.float32 and h.is_contiguous() for h in heads)
+        if fuse:        # the structured head backward has limits of its own (anchors per scale, tile geometry): ask it now
+            nT = target.shape[0] if target.dim() == 2 else -1
+            geoms = [(h.shape[0], h.shape[2] * h.shape[3], len(anc), 5 + self.num_classes, 4, nT, _lib.LAYOUT_PLANAR)
+                     for h, anc in zip(heads, scale_anchors)]
+            fuse = nT >= 0 and structured_backward_supported(srcs, geoms)
+        if fuse:
             flat = [t for s in srcs for t in s]
             loss, metrics, _counts = _RegionLossHeadFn.apply(self, target, scale_anchors, average, len(heads),
                                                              *[h.detach() for h in heads], *flat)

@@ -288,7 +288,8 @@ class _V5LossHeadFn(torch.autograd.Function):
         d, keep = owner._describe(list(heads), [_lib.LAYOUT_PLANAR] * n, target)
         out4, counts, compact = owner._forward(d, heads[0].device, True)
         ctx.desc, ctx.keep, ctx.compact, ctx.n = d, keep, compact, n
-        ctx.srcs = (srcs[0::3], srcs[1::3], srcs[2::3])
+        ctx.has = [t is not None for t in srcs]        # see losses._RegionLossHeadFn: version-checked by autograd
+        ctx.save_for_backward(*[t for t in srcs if t is not None])
         ctx.used = False
         metrics = out4[1:]
         ctx.mark_non_differentiable(metrics, counts)
@@ -301,8 +302,10 @@ class _V5LossHeadFn(torch.autograd.Function):
             raise RuntimeError("the fused YOLOv5 loss frees its gradient buffers after the first backward")
         ctx.used = True
         d, compact, n = ctx.desc, ctx.compact, ctx.n
-        xs, ws, bs = ctx.srcs
-        ctx.desc = ctx.compact = ctx.srcs = ctx.keep = None
+        saved = iter(ctx.saved_tensors)
+        srcs = [next(saved) if h else None for h in ctx.has]
+        xs, ws, bs = srcs[0::3], srcs[1::3], srcs[2::3]
+        ctx.desc = ctx.compact = ctx.keep = None
         up = g_loss.contiguous().float()
         L = _lib.lib()
         sparses = []
@@ -427,7 +430,7 @@ class MultiScaleRegionLoss_v5(nn.Module):
         return (plane // self.na, plane % self.na, gj, gi), tbox, ag >> 4, t, cell
 
     def forward(self, output, target, seen=None):
-        from .utils.headconv import fusable_source
+        from .utils.headconv import fusable_source, structured_backward_supported
         output = list(output)
         srcs = []
         if self.fuse_head_backward:
@@ -435,7 +438,12 @@ class MultiScaleRegionLoss_v5(nn.Module):
                 base = getattr(h, "_odpl_head_base", None)
                 src = fusable_source(base) if base is not None else None
                 srcs.append(src if (src is not None and _v5_layout(h)[1] == _lib.LAYOUT_PLANAR and h.data_ptr() == base.data_ptr()) else None)
-        if srcs and all(s is not None for s in srcs):
+        fuse = bool(srcs) and all(s is not None for s in srcs)
+        if fuse:        # the structured head backward's own limits (odpl_yolov5_compact_view reports 5 * na * nT row slots per layer)
+            nT = target.shape[0] if target.dim() == 2 else -1
+            geoms = [(h.shape[0], h.shape[2] * h.shape[3], self.na, 5 + self.nc, 4, 5 * self.na * nT, _lib.LAYOUT_PLANAR) for h in output]
+            fuse = nT >= 0 and structured_backward_supported(srcs, geoms)
+        if fuse:
             flat = [t for s in srcs for t in s]
             loss, m, _ = _V5LossHeadFn.apply(self, target, len(output), *[h.detach() for h in output], *flat)
         else:

@@ -74,6 +74,7 @@ def head_conv(x, conv):
     remembers (x, weight, bias) so that a YOLO criterion can run the convolution's backward from its structured gradient."""
     out = _HeadConv1x1.apply(x, conv.weight, conv.bias)
     out._odpl_head_src = (x, conv.weight, conv.bias)
+    out._odpl_head_version = out._version       # an in-place edit of the head between here and the criterion voids the shortcut
     return out
 
 
@@ -84,9 +85,13 @@ def is_head_conv(conv):
 
 def fusable_source(h):
     """(x, w, b) when the criterion may run this head's convolution backward itself: fp32 (or bf16) dense channels-last
-    input, fp32 weights, on the device, and gradients are being recorded."""
+    input, fp32 weights, on the device, and gradients are being recorded.  The shortcut bypasses the head tensor's own autograd
+    node, so it is refused when anything hangs on that node or the tensor no longer holds the convolution's output: a tensor
+    hook, `retain_grad()`, or an in-place modification since `head_conv` (version counter)."""
     src = getattr(h, "_odpl_head_src", None)
     if src is None or not torch.is_grad_enabled():
+        return None
+    if h._version != getattr(h, "_odpl_head_version", -1) or h.retains_grad or getattr(h, "_backward_hooks", None):
         return None
     x, w, b = src
     if not (x.is_cuda and w.dtype == torch.float32 and x.dtype in (torch.float32, torch.bfloat16)):
@@ -96,6 +101,35 @@ def fusable_source(h):
     if not (x.requires_grad or w.requires_grad or (b is not None and b.requires_grad)):
         return None
     return src
+
+
+def _call_groups(H, S, n):
+    """the launches `head_conv_backward` makes for n heads: all of them in one multi call when anchors per head and dtype agree,
+    one call per head otherwise -> list of (k, HeadConv array, SparseGrad array)"""
+    same = all(S[i].A == S[0].A and H[i].bf16 == H[0].bf16 for i in range(n))
+    if same:
+        return [(n, H, S)]
+    return [(1, (_lib.HeadConv * 1)(H[i]), (_lib.SparseGrad * 1)(S[i])) for i in range(n)]
+
+
+def structured_backward_supported(srcs, geoms):
+    """Asked in FORWARD, before the criterion commits to the structured route: does `odpl_head_conv_backward_multi` take these
+    heads?  srcs: [(x, w, b)] per head; geoms: [(B, G2, A, no, dense_ch, n_rows, layout)] per head -- what the compact view will
+    report.  The library's own validation answers (`*_workspace_bytes` == 0: more than 5 anchors on a scale, a geometry beyond its
+    32-bit tile offsets, ...); the query reads no device memory, so the gradient pointers it does not have yet are stand-ins."""
+    L = _lib.lib()
+    n = len(srcs)
+    if n < 1 or n > _lib.MAX_SCALES:
+        return False
+    H = (_lib.HeadConv * n)()
+    S = (_lib.SparseGrad * n)()
+    for i, ((x, w, _b), (B, G2, A, no, dc, n_rows, layout)) in enumerate(zip(srcs, geoms)):
+        if x.data_ptr() % 16 or w.data_ptr() % 16:
+            return False
+        H[i].x, H[i].w, H[i].Cin, H[i].bf16 = x.data_ptr(), w.data_ptr(), x.shape[1], 1 if x.dtype == torch.bfloat16 else 0
+        S[i].dense = S[i].rows = S[i].row_cell = x.data_ptr()          # non-NULL stand-ins (never dereferenced by the query)
+        S[i].n_rows, S[i].B, S[i].G2, S[i].A, S[i].no, S[i].dense_ch, S[i].layout = n_rows, B, G2, A, no, dc, layout
+    return all(L.odpl_head_conv_backward_multi_workspace_bytes(k, Hg, Sg) != 0 for k, Hg, Sg in _call_groups(H, S, n))
 
 
 def head_conv_backward(sparses, xs, ws, bs, upstream, needs):
@@ -121,14 +155,9 @@ def head_conv_backward(sparses, xs, ws, bs, upstream, needs):
         h.Cin = x.shape[1]
         h.bf16 = 1 if x.dtype == torch.bfloat16 else 0
         out += [gx, gw, gb]
-    same = all(S[i].A == S[0].A and H[i].bf16 == H[0].bf16 for i in range(n))
-    groups = [list(range(n))] if same else [[i] for i in range(n)]
-    for grp in groups:
-        k = len(grp)
-        Hg = H if k == n else (_lib.HeadConv * 1)(H[grp[0]])
-        Sg = S if k == n else (_lib.SparseGrad * 1)(S[grp[0]])
+    for k, Hg, Sg in _call_groups(H, S, n):
         nbytes = L.odpl_head_conv_backward_multi_workspace_bytes(k, Hg, Sg)
-        if nbytes == 0:
+        if nbytes == 0:                 # cannot happen after structured_backward_supported() said yes in forward
             raise _lib.OdplError("odpl_head_conv_backward_multi_workspace_bytes rejected the descriptors")
         ws_buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         _lib.check(L.odpl_head_conv_backward_multi(k, Hg, Sg, _lib.ptr(ws_buf), ws_buf.numel(), _lib.current_stream(dev)),

@@ -22,8 +22,10 @@
 //             17 % (tools/probe_copy.hip: 6.08 vs 5.09 TB/s at this size), and the next backward convolution reads dX
 //   finish  : (a) 64 x 4-lane groups per workgroup reduce the partials of the dense channels in a fixed order;
 //             (b) one workgroup per other output channel: the matched rows of its anchor are compacted into LDS in row
-//             order, then summed four X rows at a time; (c) one workgroup per matched cell-row for the dX correction (rows
-//             that share a cell-row are applied by the first of them, in row order)
+//             order, then summed four X rows at a time; (c) one workgroup per matched cell-row REWRITES that dX row: the dense
+//             part again (the stream kernel's arithmetic) + the matched part, summed in fp32 and stored once, so a bf16 dX is
+//             rounded once (rows that share a cell-row are applied by the first of them, in row order).
+//             (b) and (c) walk row lists longer than the LDS lists (4096 rows) in chunks: no limit on the number of rows
 // Bitwise reproducible run to run.
 #include "odpl_common.hpp"
 #include "odpl_profile.hpp"
@@ -34,7 +36,7 @@ using namespace odpl;
 
 constexpr int kThreads = 256;
 constexpr int kMaxA = 5;
-constexpr int kMaxRows = 4096;          // matched rows per head the finish kernel stages in LDS
+constexpr int kRowChunk = 4096;         // matched rows the finish kernel stages in LDS at a time (longer row lists are walked in chunks)
 int g_rows_per_tile = 32;              // rows of X per workgroup (measured best at config 2: 28.2 us; 0 = auto: one resident wave of workgroups, 29.8 us)
 
 struct Head {
@@ -49,7 +51,7 @@ struct Head {
     int fc_blk0, fc_nblk;                 // finish: one block per other output channel
     int fr_blk0, fr_nblk;                 // finish: one block per matched row
 };
-struct Multi { Head h[ODPL_MAX_SCALES]; int n, cap; };      // cap: LDS row-list capacity of the finish kernel (>= every n_rows)
+struct Multi { Head h[ODPL_MAX_SCALES]; int n, cap; };      // cap: LDS row-list capacity of the finish kernel (rows per chunk)
 
 template <bool BF> struct Vec { static constexpr int N = BF ? 8 : 4; float v[BF ? 8 : 4]; };
 
@@ -219,16 +221,16 @@ __global__ __launch_bounds__(kThreads) void headgrad_stream_kernel(const Multi M
     }
 }
 
-// ordered compaction of the rows t in [0, n_rows) that satisfy `pred(t, n, a)` into LDS lists (ascending t);
-// returns the count (same in every thread).  s_wave: kThreads/64 ints of scratch.
+// ordered compaction of the rows t in [t_begin, t_end) that satisfy `pred(t, n, a)` into LDS lists (ascending t);
+// returns the count (same in every thread).  t_end - t_begin <= cap.  s_wave: kThreads/64 ints of scratch.
 template <typename Pred>
-__device__ __forceinline__ int compact_rows(const Head& P, int cap, Pred pred, int* l_t, int* l_n, int* s_wave) {
+__device__ __forceinline__ int compact_rows(const Head& P, int cap, Pred pred, int* l_t, int* l_n, int* s_wave, int t_begin, int t_end) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int base = 0;
-    for (int t0 = 0; t0 < P.n_rows; t0 += kThreads) {
+    for (int t0 = t_begin; t0 < t_end; t0 += kThreads) {
         const int t = t0 + tid;
         int n = -1, a = 0;
-        if (t < P.n_rows) cell_decode(P, P.row_cell[t], n, a);
+        if (t < t_end) cell_decode(P, P.row_cell[t], n, a);
         const bool keep = n >= 0 && pred(t, n, a);
         const unsigned long long m = __ballot(keep);
         if (lane == 0) s_wave[wv] = __popcll(m);
@@ -315,50 +317,48 @@ __global__ __launch_bounds__(kThreads) void headgrad_finish_kernel(const Multi M
     float* l_g = reinterpret_cast<float*>(l_n + cap);       // [cap] (channel blocks) / [no] (row blocks); cap >= no
     float* s_red = l_g + cap;                               // [kThreads * E]
     if (bid < P.fc_blk0 + P.fc_nblk) {
-        // ---- (b) the other output channels: ch = a*no + c, c != dc; sum over the matched rows of anchor a
+        // ---- (b) the other output channels: ch = a*no + c, c != dc; sum over the matched rows of anchor a.  The row list is
+        //          walked in chunks of `cap` rows (the LDS lists): any number of rows, ascending row order within a thread group
         const int idx = bid - P.fc_blk0;
         const int a = idx / (P.no - 1);
         int c = idx - a * (P.no - 1); if (c >= P.dc) ++c;
         const int ch = a * P.no + c;
-        const int cnt = compact_rows(P, cap, [&](int, int, int ta) { return ta == a; }, l_t, l_n, s_wave);
-        float bs = 0.f;
-        for (int i = tid; i < cnt; i += kThreads) { const float g = P.gr[(size_t)l_t[i] * P.no + c] * f; l_g[i] = g; bs += g; }
-        __syncthreads();
-        if (P.gb) {
-            bs = wave_sum(bs);
-            if ((tid & 63) == 0) s_sum[tid >> 6] = bs;
-            __syncthreads();
-            if (tid == 0) { float v = s_sum[0]; for (int k = 1; k < kThreads / 64; ++k) v += s_sum[k]; P.gb[ch] = v; }
-        }
-        if (!P.gw) return;
         int tpc = 1; while (tpc < P.cv && tpc < kThreads) tpc <<= 1;      // threads along Cin
         const int groups = kThreads / tpc, lane_c = tid & (tpc - 1), grp = tid / tpc;
+        float bs = 0.f;
         for (int q0 = 0; q0 < P.cv; q0 += tpc) {
             const int q = q0 + lane_c;
             Vec<BF> s;
 #pragma unroll
             for (int e = 0; e < E; ++e) s.v[e] = 0.f;
-            if (q < P.cv) {
-                int i = grp;
-                for (; i + 3 * groups < cnt; i += 4 * groups) {           // four X rows in flight
-                    Vec<BF> xv[4];
+            for (int c0 = 0; c0 < P.n_rows; c0 += cap) {
+                const int c1 = c0 + cap < P.n_rows ? c0 + cap : P.n_rows;
+                const int cnt = compact_rows(P, cap, [&](int, int, int ta) { return ta == a; }, l_t, l_n, s_wave, c0, c1);
+                for (int i = tid; i < cnt; i += kThreads) { const float g = P.gr[(size_t)l_t[i] * P.no + c] * f; l_g[i] = g; if (q0 == 0) bs += g; }
+                __syncthreads();
+                if (P.gw && q < P.cv) {
+                    int i = grp;
+                    for (; i + 3 * groups < cnt; i += 4 * groups) {       // four X rows in flight
+                        Vec<BF> xv[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) xv[u] = ldv<BF>(P.x, (size_t)l_n[i + u * groups] * P.cv + q);
+                        for (int u = 0; u < 4; ++u) xv[u] = ldv<BF>(P.x, (size_t)l_n[i + u * groups] * P.cv + q);
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const float g = l_g[i + u * groups];
+                        for (int u = 0; u < 4; ++u) {
+                            const float g = l_g[i + u * groups];
 #pragma unroll
-                        for (int e = 0; e < E; ++e) s.v[e] += g * xv[u].v[e];
+                            for (int e = 0; e < E; ++e) s.v[e] += g * xv[u].v[e];
+                        }
+                    }
+                    for (; i < cnt; i += groups) {
+                        const Vec<BF> xv = ldv<BF>(P.x, (size_t)l_n[i] * P.cv + q);
+                        const float g = l_g[i];
+#pragma unroll
+                        for (int e = 0; e < E; ++e) s.v[e] += g * xv.v[e];
                     }
                 }
-                for (; i < cnt; i += groups) {
-                    const Vec<BF> xv = ldv<BF>(P.x, (size_t)l_n[i] * P.cv + q);
-                    const float g = l_g[i];
-#pragma unroll
-                    for (int e = 0; e < E; ++e) s.v[e] += g * xv.v[e];
-                }
+                __syncthreads();                                          // the next chunk overwrites the lists
             }
-            __syncthreads();
+            if (!P.gw) break;
 #pragma unroll
             for (int e = 0; e < E; ++e) s_red[(grp * E + e) * tpc + lane_c] = s.v[e];
             __syncthreads();
@@ -372,18 +372,25 @@ __global__ __launch_bounds__(kThreads) void headgrad_finish_kernel(const Multi M
                 }
                 stf<BF>(P.gw + (size_t)ch * P.Cin, q, r);
             }
+            __syncthreads();
+        }
+        if (P.gb) {
+            bs = wave_sum(bs);
+            if ((tid & 63) == 0) s_sum[tid >> 6] = bs;
+            __syncthreads();
+            if (tid == 0) { float v = s_sum[0]; for (int k = 1; k < kThreads / 64; ++k) v += s_sum[k]; P.gb[ch] = v; }
         }
         return;
     }
-    // ---- (c) dX correction of the matched cell-rows: one workgroup per row t0; the FIRST row of a cell-row n applies every
-    //          row at n, in row order (several anchors of one cell, or YOLOv5's repeated rows, must not race)
+    // ---- (c) dX of the matched cell-rows: one workgroup per row t0; the FIRST row of a cell-row n applies every row at n, in row
+    //          order (several anchors of one cell, or YOLOv5's repeated rows, must not race).  The row is REWRITTEN, not
+    //          corrected: dense part (the stream kernel's arithmetic, same order) + matched part summed in fp32, one store -- a
+    //          bf16 dX is rounded once.
     if (!P.gx) return;
     const int t0 = bid - P.fr_blk0;
     if (t0 >= P.n_rows) return;
     int n0, a0; cell_decode(P, P.row_cell[t0], n0, a0);
     if (n0 < 0) return;                                                   // uniform
-    const int cnt = compact_rows(P, cap, [&](int, int n, int) { return n == n0; }, l_t, l_n, s_wave);
-    if (cnt == 0 || l_t[0] != t0) return;                                 // a lower row owns this cell-row
     int tpc = 1; while (tpc < P.cv && tpc < kThreads) tpc <<= 1;          // threads along Cin; the other thread groups split the channels
     const int groups = kThreads / tpc, lane_c = tid & (tpc - 1), grp = tid / tpc;
     for (int q0 = 0; q0 < P.cv; q0 += tpc) {
@@ -391,36 +398,53 @@ __global__ __launch_bounds__(kThreads) void headgrad_finish_kernel(const Multi M
         Vec<BF> s;
 #pragma unroll
         for (int e = 0; e < E; ++e) s.v[e] = 0.f;
-        for (int i = 0; i < cnt; ++i) {
-            const int t = l_t[i];
-            int n, a; cell_decode(P, P.row_cell[t], n, a);
-            __syncthreads();
-            for (int c = tid; c < P.no; c += kThreads) l_g[c] = c == P.dc ? 0.f : P.gr[(size_t)t * P.no + c] * f;
-            __syncthreads();
-            if (q < P.cv) {
-                const float* wb = P.w + (size_t)a * P.no * P.Cin;
-                int c = grp;
-                for (; c + 3 * groups < P.no; c += 4 * groups) {          // four weight rows in flight (slot dc carries 0)
-                    const Vec<BF> w0 = ldf<BF>(wb + (size_t)c * P.Cin, q), w1 = ldf<BF>(wb + (size_t)(c + groups) * P.Cin, q),
-                                  w2 = ldf<BF>(wb + (size_t)(c + 2 * groups) * P.Cin, q), w3 = ldf<BF>(wb + (size_t)(c + 3 * groups) * P.Cin, q);
-                    const float g0 = l_g[c], g1 = l_g[c + groups], g2 = l_g[c + 2 * groups], g3 = l_g[c + 3 * groups];
+        bool first = true;
+        for (int c0 = 0; c0 < P.n_rows; c0 += cap) {
+            const int c1 = c0 + cap < P.n_rows ? c0 + cap : P.n_rows;
+            const int cnt = compact_rows(P, cap, [&](int, int n, int) { return n == n0; }, l_t, l_n, s_wave, c0, c1);
+            if (cnt == 0) continue;                                           // uniform (the lists are in LDS)
+            if (first && l_t[0] != t0) return;                                // a lower row owns this cell-row
+            first = false;
+            for (int i = 0; i < cnt; ++i) {
+                const int t = l_t[i];
+                int n, a; cell_decode(P, P.row_cell[t], n, a);
+                __syncthreads();
+                for (int c = tid; c < P.no; c += kThreads) l_g[c] = c == P.dc ? 0.f : P.gr[(size_t)t * P.no + c] * f;
+                __syncthreads();
+                if (q < P.cv) {
+                    const float* wb = P.w + (size_t)a * P.no * P.Cin;
+                    int c = grp;
+                    for (; c + 3 * groups < P.no; c += 4 * groups) {          // four weight rows in flight (slot dc carries 0)
+                        const Vec<BF> w0 = ldf<BF>(wb + (size_t)c * P.Cin, q), w1 = ldf<BF>(wb + (size_t)(c + groups) * P.Cin, q),
+                                      w2 = ldf<BF>(wb + (size_t)(c + 2 * groups) * P.Cin, q), w3 = ldf<BF>(wb + (size_t)(c + 3 * groups) * P.Cin, q);
+                        const float g0 = l_g[c], g1 = l_g[c + groups], g2 = l_g[c + 2 * groups], g3 = l_g[c + 3 * groups];
 #pragma unroll
-                    for (int e = 0; e < E; ++e) s.v[e] += g0 * w0.v[e] + g1 * w1.v[e] + g2 * w2.v[e] + g3 * w3.v[e];
-                }
-                for (; c < P.no; c += groups) {
-                    const Vec<BF> w0 = ldf<BF>(wb + (size_t)c * P.Cin, q);
-                    const float g0 = l_g[c];
+                        for (int e = 0; e < E; ++e) s.v[e] += g0 * w0.v[e] + g1 * w1.v[e] + g2 * w2.v[e] + g3 * w3.v[e];
+                    }
+                    for (; c < P.no; c += groups) {
+                        const Vec<BF> w0 = ldf<BF>(wb + (size_t)c * P.Cin, q);
+                        const float g0 = l_g[c];
 #pragma unroll
-                    for (int e = 0; e < E; ++e) s.v[e] += g0 * w0.v[e];
+                        for (int e = 0; e < E; ++e) s.v[e] += g0 * w0.v[e];
+                    }
                 }
             }
+            __syncthreads();                                                  // the next chunk overwrites the lists
         }
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < E; ++e) s_red[(grp * E + e) * tpc + lane_c] = s.v[e];
         __syncthreads();
         if (grp == 0 && q < P.cv) {
-            Vec<BF> r = ldv<BF>(P.gx, (size_t)n0 * P.cv + q);
+            Vec<BF> r;                                                        // the dense part, as headgrad_stream_kernel computes it
+#pragma unroll
+            for (int e = 0; e < E; ++e) r.v[e] = 0.f;
+            for (int a = 0; a < P.A; ++a) {
+                const float ga = P.gd[gd_index(P, n0, a)] * f;
+                const Vec<BF> wv = ldf<BF>(P.w + (size_t)(a * P.no + P.dc) * P.Cin, q);
+#pragma unroll
+                for (int e = 0; e < E; ++e) r.v[e] = fmaf(ga, wv.v[e], r.v[e]);
+            }
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 float t = s_red[e * tpc + lane_c];
@@ -429,6 +453,7 @@ __global__ __launch_bounds__(kThreads) void headgrad_finish_kernel(const Multi M
             }
             stv<BF, false>(P.gx, (size_t)n0 * P.cv + q, r);
         }
+        __syncthreads();
     }
 }
 
@@ -441,7 +466,7 @@ bool plan_one(const odpl_head_conv_t* h, const odpl_sparse_grad_t* g, int rows_p
     const int E = h->bf16 ? 8 : 4;
     if (h->Cin < E || h->Cin % E != 0) return false;
     if (g->B < 1 || g->G2 < 1 || g->A < 1 || g->A > kMaxA || g->no < 2 || g->dense_ch < 0 || g->dense_ch >= g->no) return false;
-    if (g->n_rows < 0 || g->n_rows > kMaxRows) return false;
+    if (g->n_rows < 0 || g->no > kRowChunk) return false;          // any number of rows (chunked); the LDS lists also hold one row's `no` values
     if (g->layout != ODPL_LAYOUT_PLANAR && g->layout != ODPL_LAYOUT_INTERLEAVED) return false;
     if (!g->dense || (g->n_rows > 0 && (!g->rows || !g->row_cell))) return false;
     const long long N = (long long)g->B * g->G2;
@@ -548,11 +573,12 @@ extern "C" int odpl_head_conv_backward_multi(int32_t n, const odpl_head_conv_t* 
         P.st_blk0 = nst; P.st_nblk = pl.ntiles * pl.ncs; nst += P.st_nblk;
         if (pl.lds_stream > lds_stream) lds_stream = pl.lds_stream;
     }
-    int nfin = 0, cap = 256;                 // >= every no (<= 256 channels per anchor) and every n_rows
+    int nfin = 0, cap = 256;                 // LDS row-list capacity: >= every no, and every n_rows up to kRowChunk (longer lists: chunks)
     for (int k = 0; k < n; ++k) {
         Head& P = M.h[k];
         if (P.n_rows > cap) cap = (P.n_rows + 63) / 64 * 64;
         if (P.no > cap) cap = (P.no + 63) / 64 * 64;
+        if (cap > kRowChunk) cap = kRowChunk;
         P.fd_vg = (P.cq + 3) / 4;
         P.fd_blk0 = nfin; P.fd_nblk = P.A * P.fd_vg; nfin += P.fd_nblk;
         P.fc_blk0 = nfin; P.fc_nblk = (P.gw || P.gb) ? P.A * (P.no - 1) : 0; nfin += P.fc_nblk;

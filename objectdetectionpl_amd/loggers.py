@@ -65,8 +65,20 @@ class ScalarWriter:
             self._f = None
 
 
+class _NoWriter:
+    """PL's DummyExperiment: what `logger.experiment` is on every rank but 0 -- accepts any SummaryWriter call, writes nothing."""
+
+    def __getattr__(self, _name):
+        return lambda *a, **k: None
+
+
+def _rank_zero():
+    return int(os.environ.get("RANK", os.environ.get("LOCAL_RANK", "0")) or 0) == 0
+
+
 class TensorBoardLogger:
-    """`TensorBoardLogger(save_dir, name=..., version=None, default_hp_metric=False)` (run.py:86)."""
+    """`TensorBoardLogger(save_dir, name=..., version=None, default_hp_metric=False)` (run.py:86).  Only rank 0 writes (PL's
+    `rank_zero_experiment`): on the other ranks of a data-parallel job `experiment` is a sink and no `version_k` directory is made."""
 
     def __init__(self, save_dir, name="default", version=None, default_hp_metric=True, **_):
         self.save_dir, self.name = save_dir, name or ""
@@ -95,6 +107,8 @@ class TensorBoardLogger:
 
     @property
     def experiment(self):
+        if not _rank_zero():
+            return _NoWriter()
         if self._experiment is None:
             self._experiment = ScalarWriter(self.log_dir)
         return self._experiment

@@ -8,12 +8,18 @@ does the same) and becomes rank 0.  Gradients are averaged by `parallel.wrap_dat
 overlapped with backward); buffers are re-broadcast from rank 0 before every synchronising forward (DDP's
 `broadcast_buffers=True`, PL's default); micro-steps that do not end in an optimiser step run under `no_sync`;
 `val_loss` is averaged over the ranks before the scheduler, checkpoint and early-stopping decisions, so every rank takes the
-same ones.  Not re-implemented: PL's profiler, precision plugins, multi-optimizer loops."""
+same ones.  A `torch.utils.data.DataLoader` is re-built around a `DistributedSampler` (PL's `replace_sampler_ddp=True`:
+disjoint shards, `set_epoch` per epoch); validation runs on the bare module after ONE buffer broadcast per validation phase, so
+ranks with different numbers of validation batches cannot meet in mismatched collectives; only rank 0 writes logs and
+checkpoints; the ranks this process started are supervised (one of them dying takes the job down, promptly, non-zero).
+Not re-implemented: PL's profiler, precision plugins, multi-optimizer loops."""
 import contextlib
 import inspect
 import os
 import subprocess
 import sys
+import threading
+import time
 
 import torch
 
@@ -80,7 +86,7 @@ class Trainer:
         self.checkpoint_callback = next((c for c in self.callbacks if hasattr(c, "best_model_path")), None)
         self.callback_metrics, self.optimizers, self.lr_schedulers = {}, [], []
         self.current_epoch, self.global_step, self.should_stop, self.running_sanity_check = 0, 0, False, False
-        self._children = []
+        self._children, self._crashed, self._watch_done, self._own_group = [], False, False, False
 
     # -- construction from the flattened yaml Namespace (run.py:26-39, 109) ---------------------------------------------
     @classmethod
@@ -111,14 +117,74 @@ class Trainer:
         self.world, self.rank, self.local_rank = n, 0, 0
         import atexit
         atexit.register(self._reap)
+        # an exception that ends this process must not leave the children waiting in a collective for ten minutes each
+        prev_hook = sys.excepthook
 
-    def _reap(self):
+        def hook(tp, val, tb):
+            self._crashed = True
+            prev_hook(tp, val, tb)
+        sys.excepthook = hook
+        self._watcher = threading.Thread(target=self._watch_children, name="odpl-rank-watcher", daemon=True)
+        self._watcher.start()
+
+    def _stop_children(self, grace):
+        """terminate exactly the processes this trainer started; one shared deadline, then kill"""
+        for p in self._children:
+            if p.poll() is None:
+                p.terminate()
+        deadline = time.monotonic() + grace
         for p in self._children:
             try:
-                p.wait(timeout=600)
+                p.wait(timeout=max(0.0, deadline - time.monotonic()))
             except subprocess.TimeoutExpired:
                 p.kill()
+                p.wait()
+
+    def _watch_children(self):
+        """bench.py's launcher policy: a rank that exits non-zero takes the job down -- its peers (this process included) would
+        otherwise wait in the next all_reduce / broadcast for ever.  Runs on a daemon thread; the main thread may be inside a
+        collective, so the job ends through os._exit with the child's code."""
+        while not self._watch_done:
+            for r, p in enumerate(self._children, start=1):
+                rc = p.poll()
+                if rc not in (None, 0):
+                    print(f"[trainer] rank {r} exited with code {rc}; stopping the other ranks", file=sys.stderr, flush=True)
+                    self._watch_done = True
+                    self._stop_children(10.0)
+                    sys.stdout.flush()
+                    os._exit(rc if rc > 0 else 1)
+            if all(p.poll() is not None for p in self._children):
+                return
+            time.sleep(0.2)
+
+    def _reap(self):
+        """atexit of rank 0: after a clean run the children are finishing too (shared deadline of two minutes); after a crash
+        they are stuck in a collective: stop them at once.  A child that failed makes this process exit non-zero."""
+        self._watch_done = True
+        if self._crashed:
+            self._stop_children(10.0)
+        else:
+            deadline = time.monotonic() + 120.0
+            for p in self._children:
+                try:
+                    p.wait(timeout=max(0.0, deadline - time.monotonic()))
+                except subprocess.TimeoutExpired:
+                    pass
+            self._stop_children(10.0)
+        bad = [p.returncode for p in self._children if p.returncode not in (0, None)]
         self._children = []
+        self._teardown_group()
+        if bad and not self._crashed:
+            sys.stdout.flush()
+            os._exit(bad[0] if bad[0] > 0 else 1)
+
+    def _teardown_group(self):
+        if self._own_group and torch.distributed.is_available() and torch.distributed.is_initialized():
+            try:
+                torch.distributed.destroy_process_group()
+            except Exception:  # noqa: BLE001
+                pass
+        self._own_group = False
 
     # -- helpers ------------------------------------------------------------------------------------------------------------
     def _limit(self, loader, kind):
@@ -180,12 +246,42 @@ class Trainer:
         return self.optimizers[0]
 
     def _mean_over_ranks(self, t):
-        """mean of a scalar over the data-parallel ranks (every rank then decides on the same number)."""
+        """mean of a scalar over the data-parallel ranks that have one (`t` None: this rank saw no validation batch) -- EVERY rank
+        calls this once per validation phase, so the collective always matches; None when no rank had a value."""
         if self.world > 1 and torch.distributed.is_initialized():
-            t = t.detach().clone().float()
-            torch.distributed.all_reduce(t)
-            t /= self.world
+            dev = self.device
+            v = torch.zeros(2, dtype=torch.float32, device=dev)
+            if t is not None:
+                v[0], v[1] = t.detach().float().to(dev), 1.0
+            torch.distributed.all_reduce(v)
+            return (v[0] / v[1]) if float(v[1]) > 0 else None
         return t
+
+    def _loader(self, loader, epoch=0):
+        """PL's `replace_sampler_ddp=True`: with more than one rank a `torch.utils.data.DataLoader` that has no distributed
+        sampler is re-built around `DistributedSampler(dataset, world, rank, shuffle=<it was shuffling>)` -- disjoint index
+        shards, every rank the same number of batches -- and told the epoch (the shuffle differs per epoch, identically on
+        every rank).  Anything else (generators, lists, loaders with a custom batch_sampler, the synthetic module that seeds by
+        rank) is used as it is."""
+        from torch.utils.data import BatchSampler, DataLoader, RandomSampler, SequentialSampler
+        from torch.utils.data.distributed import DistributedSampler
+        if self.world <= 1 or not isinstance(loader, DataLoader):
+            return loader
+        if isinstance(loader.sampler, DistributedSampler):
+            loader.sampler.set_epoch(epoch)
+            return loader
+        if type(loader.batch_sampler) is not BatchSampler or not isinstance(loader.sampler, (RandomSampler, SequentialSampler)):
+            return loader
+        sampler = DistributedSampler(loader.dataset, num_replicas=self.world, rank=self.rank,
+                                     shuffle=isinstance(loader.sampler, RandomSampler), drop_last=False)
+        sampler.set_epoch(epoch)
+        kw = dict(batch_size=loader.batch_size, sampler=sampler, num_workers=loader.num_workers, collate_fn=loader.collate_fn,
+                  pin_memory=loader.pin_memory, drop_last=loader.drop_last, timeout=loader.timeout,
+                  worker_init_fn=loader.worker_init_fn, generator=loader.generator)
+        if loader.num_workers > 0:
+            kw.update(prefetch_factor=loader.prefetch_factor, persistent_workers=loader.persistent_workers,
+                      multiprocessing_context=loader.multiprocessing_context)
+        return DataLoader(loader.dataset, **kw)
 
     def _call(self, hook, *a):
         for c in self.callbacks:
@@ -210,10 +306,15 @@ class Trainer:
             except AttributeError:
                 pass
 
-    def _validate(self, model, vstep, datamodule, max_batches=None):
+    def _validate(self, model, vstep, datamodule, max_batches=None, net=None):
+        """validation_step over the rank's shard on the BARE module.  Under DDP every forward re-broadcasts the buffers; here
+        rank 0's BatchNorm statistics are broadcast ONCE per validation phase (every rank gets here exactly once, whatever the
+        number of batches its shard holds) and the forwards run no collective at all."""
         model.eval()
+        if net is not None and net is not model and hasattr(net, "sync_buffers"):
+            net.sync_buffers()
         vouts = []
-        for i, b, _last in self._take(datamodule.val_dataloader(), "val"):
+        for i, b, _last in self._take(self._loader(datamodule.val_dataloader(), self.current_epoch), "val"):
             if max_batches is not None and i >= max_batches:
                 break
             vouts.append(vstep(b, i))
@@ -226,7 +327,10 @@ class Trainer:
         if self.requested_world > 1 and "RANK" not in os.environ:
             self._launch_ranks()
         if self.world > 1:
+            self._own_group = not torch.distributed.is_initialized()
             parallel.init_process_group_from_env(self.device)
+            if self.rank != 0:
+                self.logger = None            # PL logs from rank 0 only (the model's `logger.experiment` is a no-op there too)
         if hasattr(datamodule, "setup"):
             datamodule.setup("fit")
         model.to(self.device).train()
@@ -234,9 +338,9 @@ class Trainer:
         if net is not model:                                              # forward goes through the wrapper (gradient hooks, buffer broadcast)
             via = _ForwardVia(model, net)
             tstep = lambda b, i: type(model).training_step(via, b, i)      # noqa: E731
-            vstep = lambda b, i: type(model).validation_step(via, b, i)    # noqa: E731
         else:
-            tstep, vstep = model.training_step, model.validation_step
+            tstep = model.training_step
+        vstep = model.validation_step                                     # the bare module: no collective inside a validation forward
         opt = self._setup_optimizers(model)
         self._attach(model)
         history = []
@@ -245,7 +349,7 @@ class Trainer:
         if self.num_sanity_val_steps > 0:
             self.running_sanity_check = True
             with torch.no_grad():
-                self._validate(model, vstep, datamodule, self.num_sanity_val_steps)
+                self._validate(model, vstep, datamodule, self.num_sanity_val_steps, net)
             self.running_sanity_check = False
         for epoch in range(self.max_epochs):
             self.current_epoch = epoch
@@ -254,7 +358,7 @@ class Trainer:
             self._call("on_train_epoch_start", model)
             outs = []
             pending = 0                                                   # micro-batches since the last optimiser step
-            for i, batch, is_last in self._take(datamodule.train_dataloader(), "train"):
+            for i, batch, is_last in self._take(self._loader(datamodule.train_dataloader(), epoch), "train"):
                 steps_now = (i + 1) % self.accumulate == 0 or is_last      # PL also steps on the last batch of the epoch
                 sync = contextlib.nullcontext() if steps_now or not hasattr(net, "no_sync") else net.no_sync()
                 with sync:
@@ -273,9 +377,10 @@ class Trainer:
                 history.append(("train", epoch, model.training_epoch_end(outs)))
             self._call("on_train_epoch_end", model, outs)
             with torch.no_grad():
-                vouts = self._validate(model, vstep, datamodule)
-            if vouts:
-                val_loss = self._mean_over_ranks(torch.stack([o["loss"].detach().float() for o in vouts]).mean())
+                vouts = self._validate(model, vstep, datamodule, None, net)
+            val_loss = self._mean_over_ranks(torch.stack([o["loss"].detach().float() for o in vouts]).mean() if vouts else None)
+            have_val = val_loss is not None                                # the same on every rank
+            if have_val:
                 self.callback_metrics["val_loss"] = val_loss
                 for k, v in getattr(model, "_logged_metrics", {}).items():
                     if k != "val_loss":
@@ -289,10 +394,10 @@ class Trainer:
                         sch.step(float(self.callback_metrics[d["monitor"]]))
                 else:
                     sch.step()
-            if vouts:
+            if have_val:
                 self._call("on_validation_end", model)                     # ModelCheckpoint / EarlyStopping read callback_metrics
-                if hasattr(model, "validation_epoch_end"):
-                    history.append(("val", epoch, model.validation_epoch_end(vouts)))
+            if vouts and hasattr(model, "validation_epoch_end"):
+                history.append(("val", epoch, model.validation_epoch_end(vouts)))
             if self.should_stop and epoch + 1 >= self.min_epochs:
                 break
         self._call("on_fit_end", model)
@@ -300,6 +405,9 @@ class Trainer:
             self.logger.save()
         if net is not model and hasattr(net, "averager"):
             net.averager.remove()
+        if self.world > 1 and torch.distributed.is_initialized():
+            torch.distributed.barrier()                                    # every rank has finished before the group goes
+        self._teardown_group()
         return history
 
     # -- test ---------------------------------------------------------------------------------------------------------------

@@ -313,3 +313,165 @@ def test_structured_backward_under_the_rccl_gradient_averager():
         net.averager.remove()
     finally:
         dist.destroy_process_group()
+
+
+# ---- the structured route's limits (no route may raise in the middle of loss.backward()) -----------------------
+
+@pytest.mark.parametrize("layout", [0, 1])
+def test_c_abi_head_conv_backward_row_list_longer_than_one_lds_chunk(layout):
+    """9 500 rows on a 13 x 13 x 2 map: the finish launch walks the list in chunks of 4 096; cell-rows are shared by dozens of
+    rows spread over different chunks (the first of them rewrites the dX row, in row order); against float64 dense math."""
+    from objectdetectionpl_amd import _lib
+    g = torch.Generator().manual_seed(77)
+    A, no, Cin, G, nrows, B, dc = 3, 11, 96, 13, 9500, 2, 4
+    G2 = G * G
+    N = B * G2
+    x = torch.randn(N, Cin, generator=g)
+    w = torch.randn(A * no, Cin, generator=g) * 0.1
+    gd = torch.randn(B * A * G2, generator=g)
+    gr = torch.randn(nrows, no, generator=g) * 0.1
+    cells = torch.randint(0, B * A * G2, (nrows,), generator=g, dtype=torch.int32)
+    cells[::7] = -1                                     # unused row slots anywhere in the list
+    dense = _dense_from_sparse(gd, gr, cells, B, G2, A, no, dc, layout)
+    xd = x.double().view(B, G2, Cin)
+    ref_gx = torch.einsum("bos,oc->bsc", dense, w.double()).reshape(N, Cin)
+    ref_gw = torch.einsum("bos,bsc->oc", dense, xd)
+    ref_gb = dense.sum((0, 2))
+    L = _lib.lib()
+    t = {k: v.to(DEV) for k, v in dict(x=x, w=w, gd=gd, gr=gr, cells=cells).items()}
+    outs = []
+    for _ in range(2):
+        gx, gw, gb = torch.empty_like(t["x"]), torch.empty_like(t["w"]), torch.empty(A * no, device=DEV)
+        sg = _lib.SparseGrad(dense=t["gd"].data_ptr(), rows=t["gr"].data_ptr(), row_cell=t["cells"].data_ptr(), n_rows=nrows,
+                             B=B, G2=G2, A=A, no=no, dense_ch=dc, layout=layout)
+        h = _lib.HeadConv(x=t["x"].data_ptr(), w=t["w"].data_ptr(), grad_x=gx.data_ptr(), grad_w=gw.data_ptr(), grad_b=gb.data_ptr(),
+                          upstream=None, Cin=Cin, bf16=0)
+        nb = L.odpl_head_conv_backward_workspace_bytes(ctypes.byref(h), ctypes.byref(sg))
+        assert nb > 0
+        ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+        _lib.check(L.odpl_head_conv_backward(ctypes.byref(h), ctypes.byref(sg), _lib.ptr(ws), nb, _lib.current_stream(torch.device(DEV))), "head")
+        torch.cuda.synchronize()
+        outs.append((gx, gw, gb))
+    _close(outs[0][0], ref_gx, 1e-4, 1e-5)
+    _close(outs[0][1], ref_gw, 1e-4, 1e-5)
+    _close(outs[0][2], ref_gb, 1e-4, 1e-5)
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)                        # chunked or not: bitwise reproducible
+
+
+def test_region_loss_with_more_targets_than_one_lds_chunk_stays_on_the_structured_route():
+    """nT = 4 400 > 4 096 rows per head (a crowded batch): still two launches, no dense tensor, same gradients as the dense route."""
+    from objectdetectionpl_amd import _lib
+    from objectdetectionpl_amd.LightningFunc.losses import MultiScaleRegionLoss_v4, _RegionLossBase
+    from objectdetectionpl_amd.LightningFunc.utils.headconv import HeadConv2d
+    g = torch.Generator().manual_seed(5)
+    C, B = 4, 4
+    cins, Gs, cout = (32, 64, 128), (52, 26, 13), 3 * (5 + C)
+    xs = [torch.randn(B, c, G, G, generator=g) * 0.5 for c, G in zip(cins, Gs)]
+    tgt = _targets(g, B, 1100, C)
+    torch.manual_seed(0)
+    net = _Heads(cins, cout, HeadConv2d).to(DEV)
+    crit = MultiScaleRegionLoss_v4(V4_ANCHORS, V4_MASKS, "bce_loss", "smooth_l1_loss", "bce_loss", C, 416)
+    res = []
+    for fused in (True, False):
+        _RegionLossBase.fuse_head_backward = fused
+        _lib.profile_enable("yolo_expand", True); _lib.profile_enable("headgrad_stream", True)
+        try:
+            net.zero_grad(set_to_none=True)
+            xd = [x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_() for x in xs]
+            out = crit(net(xd), tgt.to(DEV))
+            out["loss"].backward()
+        finally:
+            _RegionLossBase.fuse_head_backward = True
+            _lib.profile_enable("yolo_expand", False); _lib.profile_enable("headgrad_stream", False)
+        launches = (len(_lib.profile_collect("yolo_expand")[0]), len(_lib.profile_collect("headgrad_stream")[0]))
+        assert launches == ((0, 1) if fused else (1, 0))
+        res.append((out, [x.grad.clone() for x in xd], [p.grad.clone() for p in net.parameters()]))
+    (of, xf, pf), (od, xdn, pd) = res
+    for k in of:
+        assert of[k].item() == od[k].item()
+    for a, b in zip(xf + pf, xdn + pd):
+        _close(a, b, 1e-4, 1e-5)
+
+
+def test_region_loss_with_six_anchors_on_a_scale_takes_the_dense_route():
+    """The structured head backward serves at most 5 anchors per scale (ODPL_MAX_ANCHORS is 8).  A 6-anchor single-scale
+    RegionLoss_v2 on a HeadConv2d output must notice in FORWARD and hand autograd the dense gradient -- nothing raises in
+    backward -- and the gradients equal the CPU oracle's through F.conv2d."""
+    from objectdetectionpl_amd import _lib
+    from objectdetectionpl_amd.LightningFunc.losses import RegionLoss_v2
+    from objectdetectionpl_amd.LightningFunc.utils.headconv import HeadConv2d
+    g = torch.Generator().manual_seed(11)
+    C, B, G, Cin = 3, 2, 9, 32
+    anchors = [(1.0, 1.5), (2.0, 1.0), (3.0, 3.5), (4.5, 2.0), (6.0, 6.5), (8.0, 4.0)]
+    A = len(anchors)
+    x = torch.randn(B, Cin, G, G, generator=g) * 0.5
+    tgt = _targets(g, B, 4, C)
+    torch.manual_seed(0)
+    conv = HeadConv2d(Cin, A * (5 + C), 1)
+    xc = x.clone().requires_grad_()
+    ref = oracle_yolo.region_loss_v2(F.conv2d(xc, conv.weight, conv.bias), tgt, anchors, C, 288)
+    crit = RegionLoss_v2(anchors, "bce_loss", "smooth_l1_loss", "bce_loss", C, 288)
+    conv.to(DEV)
+    _lib.profile_enable("yolo_expand", True); _lib.profile_enable("headgrad_stream", True)
+    try:
+        xd = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_()
+        h = conv(xd)
+        assert hasattr(h, "_odpl_head_src")
+        out = crit(h, tgt.to(DEV))
+        out["loss"].backward()
+    finally:
+        _lib.profile_enable("yolo_expand", False); _lib.profile_enable("headgrad_stream", False)
+    assert (len(_lib.profile_collect("yolo_expand")[0]), len(_lib.profile_collect("headgrad_stream")[0])) == (1, 0)
+    # the dense route through the same hosted convolution against the plain F.conv2d graph on the device
+    conv2 = HeadConv2d(Cin, A * (5 + C), 1).to(DEV)
+    conv2.load_state_dict(conv.state_dict())
+    HeadConv2d.enabled = False
+    try:
+        xe = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_()
+        out2 = crit(conv2(xe), tgt.to(DEV))
+        out2["loss"].backward()
+    finally:
+        HeadConv2d.enabled = True
+    assert out["loss"].item() == out2["loss"].item()
+    _close(xd.grad, xe.grad, 1e-4, 1e-5)
+    for p1, p2 in zip(conv.parameters(), conv2.parameters()):
+        _close(p1.grad, p2.grad, 1e-4, 1e-5)
+    ref["loss"].backward()
+    assert abs(out["loss"].item() - ref["loss"].item()) <= 1e-4 * abs(ref["loss"].item()) + 1e-6
+    _close(xd.grad, xc.grad, 1e-4, 1e-5)
+
+
+def test_a_hook_or_an_inplace_edit_on_the_head_disables_the_shortcut():
+    """the structured route bypasses the head tensor's autograd node.  A tensor hook, retain_grad() or an in-place
+    edit of the head must therefore send the criterion down the ordinary route -- where hooks fire and the edit is differentiated."""
+    from objectdetectionpl_amd import _lib
+    from objectdetectionpl_amd.LightningFunc.losses import MultiScaleRegionLoss_v4
+    from objectdetectionpl_amd.LightningFunc.utils.headconv import HeadConv2d, fusable_source
+    g = torch.Generator().manual_seed(9)
+    C, B = 4, 2
+    cins, Gs, cout = (16, 32, 64), (52, 26, 13), 3 * (5 + C)
+    xs = [(torch.randn(B, c, G, G, generator=g) * 0.5).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_() for c, G in zip(cins, Gs)]
+    tgt = _targets(g, B, 3, C).to(DEV)
+    torch.manual_seed(0)
+    net = _Heads(cins, cout, HeadConv2d).to(DEV)
+    crit = MultiScaleRegionLoss_v4(V4_ANCHORS, V4_MASKS, "bce_loss", "smooth_l1_loss", "bce_loss", C, 416)
+    heads = net(xs)
+    assert all(fusable_source(h) is not None for h in heads)
+    seen = []
+    heads[1].register_hook(lambda gr_: seen.append(gr_.shape))
+    heads[2].retain_grad()
+    assert fusable_source(heads[1]) is None and fusable_source(heads[2]) is None and fusable_source(heads[0]) is not None
+    crit(heads, tgt)["loss"].backward()
+    assert seen == [heads[1].shape] and heads[2].grad is not None and heads[2].grad.shape == heads[2].shape
+    # in place: the head no longer holds the convolution's output
+    heads = net(xs)
+    heads[0].mul_(0.5)
+    assert fusable_source(heads[0]) is None
+    # and an in-place edit of a saved activation between forward and backward is an autograd error, not a silent wrong gradient
+    xs2 = [x.detach().clone().requires_grad_() for x in xs]
+    mids = [x * 1.0 for x in xs2]
+    loss = crit(net(mids), tgt)["loss"]
+    mids[0].mul_(2.0)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        loss.backward()

@@ -157,10 +157,12 @@ def test_v5_planar_view_heads_equal_contiguous_heads(dtype):
         assert torch.equal(h.grad, gv)                    # same arithmetic per element
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_v5_detect_convs_structured_backward(dtype):
+@pytest.mark.parametrize("dtype,per_image", [(torch.float32, 6), (torch.bfloat16, 6), (torch.float32, 80), (torch.bfloat16, 80)])
+def test_v5_detect_convs_structured_backward(dtype, per_image):
     """x -> Detect 1x1 convs (HeadConv2d) -> Yolo_Layers view -> criterion: the convolutions' backward from the compact
-    gradient equals the dense route (bf16: activations and their gradients in bf16, weights fp32)."""
+    gradient equals the dense route (bf16: activations and their gradients in bf16, weights fp32).  80 targets per image:
+    nT = 320 > 273, i.e. 15 * nT = 4 800 row slots per layer -- more than one LDS chunk of the finish launch (this
+    used to raise OdplError in the middle of loss.backward())."""
     import torch.nn as nn
     from objectdetectionpl_amd import _lib
     from objectdetectionpl_amd.LightningFunc.losses_dense import MultiScaleRegionLoss_v5
@@ -171,9 +173,9 @@ def test_v5_detect_convs_structured_backward(dtype):
     B, C = 4, 12
     cins, Gs = (64, 128, 256), (20, 10, 5)
     xs = [(torch.randn(B, c, G, G, generator=g) * 0.5).to(dtype) for c, G in zip(cins, Gs)]
-    n = B * 6
+    n = B * per_image
     wh = torch.rand(n, 2, generator=g) * 0.4 + 0.02
-    tgt = torch.cat([torch.arange(B).repeat_interleave(6).float()[:, None], torch.randint(0, C, (n, 1), generator=g).float(),
+    tgt = torch.cat([torch.arange(B).repeat_interleave(per_image).float()[:, None], torch.randint(0, C, (n, 1), generator=g).float(),
                      torch.rand(n, 2, generator=g) * 0.9 + 0.05, wh], 1).to(d)
     torch.manual_seed(1)
     convs = nn.ModuleList(HeadConv2d(c, 3 * (5 + C), 1) for c in cins).to(d)

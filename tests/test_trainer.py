@@ -17,9 +17,7 @@ def test_fit_world2_one_process_start_keeps_ranks_identical(tmp_path):
     """ADVICE r01 (high + medium): `Trainer.fit` at world 2 -- started as ONE process, which launches rank 1 itself -- trains
     with accumulation (last partial group stepped), averages gradients, re-broadcasts buffers, reduces val_loss over the ranks
     before the plateau scheduler: parameters, buffers and learning rates end identical on both ranks."""
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "_ddp_cpu_fit_script.py"), str(tmp_path)], env=env,
-                       capture_output=True, text=True, timeout=600)
+    r = _run_ddp_script(tmp_path, "gen")
     assert r.returncode == 0, r.stderr[-3000:]
     a = torch.load(tmp_path / "rank0.pt", weights_only=True)
     b = torch.load(tmp_path / "rank1.pt", weights_only=True)
@@ -29,6 +27,47 @@ def test_fit_world2_one_process_start_keeps_ranks_identical(tmp_path):
     assert a["val_loss"] == b["val_loss"]                            # the rank-averaged figure
     for k in a["params"]:
         assert torch.equal(a["params"][k], b["params"][k]), k        # weights AND BatchNorm buffers
+
+
+def _run_ddp_script(tmp_path, mode, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    return subprocess.run([sys.executable, os.path.join(REPO, "tests", "_ddp_cpu_fit_script.py"), str(tmp_path), mode], env=env,
+                          capture_output=True, text=True, timeout=timeout)
+
+
+def test_fit_world2_shards_a_dataloader_and_survives_uneven_validation(tmp_path):
+    """a datamodule that returns plain DataLoaders (run.py, dataset/Pascal.py) is sharded like PL's
+    `replace_sampler_ddp=True` -- the ranks' index sets are disjoint, together they cover the dataset, the shuffle changes with the
+    epoch; validation with a different number of batches per rank finishes (no collective inside a validation forward) and both
+    ranks decide on the same val_loss; only rank 0 writes logs; fit leaves no process group behind."""
+    r = _run_ddp_script(tmp_path, "loader")
+    assert r.returncode == 0, r.stderr[-3000:]
+    a = torch.load(tmp_path / "rank0.pt", weights_only=True)
+    b = torch.load(tmp_path / "rank1.pt", weights_only=True)
+    for ep in range(2):
+        sa, sb = set(a["seen"][ep]), set(b["seen"][ep])
+        assert len(a["seen"][ep]) == len(b["seen"][ep]) == 11              # 22 samples over two ranks
+        assert not (sa & sb) and (sa | sb) == set(range(22))
+    assert a["seen"][0] != a["seen"][1]                                    # set_epoch: another permutation in epoch 1
+    assert a["val_loss"] == b["val_loss"]
+    for k in a["params"]:
+        assert torch.equal(a["params"][k], b["params"][k]), k
+    assert not a["group_alive"] and not b["group_alive"]
+    versions = sorted(os.listdir(tmp_path / "tb" / "tiny"))
+    assert versions == ["version_0"]                                       # one writer
+    tags = [json.loads(l)["tag"] for l in open(tmp_path / "tb" / "tiny" / "version_0" / "scalars.jsonl")]
+    assert tags.count("val_loss") == 2 and tags.count("train_loss") == 2 * 3      # rank 0's three training batches per epoch, once
+
+
+def test_a_dying_rank_takes_the_job_down_promptly(tmp_path):
+    """rank 1 exits with code 7 before the rendezvous; rank 0 (the process the user started) must not wait
+    in a collective: the job ends non-zero within seconds and no child is left behind."""
+    import time
+    t0 = time.time()
+    r = _run_ddp_script(tmp_path, "fail", timeout=120)
+    assert r.returncode == 7, (r.returncode, r.stderr[-2000:])
+    assert time.time() - t0 < 60
+    assert "rank 1 exited with code 7" in r.stderr
 
 
 class _Tiny(nn.Module):
