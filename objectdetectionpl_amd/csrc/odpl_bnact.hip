@@ -14,8 +14,7 @@
 // concatenated tensor (row strides: the CSP merges write in place of torch.cat), bf16 activations (template BF: 8-byte
 // quads, fp32 arithmetic, one rounding), inference (statistics derived from the running buffers inside apply), and the
 // per-channel bias gradient of the linear head convs.
-#include "odpl_common.hpp"
-#include "../../include/odpl_hip.h"
+#include "odpl_bn_dev.hpp"
 
 namespace {
 using namespace odpl;
@@ -28,67 +27,6 @@ int g_bn_max_rows_per_tile = 2048;
 int g_bn_slice_from_c = 256;            // reduce passes cut the row into 16-quad channel slices from this many channels on
 }
 namespace {
-
-// Mish through ONE exponential: with n = e^z,  tanh(softplus(z)) = n(n+2) / (n(n+2) + 2)  and  sigmoid(z) = n / (1+n).
-// (ATen evaluates tanh(log1p(exp(z))): three transcendentals, which makes the epilogue VALU-bound instead of
-// HBM-bound.)  No cancellation: every term is positive; for z > 20 the ratio is 1 to fp32 precision.
-// Divisions by the hardware reciprocal (v_rcp_f32, 1 ulp; both divisors are >= 1): HIP's `__fdividef` is an IEEE division
-// here -- ten instructions (div_scale x2, rcp, four fma, div_fmas, div_fixup) -- and the backward kernels carry two per element,
-// which is what kept them on the VALU issue limit instead of the HBM one.
-__device__ __forceinline__ float div_rcp(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
-__device__ __forceinline__ float mish_t(float z, float& n) {
-    n = __expf(fminf(z, 20.0f));
-    const float p = n * (n + 2.0f);
-    return div_rcp(p, p + 2.0f);
-}
-// ACT is a template parameter of the streaming kernels: a run-time switch costs a scalar compare-and-branch per ELEMENT and cuts the
-// loop body into basic blocks the scheduler cannot interleave.
-template <int ACT>
-__device__ __forceinline__ float act_fwd(float z) {
-    constexpr int act = ACT;
-    if (act == ODPL_ACT_MISH) { float n; return z * mish_t(z, n); }            // x * tanh(softplus(x))
-    if (act == ODPL_ACT_LEAKY) return z > 0.f ? z : 0.1f * z;
-    if (act == ODPL_ACT_RELU) return z > 0.f ? z : 0.f;
-    return z;
-}
-template <int ACT>
-__device__ __forceinline__ float act_grad(float z) {
-    constexpr int act = ACT;
-    if (act == ODPL_ACT_MISH) {                                                 // ts + z * sigmoid(z) * (1 - ts^2)  (ATen mish_backward)
-        float n;
-        const float ts = mish_t(z, n);
-        const float sg = z > 20.0f ? 1.0f : div_rcp(n, 1.0f + n);
-        return ts + z * sg * (1.0f - ts * ts);
-    }
-    if (act == ODPL_ACT_LEAKY) return z > 0.f ? 1.0f : 0.1f;
-    if (act == ODPL_ACT_RELU) return z > 0.f ? 1.0f : 0.f;
-    return 1.0f;
-}
-
-struct BnParams {
-    const void* x; const void* gy; void* y; void* gx;  // activations / their gradients: fp32 or bf16 (template BF)
-    const float* gamma; const float* beta;
-    float* mean; float* invstd;                  // [C] batch statistics (saved for backward)
-    float* running_mean; float* running_var;     // [C] or null
-    const void* res;                             // optional residual added after the activation (same layout as y)
-    double* part;                                // [nblk][C][2]
-    float* dgamma; float* dbeta;                 // [C]
-    long long* num_batches_tracked;              // nn.BatchNorm2d buffer, +1 per training forward (or null)
-    long long R; int C, act, nblk, rows_per_blk, training;
-    int res_pre;                                 // residual added BEFORE the activation (ResNet: relu(bn(x) + s)) instead of after it
-    int slice_q;                                 // channel quads per workgroup of the reduce passes (grid.y slices of the row), or C/4
-    long long y_rs4, gy_rs4;                     // row strides of y / grad_y in float4 units (== C/4 when dense)
-    float eps, momentum;
-};
-
-// 16 bytes (fp32) / 8 bytes (bf16) of a channels-last row at a byte offset from a workgroup-uniform base: the compiler keeps
-// the base in scalar registers and the offset in ONE vector register (global_load ... v_off, s[base:base+1])
-template <bool BF>
-__device__ __forceinline__ float4 ld_quad_at(const char* base, unsigned byte_off) {
-    if (!BF) return *reinterpret_cast<const float4*>(base + byte_off);
-    const uint2 u = *reinterpret_cast<const uint2*>(base + byte_off);
-    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
-}
 
 // one pass over a row tile: per-channel sums of (a, b) where (a, b) = f(row, channel-quad).
 // K rows per lane are requested before any is consumed (forward: 8 x 16 B, backward: 4 x (x, gy)); the loads are unconditional
@@ -457,7 +395,10 @@ bool plan(long long R, int C, RPlan* p) {
 extern "C" size_t odpl_bn_act_workspace_bytes(int64_t R, int32_t C) {
     RPlan pl;
     if (!plan(R, C, &pl)) return 0;
-    return (size_t)pl.nblk * C * 2 * sizeof(double) + 256;
+    size_t need = (size_t)pl.nblk * C * 2 * sizeof(double);
+    const size_t fused = odpl::bn_fused_workspace_bytes(R, C);          // the one-launch path's partial array (other tiling)
+    if (fused > need) need = fused;
+    return need + 256;
 }
 
 extern "C" int odpl_bn_act_forward(const float* x, int64_t R, int32_t C, const float* gamma, const float* beta,
@@ -524,6 +465,12 @@ static int bn_forward_impl(const void* x, const void* residual, int32_t res_pre,
     P.num_batches_tracked = (long long*)num_batches_tracked;
     if (training) {
         if (!workspace || workspace_bytes < odpl_bn_act_workspace_bytes(R, C) || ((uintptr_t)workspace & 15)) return ODPL_EINVAL;
+        // maps the chip can hold in registers: statistics + apply in ONE launch (odpl_bnfused.hip); 1 = declined -> three launches
+        odpl::BnFusedPlan fp;
+        if (odpl::bn_fused_plan(R, C, bf16 != 0, false, &fp)) {
+            const int rc = odpl::bn_fused_launch(P, fp, false, bf16 != 0, stream);
+            if (rc != 1) return rc;
+        }
         if (bf16) hipLaunchKernelGGL((bn_reduce_kernel<false, true, 0>), dim3(nblk, pl.nslices), dim3(kT), lds, stream, P);      // statistics: no activation involved
         else hipLaunchKernelGGL((bn_reduce_kernel<false, false, 0>), dim3(nblk, pl.nslices), dim3(kT), lds, stream, P);
         ODPL_HIP_TRY(hipGetLastError());
@@ -565,6 +512,13 @@ extern "C" int odpl_bn_act_backward_strided(const void* x, const void* grad_y, i
     P.R = R; P.C = C; P.act = act; P.nblk = nblk; P.rows_per_blk = rpb; P.slice_q = pl.slice_q; P.training = training; P.part = (double*)workspace;
     P.y_rs4 = C >> 2; P.gy_rs4 = gy_row_stride >> 2;
     P.dgamma = grad_gamma; P.dbeta = grad_beta;
+    if (training) {             // one launch where the map fits on chip (odpl_bnfused.hip); 1 = declined -> three launches
+        odpl::BnFusedPlan fp;
+        if (odpl::bn_fused_plan(R, C, bf16 != 0, true, &fp)) {
+            const int rc = odpl::bn_fused_launch(P, fp, true, bf16 != 0, stream);
+            if (rc != 1) return rc;
+        }
+    }
     if (bf16) { ODPL_BN_LAUNCH(bn_reduce_kernel, true ODPL_COMMA true, dim3(nblk, pl.nslices), lds, stream, P) }
     else { ODPL_BN_LAUNCH(bn_reduce_kernel, true ODPL_COMMA false, dim3(nblk, pl.nslices), lds, stream, P) }
     ODPL_HIP_TRY(hipGetLastError());

@@ -766,7 +766,7 @@ extern "C" int odpl_yolo_compact_view(const odpl_yolo_loss_desc_t* d, const void
     return 0;
 }
 
-namespace odpl { extern int g_retina_fill_nt; extern int g_bn_target_blocks; extern int g_bn_stream_max_blocks; extern int g_bn_max_rows_per_tile; extern int g_bn_slice_from_c; }
+namespace odpl { extern int g_retina_fill_nt; extern int g_bn_target_blocks; extern int g_bn_stream_max_blocks; extern int g_bn_max_rows_per_tile; extern int g_bn_slice_from_c; extern int g_bn_fused; extern int g_bn_fused_timeout_us; }
 
 extern "C" int odpl_debug_set_stamp_buffer(void* dev_u64x2) { g_stamp = (unsigned long long*)dev_u64x2; return 0; }
 
@@ -779,6 +779,8 @@ extern "C" int odpl_tune_set(int32_t key, int32_t value) {
         case ODPL_TUNE_BN_STREAM_MAX_BLOCKS: if (value != 0 && (value < 64 || value > (1 << 20))) return ODPL_EINVAL; odpl::g_bn_stream_max_blocks = value; return 0;
         case ODPL_TUNE_BN_MAX_ROWS_PER_TILE: if (value < 16 || value > (1 << 16)) return ODPL_EINVAL; odpl::g_bn_max_rows_per_tile = value; return 0;
         case ODPL_TUNE_BN_SLICE_FROM_C: if (value < 4) return ODPL_EINVAL; odpl::g_bn_slice_from_c = value; return 0;
+        case ODPL_TUNE_BN_FUSED: odpl::g_bn_fused = value ? 1 : 0; return 0;
+        case ODPL_TUNE_BN_FUSED_TIMEOUT_US: if (value < 0 || value > 10000000) return ODPL_EINVAL; odpl::g_bn_fused_timeout_us = value; return 0;
         default: return ODPL_EINVAL;
     }
 }

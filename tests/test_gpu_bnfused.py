@@ -1,0 +1,152 @@
+"""BatchNorm(train) + activation in ONE launch per direction (csrc/odpl_bnfused.hip): the tile stays in registers across the
+grid-wide dependency; the workgroups of a channel slice exchange their partial sums inside the launch (agent-scope visibility rules,
+bounded wait, self-service path).  Checked against the three-launch path of the same library (tune switch), against torch, under
+back-to-back load, and with the wait forced to give up (the self-service path must give the same bits)."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+ACTS = {"mish": F.mish, "leaky": lambda z: F.leaky_relu(z, 0.1), "relu": F.relu, "linear": lambda z: z}
+
+
+def _bn(C, seed=1):
+    bn = nn.BatchNorm2d(C).cuda().train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=torch.Generator().manual_seed(seed)) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=torch.Generator().manual_seed(seed + 1)) * 0.2)
+    return bn
+
+
+def _run(x, act, res=None, dtype=torch.float32, seed=1):
+    from objectdetectionpl_amd.LightningFunc.utils.bnact import bn_act
+    bn = _bn(x.shape[1], seed)
+    xi = x.detach().clone().to(dtype).requires_grad_()
+    ri = None if res is None else res.detach().clone().to(dtype).requires_grad_()
+    y = bn_act(xi, bn, act) if ri is None else bn_act(xi, bn, act, residual=ri)
+    w = torch.randn(y.shape, generator=torch.Generator().manual_seed(5)).cuda().contiguous(memory_format=torch.channels_last).to(dtype)
+    (y * w).sum().backward()
+    out = [y.detach(), xi.grad, bn.weight.grad, bn.bias.grad, bn.running_mean.clone(), bn.running_var.clone()]
+    if ri is not None:
+        out.append(ri.grad)
+    return out
+
+
+@pytest.fixture
+def lib():
+    from objectdetectionpl_amd import _lib
+    yield _lib
+    _lib.tune_set("bn_fused", 1)
+    _lib.tune_set("bn_fused_timeout_us", 20000)
+
+
+# BASELINE config-2 stage shapes that qualify (H <= 52) + odd row counts, a single slice, bf16-friendly channel counts
+SHAPES = [(16, 1024, 13, 13), (16, 512, 13, 13), (16, 256, 13, 13), (16, 512, 26, 26), (16, 256, 26, 26), (16, 128, 26, 26),
+          (16, 128, 52, 52), (16, 256, 52, 52), (3, 64, 17, 19), (2, 32, 52, 52), (5, 96, 11, 7), (1, 160, 9, 9)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("act", ["mish", "leaky"])
+def test_one_launch_path_equals_three_launch_path_and_torch(lib, shape, act):
+    g = torch.Generator().manual_seed(shape[1] + shape[2])
+    x = (torch.randn(*shape, generator=g) * 1.4 + 0.25).cuda().contiguous(memory_format=torch.channels_last)
+    n0 = lib.bn_fused_stats()
+    lib.tune_set("bn_fused", 1)
+    a = _run(x, act)
+    n1 = lib.bn_fused_stats()
+    lib.tune_set("bn_fused", 0)
+    b = _run(x, act)
+    n2 = lib.bn_fused_stats()
+    assert n1[0] - n0[0] >= 1 and n2[0] == n1[0], (n0, n1, n2)          # the switch switches; at least the forward took one launch
+    assert n1[1] == n0[1]                                               # nobody gave up waiting
+    # same statistics to summation order (double accumulation): outputs agree far inside fp32 resolution of the sums
+    for u, v in zip(a, b):
+        assert torch.allclose(u, v, rtol=2e-5, atol=2e-6 * float(v.abs().max()) + 1e-30), float((u - v).abs().max())
+    # and torch
+    bn = _bn(shape[1])
+    xt = x.clone().requires_grad_()
+    yt = ACTS[act](bn(xt))
+    assert torch.allclose(a[0], yt, rtol=1e-4, atol=2e-5)
+    w = torch.randn(yt.shape, generator=torch.Generator().manual_seed(5)).cuda().contiguous(memory_format=torch.channels_last)
+    (yt * w).sum().backward()
+    assert torch.allclose(a[1], xt.grad, rtol=1e-3, atol=2e-5 * float(xt.grad.abs().max()))
+    assert torch.allclose(a[2], bn.weight.grad, rtol=2e-3, atol=2e-4 * float(bn.weight.grad.abs().max()))
+    assert torch.allclose(a[3], bn.bias.grad, rtol=2e-3, atol=2e-4 * float(bn.bias.grad.abs().max()))
+    assert torch.allclose(a[4], bn.running_mean, rtol=1e-5, atol=1e-6) and torch.allclose(a[5], bn.running_var, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("shape", [(16, 512, 26, 26), (16, 1024, 13, 13), (16, 128, 52, 52), (3, 64, 17, 19)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_giving_up_the_wait_gives_the_same_bits(lib, shape, dtype):
+    """timeout 0: a workgroup whose peers have not all arrived at its first look computes the slice's statistics itself from global
+    memory.  Same additions in the same order: every output is BITWISE the normal path's."""
+    g = torch.Generator().manual_seed(7)
+    x = (torch.randn(*shape, generator=g) * 1.4 + 0.25).cuda().contiguous(memory_format=torch.channels_last)
+    res = torch.randn(*shape, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    lib.tune_set("bn_fused", 1)
+    a = _run(x, "mish", res, dtype)
+    s0 = lib.bn_fused_stats()
+    lib.tune_set("bn_fused_timeout_us", 0)
+    b = _run(x, "mish", res, dtype)
+    s1 = lib.bn_fused_stats()
+    assert s1[0] > s0[0] and s1[1] > s0[1], (s0, s1)                    # one-launch kernels ran, some workgroups did not wait
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+
+
+def test_back_to_back_layers_under_load_are_reproducible(lib):
+    """The hand-off inside the launch must hold when the chip is busy and the consumer's caches are warm: 60 layers of alternating
+    shapes back to back on one stream (counter rows reused round-robin, partial buffers recycled by the allocator), three times: the
+    three runs agree bit for bit, and with the three-launch path to summation order."""
+    shapes = [(16, 256, 26, 26), (16, 512, 13, 13), (16, 128, 52, 52), (16, 1024, 13, 13), (16, 512, 26, 26), (8, 64, 26, 26)]
+    gens = torch.Generator().manual_seed(11)
+    xs = [(torch.randn(*s, generator=gens) * 1.2).cuda().contiguous(memory_format=torch.channels_last) for s in shapes]
+    from objectdetectionpl_amd.LightningFunc.utils.bnact import bn_act
+
+    def chain():
+        outs = []
+        bns = [_bn(s[1], 3 + i) for i, s in enumerate(shapes)]
+        for rep in range(10):
+            for x, bn in zip(xs, bns):
+                xi = x.clone().requires_grad_()
+                y = bn_act(xi, bn, "mish")
+                y.square().sum().backward()
+                outs.append((y.detach(), xi.grad))
+        torch.cuda.synchronize()
+        return outs, [b.running_var.clone() for b in bns]
+    lib.tune_set("bn_fused", 1)
+    runs = [chain() for _ in range(3)]
+    for r in runs[1:]:
+        for (y0, g0), (y1, g1) in zip(runs[0][0], r[0]):
+            assert torch.equal(y0, y1) and torch.equal(g0, g1)
+        for v0, v1 in zip(runs[0][1], r[1]):
+            assert torch.equal(v0, v1)
+    lib.tune_set("bn_fused", 0)
+    ref = chain()
+    for (y0, g0), (y1, g1) in zip(runs[0][0], ref[0]):
+        assert torch.allclose(y0, y1, rtol=2e-5, atol=1e-5) and torch.allclose(g0, g1, rtol=1e-4, atol=1e-5 * float(g1.abs().max()))
+
+
+def test_one_launch_path_into_a_concat_slice_and_with_the_resnet_tail(lib):
+    """riders: the CSP merge writes its column slice of the concat buffer (row stride 2C) and reads the slice of the incoming gradient
+    in place; `relu(bn(x) + s)` adds the shortcut before the activation."""
+    from objectdetectionpl_amd.LightningFunc.utils import bnact
+    g = torch.Generator().manual_seed(3)
+    shape = (8, 128, 26, 26)
+    x1 = torch.randn(*shape, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    x2 = torch.randn(*shape, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    outs = []
+    for fused in (1, 0):
+        lib.tune_set("bn_fused", fused)
+        b1, b2 = _bn(128, 1), _bn(128, 9)
+        a1, a2 = x1.clone().requires_grad_(), x2.clone().requires_grad_()
+        y = bnact.bn_act_cat(a1, b1, "mish", a2, b2, "leaky")
+        assert y is not None                                            # the C++ binding is built in-tree
+        (y * y).sum().backward()
+        outs.append((y.detach(), a1.grad, a2.grad, b1.weight.grad, b2.bias.grad))
+    for u, v in zip(*outs):
+        assert torch.allclose(u, v, rtol=2e-5, atol=2e-6 * float(v.abs().max()))
+    ref = torch.cat([F.mish(_bn(128, 1)(x1)), F.leaky_relu(_bn(128, 9)(x2), 0.1)], 1)
+    assert torch.allclose(outs[0][0], ref, rtol=1e-4, atol=2e-5)
