@@ -547,14 +547,19 @@ int odpl_bn_act_backward_strided(const void* x, const void* grad_y, int64_t gy_r
 #define ODPL_TUNE_BN_STREAM_MAX_BLOCKS 4  /* grid cap of the BN apply / dx streams (0 = by size: 4096 / 16384) */
 #define ODPL_TUNE_BN_MAX_ROWS_PER_TILE 5  /* rows per reduce tile at most (default 2048) */
 #define ODPL_TUNE_BN_SLICE_FROM_C 6       /* BN reduce passes cut rows into 16-quad channel slices from this C on (default 256) */
-#define ODPL_TUNE_BN_FUSED 7             /* 1 (default): BatchNorm(train) + activation in ONE launch per direction for the maps the chip holds in
-                                           * registers (odpl_bnfused.hip); 0: always statistics / finalize / apply as three launches */
+#define ODPL_TUNE_BN_FUSED 7             /* 1: BatchNorm(train) + activation in ONE launch per direction for the maps the chip holds in registers
+                                           * (odpl_bnfused.hip); 0 (default: the one-launch form measured slower, see that file): always statistics /
+                                           * finalize / apply as three launches */
 #define ODPL_TUNE_BN_FUSED_TIMEOUT_US 8  /* bound of the in-launch wait for a channel slice's other workgroups (default 20000); a workgroup
                                            * whose peers are late computes the slice's statistics itself (same bits); 0 = never wait (tests) */
 int odpl_tune_set(int32_t key, int32_t value);
 /* diagnostic (synchronises): out[0] = launches of the one-launch BatchNorm path since the library was loaded, out[1] = workgroups among
  * them that did not wait for their peers (self-service) */
 int odpl_bn_fused_stats(int32_t* out2);
+/* diagnostic: on != 0 makes later one-launch BatchNorm launches record 8 readings of the 100 MHz clock per workgroup (start, sums done,
+ * partials drained, peers seen, acquired, statistics done, stores issued, unused); out (HOST, n_wg * 8 uint64, may be NULL) receives the
+ * last launch's readings (synchronises) */
+int odpl_bn_fused_debug_stamps(int32_t on, uint64_t* out, int32_t n_wg);
 
 /* diagnostic: when non-NULL, every workgroup w of yolo_expand_kernel stores its start / end reading of the
  * constant 100 MHz counter into dev_u64[2w], dev_u64[2w+1] (buffer >= 2 * grid entries); NULL disables it. */

@@ -172,6 +172,7 @@ SIGNATURES = {
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "odpl_tune_set": (c_int32, [c_int32, c_int32]),
     "odpl_bn_fused_stats": (c_int32, [POINTER(c_int32)]),
+    "odpl_bn_fused_debug_stamps": (c_int32, [c_int32, c_void_p, c_int32]),
     "odpl_scale_inplace_if_not_one_bf16": (c_int32, [c_void_p, c_size_t, c_void_p, c_void_p]),
     "odpl_profile_enable": (c_int32, [c_int32, c_int32]),
     "odpl_profile_collect": (c_int32, [c_int32, POINTER(c_float), POINTER(c_float), c_int32]),

@@ -24,8 +24,15 @@
 
 #include <atomic>
 
+// MEASURED (MI355X, round 3, profiles/r03_bnfused_*.txt): correct -- bitwise reproducible, the self-service path gives the same bits --
+// but NOT faster, so it is OFF by default (odpl_tune_set(ODPL_TUNE_BN_FUSED, 1) turns it on).  The in-launch exchange costs 15-25 us with
+// 688 workgroups in flight: write-through partials take 3-16 us to drain while the other workgroups still stream their tiles, everybody
+// then waits for the slowest drain, the acquire costs 2-3.5 us at 2.7 workgroups per CU and the write-through partials come back from
+// memory in ~6 us -- against 4.8 us for the finalize launch + two launch boundaries + one re-read of a map that is still in the
+// 256 MB Infinity Cache.  Per layer, device time, forward / backward: 5.5 MB 16.8 / 16.6 us (three launches: 16.2 / 18.4),
+// 11 MB 22-24 / 24-26 (18.3 / 23.3), 22 MB 45 / 45 (22.7 / 31.1), 44 MB forward 63 (32.6).
 namespace odpl {
-int g_bn_fused = 1;
+int g_bn_fused = 0;
 int g_bn_fused_timeout_us = 20000;
 }
 
@@ -34,12 +41,16 @@ using namespace odpl;
 constexpr int kT = 256;
 constexpr int kSlots = 64;              // concurrent calls (streams, graph replays in flight) each own a counter row
 constexpr int kMaxSlices = 64;
+constexpr int kMaxChunk = 24;           // tiles one thread of the phase-2 reduction sums (all of their partials in flight at once)
 
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) unsigned gu32;
 
 __device__ unsigned g_bn_sync[kSlots * kMaxSlices * 2];    // zero at load; the last workgroup to leave a slice group resets its pair
 __device__ unsigned g_bn_fallbacks;                        // diagnostic: workgroups that took the self-service path
+constexpr int kStampWgs = 2048;
+__device__ unsigned long long g_bn_stamp[kStampWgs * 8];   // diagnostic: phase boundaries of the last stamped launch
+bool g_stamp_on = false;
 
 __device__ __forceinline__ void st_u64_sc1(double* p, double v) {
     __hip_atomic_store((gu64*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -135,6 +146,9 @@ __global__ __launch_bounds__(kT, min_waves(BWD, KR)) void bn_fused_kernel(const 
         c.xs = (unsigned)c4n * QB; c.gs = (unsigned)P.gy_rs4 * QB;
     };
 
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    auto stamp = [&](int i) { if (P.stamp && threadIdx.x == 0 && wg < kStampWgs) P.stamp[wg * 8 + i] = __builtin_amdgcn_s_memrealtime(); };
+    stamp(0);
     // ---- phase 1: this workgroup's tile, loaded once and kept
     set_tile(tile);
     const int my_rows = c.nrows;
@@ -152,6 +166,7 @@ __global__ __launch_bounds__(kT, min_waves(BWD, KR)) void bn_fused_kernel(const 
         __builtin_amdgcn_sched_barrier(0);                            // one row at a time: the scheduler otherwise widens every row to double first
     }
     combine_rows(s_red, tr, tc, tpr, rows_par, a, b);
+    stamp(1);
     if (tr == 0) {
         double* o = P.part + ((size_t)tile * C + 4 * q) * 2;
 #pragma unroll
@@ -161,20 +176,23 @@ __global__ __launch_bounds__(kT, min_waves(BWD, KR)) void bn_fused_kernel(const 
     __syncthreads();                                                  // ... before the one lane that signals for all of them
     gu32* arrive = (gu32*)(P.sync + 2 * slice);
     gu32* depart = arrive + 1;
+    stamp(2);
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // ---- exchange: ONE lane polls ONE word, relaxed, with a bound
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         int ok = 1;
         while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)T) {
-            __builtin_amdgcn_s_sleep(4);
+            __builtin_amdgcn_s_sleep(24);                             // ~0.6 us: hundreds of lanes poll a handful of words -- keep that traffic off the channels the late tiles load from
             if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)P.timeout_ticks) { ok = 0; break; }
         }
         *s_flag = ok;
+        stamp(3);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");            // ONE acquire after the match
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
+    stamp(4);
     const bool all_here = *s_flag != 0;
 
     // ---- the slice's sums over its T tiles: each (channel, which) value is summed by G = 256 / (8 s) threads, thread g taking the
@@ -184,18 +202,19 @@ __global__ __launch_bounds__(kT, min_waves(BWD, KR)) void bn_fused_kernel(const 
     if (all_here) {
         const int j = threadIdx.x % nval, g = threadIdx.x / nval;
         const int ch = slice * 4 * s + (j >> 1), which = j & 1;
-        const int k1 = (g + 1) * chunk < T ? (g + 1) * chunk : T;
+        const int k0 = g * chunk, k1 = (g + 1) * chunk < T ? (g + 1) * chunk : T;
         const double* base = P.part + (size_t)ch * 2 + which;
-        double t = 0;
-        int k = g * chunk;
-        for (; k + 3 < k1; k += 4) {                                  // four partial rows in flight, added in tile order
-            double v[4];
+        // every load of the chunk is issued before the first addition (one trip to memory, not chunk / 4 of them): unconditional,
+        // clamped to the chunk's last tile; the additions then run in tile order, the clamped repeats counting as +0
+        double v[kMaxChunk];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = ld_f64_sc1(base + (size_t)(k + u) * C * 2);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) t += v[u];
+        for (int u = 0; u < kMaxChunk; ++u) {
+            int k = k0 + u; if (k > k1 - 1) k = k1 - 1; if (k < 0) k = 0;
+            v[u] = ld_f64_sc1(base + (size_t)k * C * 2);
         }
-        for (; k < k1; ++k) t += ld_f64_sc1(base + (size_t)k * C * 2);
+        double t = 0;
+#pragma unroll
+        for (int u = 0; u < kMaxChunk; ++u) t += (k0 + u < k1) ? v[u] : 0.0;
         s_chunk[g * nval + j] = t;
         __syncthreads();
         if (g == 0) {
@@ -271,6 +290,7 @@ __global__ __launch_bounds__(kT, min_waves(BWD, KR)) void bn_fused_kernel(const 
     }
     __syncthreads();
 
+    stamp(5);
     // ---- phase 2: apply to the tile still held in registers
     const float* st = s_stat + 8 * tc;                                // (v0, w0, v1, w1, v2, w2, v3, w3) of this lane's channel quad
     const long long r0 = (long long)tile * P.rows_per_blk;
@@ -332,6 +352,7 @@ __global__ __launch_bounds__(kT, min_waves(BWD, KR)) void bn_fused_kernel(const 
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    stamp(6);
 }
 
 constexpr size_t kLds = (size_t)kT * 8 * sizeof(double) + 384 * sizeof(double) + 128 * sizeof(float) + 16;
@@ -394,6 +415,7 @@ bool bn_fused_plan(long long R, int C, bool bf16, bool bwd, BnFusedPlan* p) {
             if (c4n % s) continue;
             const long long rpb = (long long)kr * (kT / s), T = (R + rpb - 1) / rpb;
             if (T > 128 || T * 4 * s * 16 > (48 << 10)) continue;
+            if ((T + (kT / (8 * s)) - 1) / (kT / (8 * s)) > kMaxChunk) continue;      // tiles per reduction thread
             if (c4n / s > kMaxSlices) continue;
             best_s = s; best_kr = kr; best_T = T;
             break;
@@ -428,11 +450,24 @@ int bn_fused_launch(const BnParams& P0, const BnFusedPlan& pl, bool bwd, bool bf
     P.nblk = pl.T; P.rows_per_blk = pl.rpb; P.slice_q = pl.s;
     P.sync = D.sync + (size_t)(g_slot.fetch_add(1) % kSlots) * kMaxSlices * 2;
     P.timeout_ticks = (unsigned)(g_bn_fused_timeout_us < 0 ? 0 : g_bn_fused_timeout_us) * 100u;
+    P.stamp = nullptr;
+    if (g_stamp_on) ODPL_HIP_TRY(hipGetSymbolAddress((void**)&P.stamp, HIP_SYMBOL(g_bn_stamp)));
     if (bwd) return bf16 ? launch_act<true, true>(P, pl, D, stream) : launch_act<true, false>(P, pl, D, stream);
     return bf16 ? launch_act<false, true>(P, pl, D, stream) : launch_act<false, false>(P, pl, D, stream);
 }
 
 }  // namespace odpl
+
+// diagnostic: on != 0 -> later one-launch BatchNorm launches record 8 readings of the 100 MHz clock per workgroup (start, sums done,
+// partials drained, peers seen, acquired, statistics done, stores issued); out (host, n_wg * 8 u64) receives the last launch's
+extern "C" int odpl_bn_fused_debug_stamps(int32_t on, uint64_t* out, int32_t n_wg) {
+    g_stamp_on = on != 0;
+    if (out && n_wg > 0) {
+        if (n_wg > kStampWgs) n_wg = kStampWgs;
+        ODPL_HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bn_stamp), (size_t)n_wg * 8 * sizeof(uint64_t)));
+    }
+    return 0;
+}
 
 // diagnostic: out[0] = one-launch BatchNorm launches since the library was loaded, out[1] = workgroups among them that did not wait
 // for their slice (self-service path); synchronises the device

@@ -1,4 +1,4 @@
-"""BatchNorm(train) + activation in ONE launch per direction (csrc/odpl_bnfused.hip): the tile stays in registers across the
+"""BatchNorm(train) + activation in ONE launch per direction (csrc/odpl_bnfused.hip; opt-in, off by default): the tile stays in registers across the
 grid-wide dependency; the workgroups of a channel slice exchange their partial sums inside the launch (agent-scope visibility rules,
 bounded wait, self-service path).  Checked against the three-launch path of the same library (tune switch), against torch, under
 back-to-back load, and with the wait forced to give up (the self-service path must give the same bits)."""
@@ -38,13 +38,13 @@ def _run(x, act, res=None, dtype=torch.float32, seed=1):
 def lib():
     from objectdetectionpl_amd import _lib
     yield _lib
-    _lib.tune_set("bn_fused", 1)
+    _lib.tune_set("bn_fused", 0)                   # the library's default (the one-launch form is correct but not faster: DESIGN.md)
     _lib.tune_set("bn_fused_timeout_us", 20000)
 
 
 # BASELINE config-2 stage shapes that qualify (H <= 52) + odd row counts, a single slice, bf16-friendly channel counts
 SHAPES = [(16, 1024, 13, 13), (16, 512, 13, 13), (16, 256, 13, 13), (16, 512, 26, 26), (16, 256, 26, 26), (16, 128, 26, 26),
-          (16, 128, 52, 52), (16, 256, 52, 52), (3, 64, 17, 19), (2, 32, 52, 52), (5, 96, 11, 7), (1, 160, 9, 9)]
+          (16, 128, 52, 52), (16, 256, 52, 52), (3, 64, 17, 19), (2, 32, 52, 52), (5, 96, 11, 7), (2, 160, 9, 9)]
 
 
 @pytest.mark.parametrize("shape", SHAPES)

@@ -55,5 +55,5 @@ for shp, layers in SHAPES:
     r["saved_us_per_step"] = round(layers * (r["three_launch_fwd_us"] - r["one_launch_fwd_us"] + r["three_launch_bwd_us"] - r["one_launch_bwd_us"]), 1)
     rows.append(r)
     print(json.dumps(r), flush=True)
-_lib.tune_set("bn_fused", 1)
+_lib.tune_set("bn_fused", 0)
 print(json.dumps({"total_saved_us_per_step": round(sum(r["saved_us_per_step"] for r in rows), 1), "stats": _lib.bn_fused_stats()}))
