@@ -27,7 +27,8 @@
 extern "C" {
 #endif
 
-#define ODPL_ABI_VERSION 3   /* 3: memory-format strides + compact (structured) gradients on the YOLO losses, head-conv backward from them */
+#define ODPL_ABI_VERSION 4   /* 3: memory-format strides + compact (structured) gradients on the YOLO losses, head-conv backward from them;
+                              * 4: odpl_retina_loss_desc_t grew pos_anchor / num_pos (ODPL_RETINA_ROWS_ONLY), odpl_retina_heads_backward */
 #define ODPL_EINVAL (-1)
 #define ODPL_MAX_SCALES 4
 #define ODPL_MAX_ANCHORS 8
@@ -201,10 +202,18 @@ typedef struct {
     float img_size;                 /* scalar target scale, losses.py:425: boxes = y[:, 2:] * img_size */
     float img_size_y;               /* EXTENSION for non-square inputs (BASELINE config 4 is 1333 x 800): when > 0 the y / h columns
                                      * are scaled by it and the x / w columns by img_size (= input width); 0 = the reference's one scalar */
+    int32_t* pos_anchor;            /* ODPL_RETINA_ROWS_ONLY: int32 [B * An] (first num_pos entries written): b * An + a of the positive
+                                     * anchors in ascending order -- the rows of grad_loc / grad_cls that carry a gradient; else NULL */
+    int32_t* num_pos;               /* ODPL_RETINA_ROWS_ONLY: device int32 [1], the number of positive anchors; else NULL */
 } odpl_retina_loss_desc_t;
 
 /* the caller promises the last use of this workspace was a successful odpl_retina_loss call */
 #define ODPL_RETINA_STATE_CLEAN 1
+/* The focal one-hot drops the background column (losses.py:336-339) and SmoothL1 runs on positives only (:458-461): d loss/d (loc, cls)
+ * is zero except on the num_pos positive anchors (~0.1 % of the rows at BASELINE config 4).  With this flag grad_loc / grad_cls are written
+ * on those rows ONLY (no zero stream: the other rows are left untouched) and the rows are listed in pos_anchor / num_pos -- the
+ * structured form odpl_retina_heads_backward consumes. */
+#define ODPL_RETINA_ROWS_ONLY 2
 
 size_t odpl_retina_loss_workspace_bytes(const odpl_retina_loss_desc_t* desc);
 
@@ -297,6 +306,36 @@ typedef struct {
 } odpl_yolov5_rows_t;
 int odpl_yolov5_compact_view(const odpl_yolov5_loss_desc_t* desc, const void* compact, int32_t layer, odpl_sparse_grad_t* out,
                              odpl_yolov5_rows_t* rows);
+
+/* ---- backward of RetinaNet's two final head convolutions from the structured gradient (ODPL_RETINA_ROWS_ONLY) -------------------
+ * cls_head[-1] / loc_head[-1] (model/RetinaNet.py:93-99: Conv2d(Cin, A * no, 3, 1, 1), shared by the FPN levels) produce cls_preds / loc_preds
+ * directly (RetinaNet.py:101-113: permute(0, 2, 3, 1) + view(B, -1, no) + cat over the levels), so the rows of d loss/d preds map one to one
+ * onto (level, pixel, anchor k) and only the num_pos rows of pos_anchor are non-zero.  What aten::convolution_backward computes from the
+ * dense tensors, from those rows alone:  dW[k*no + c, :, ky, kx] += g[c] * X[b, y+ky-1, x+kx-1, :],  db[k*no + c] += g[c],
+ * dX[b, y+ky-1, x+kx-1, :] += sum_c g[c] * W[k*no + c, :, ky, kx].  Every output is fully written (dX is zero away from the positives);
+ * no float atomics.  X / dX: channels-last fp32 [B, H_l, W_l, Cin] per level; weights through their element strides (NCHW-contiguous
+ * or channels-last parameters). */
+#define ODPL_RETINA_LEVELS 5
+typedef struct {
+    const float* x[ODPL_RETINA_LEVELS];      /* the convolution's input on each level */
+    float* grad_x[ODPL_RETINA_LEVELS];       /* all NULL = not wanted */
+    const float* w;                          /* [A * no, Cin, 3, 3] */
+    float* grad_w;                           /* same strides as w; NULL = not wanted */
+    float* grad_b;                           /* [A * no]; NULL = not wanted */
+    const float* grad_rows;                  /* d loss/d preds in the dense [B, An, no] layout; only the rows listed in pos_anchor are read */
+    int64_t w_stride[4];                     /* element strides of w / grad_w along (o, i, ky, kx) */
+    int32_t no;                              /* outputs per anchor: C (class head) or 4 (box head) */
+} odpl_retina_head_t;
+typedef struct {
+    int32_t B, A, Cin, nlevels;
+    int32_t H[ODPL_RETINA_LEVELS], W[ODPL_RETINA_LEVELS];     /* feature-map sizes; An = A * sum H*W, rows ordered (level, y, x, k) */
+    const int32_t* pos_anchor;               /* device int32 [>= num_pos]: b * An + a, ascending (odpl_retina_loss, ODPL_RETINA_ROWS_ONLY) */
+    const int32_t* num_pos;                  /* device int32 [1] */
+    const float* upstream;                   /* device scalar multiplied into every gradient; NULL = 1 */
+} odpl_retina_heads_desc_t;
+size_t odpl_retina_heads_backward_workspace_bytes(const odpl_retina_heads_desc_t* desc, int32_t n_heads, const odpl_retina_head_t* heads);
+int odpl_retina_heads_backward(const odpl_retina_heads_desc_t* desc, int32_t n_heads, const odpl_retina_head_t* heads,
+                               void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- SSD loss: losses.py:159-315 ---------------------------------------------------------------- */
 

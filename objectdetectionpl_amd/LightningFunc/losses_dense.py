@@ -56,6 +56,42 @@ class _RetinaLossFn(torch.autograd.Function):
         return None, None, g_loc, g_cls
 
 
+class _RetinaLossHeadFn(torch.autograd.Function):
+    """The same loss when (loc_preds, cls_preds) come from `utils.retinahead.final_convs`: the differentiable inputs are the two final
+    head convolutions' weights, biases and per-level inputs.  forward writes d loss/d preds on the positive rows only (no zero
+    stream); backward runs both convolutions' backward from those rows (`odpl_retina_heads_backward`)."""
+
+    @staticmethod
+    def forward(ctx, owner, target, loc, cls, src, *diff):
+        B, An = loc.shape[0], loc.shape[1]
+        dev = loc.device
+        g_loc, g_cls = torch.empty_like(loc), torch.empty_like(cls)          # only the positive rows will be written -- and read
+        pos = torch.empty(B * An, dtype=torch.int32, device=dev)
+        npos = torch.empty(1, dtype=torch.int32, device=dev)
+        out3, counts = owner._launch(loc, cls, g_loc, g_cls, target, rows_only=(pos, npos))
+        ctx.src, ctx.aux = src, (g_loc, g_cls, pos, npos)
+        ctx.has = [t is not None for t in diff]
+        ctx.save_for_backward(*[t for t in diff if t is not None])              # version-checked by autograd
+        ctx.used = False
+        metrics = out3[1:]
+        ctx.mark_non_differentiable(metrics, counts)
+        return out3[0], metrics, counts
+
+    @staticmethod
+    def backward(ctx, g_loss, _gm, _gc):
+        from .utils.retinahead import heads_backward
+        if ctx.used:
+            raise RuntimeError("the fused RetinaNet loss frees its gradient buffers after the first backward")
+        ctx.used = True
+        g_loc, g_cls, pos, npos = ctx.aux
+        src = ctx.src
+        ctx.aux = ctx.src = None
+        _ = ctx.saved_tensors                                                    # raises if an input was edited in place since forward
+        need = ctx.needs_input_grad[5:]
+        gw, gx = heads_backward(src, g_loc, g_cls, pos, npos, g_loss.contiguous().float(), need[:4], need[4:])
+        return (None, None, None, None, None) + tuple(gw) + tuple(gx)
+
+
 class RetinaNetLoss(nn.Module):
     """losses.py:351-472.  ctor `(iou_boxes, cls_criterion, coord_criterion, num_classes, img_size)`;
     forward((loc_preds, cls_preds), targets) -> {"loss", "Localization", "Classification"}.
@@ -87,7 +123,9 @@ class RetinaNetLoss(nn.Module):
             self._anchors_dev = a
         return a
 
-    def _launch(self, loc, cls, g_loc, g_cls, target):
+    fuse_head_backward = True      # class switch: False = always hand autograd the dense d loss/d preds
+
+    def _launch(self, loc, cls, g_loc, g_cls, target, rows_only=None):
         _lib.require_cuda(loc, cls, target)
         L = _lib.lib()
         dev = loc.device
@@ -119,6 +157,9 @@ class RetinaNetLoss(nn.Module):
             self._clean_key = None
         key = (dev, torch.cuda.current_stream(dev).cuda_stream)
         d.flags = _lib.RETINA_STATE_CLEAN if self._clean_key == key else 0
+        if rows_only is not None:              # gradient on the positive rows only + the list of those rows (structured backward)
+            d.flags |= _lib.RETINA_ROWS_ONLY
+            d.pos_anchor, d.num_pos = rows_only[0].data_ptr(), rows_only[1].data_ptr()
         self._clean_key = None
         out3 = torch.empty(3, dtype=torch.float32, device=dev)
         counts = torch.empty(4, dtype=torch.int32, device=dev)
@@ -129,6 +170,12 @@ class RetinaNetLoss(nn.Module):
         return out3, counts
 
     def forward(self, outputs, targets):
+        from .utils.retinahead import fusable_source
+        loc_preds, cls_preds = outputs
+        src = fusable_source(loc_preds, cls_preds) if self.fuse_head_backward else None
+        if src is not None:
+            loss, metrics, _ = _RetinaLossHeadFn.apply(self, targets, loc_preds.detach(), cls_preds.detach(), src, *src["w"], *src["xs"])
+            return {"loss": loss, "Localization": metrics[0], "Classification": metrics[1]}
         loc_preds, cls_preds = (_widen(t) for t in outputs)
         loss, metrics, _ = _RetinaLossFn.apply(self, targets, loc_preds, cls_preds)
         return {"loss": loss, "Localization": metrics[0], "Classification": metrics[1]}

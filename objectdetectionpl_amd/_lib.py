@@ -6,7 +6,7 @@ from ctypes import POINTER, c_float, c_int32, c_size_t, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libodpl_hip.so")
 
-ABI_VERSION = 3            # include/odpl_hip.h: ODPL_ABI_VERSION
+ABI_VERSION = 4            # include/odpl_hip.h: ODPL_ABI_VERSION
 LAYOUT_PLANAR, LAYOUT_INTERLEAVED = 0, 1
 MAX_SCALES = 4
 MAX_ANCHORS = 8
@@ -47,7 +47,23 @@ class RetinaLossDesc(ctypes.Structure):
     _fields_ = [("loc", c_void_p), ("cls", c_void_p), ("grad_loc", c_void_p), ("grad_cls", c_void_p),
                 ("anchors", c_void_p), ("target", c_void_p),
                 ("B", c_int32), ("An", c_int32), ("C", c_int32), ("nT", c_int32),
-                ("coord_mode", c_int32), ("flags", c_int32), ("img_size", c_float), ("img_size_y", c_float)]
+                ("coord_mode", c_int32), ("flags", c_int32), ("img_size", c_float), ("img_size_y", c_float),
+                ("pos_anchor", c_void_p), ("num_pos", c_void_p)]
+
+
+RETINA_LEVELS = 5
+
+
+class RetinaHead(ctypes.Structure):
+    """odpl_retina_head_t"""
+    _fields_ = [("x", c_void_p * RETINA_LEVELS), ("grad_x", c_void_p * RETINA_LEVELS), ("w", c_void_p), ("grad_w", c_void_p), ("grad_b", c_void_p),
+                ("grad_rows", c_void_p), ("w_stride", ctypes.c_int64 * 4), ("no", c_int32)]
+
+
+class RetinaHeadsDesc(ctypes.Structure):
+    """odpl_retina_heads_desc_t"""
+    _fields_ = [("B", c_int32), ("A", c_int32), ("Cin", c_int32), ("nlevels", c_int32), ("H", c_int32 * RETINA_LEVELS), ("W", c_int32 * RETINA_LEVELS),
+                ("pos_anchor", c_void_p), ("num_pos", c_void_p), ("upstream", c_void_p)]
 
 
 class YoloNmsDesc(ctypes.Structure):
@@ -118,6 +134,8 @@ SIGNATURES = {
     "odpl_scale_inplace_if_not_one": (c_int32, [c_void_p, c_size_t, c_void_p, c_void_p]),
     "odpl_retina_loss_workspace_bytes": (c_size_t, [POINTER(RetinaLossDesc)]),
     "odpl_retina_loss": (c_int32, [POINTER(RetinaLossDesc), c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "odpl_retina_heads_backward_workspace_bytes": (c_size_t, [POINTER(RetinaHeadsDesc), c_int32, c_void_p]),
+    "odpl_retina_heads_backward": (c_int32, [POINTER(RetinaHeadsDesc), c_int32, c_void_p, c_void_p, c_size_t, c_void_p]),
     "odpl_retina_anchors": (c_int32, [POINTER(c_int32), POINTER(c_float), POINTER(c_float), c_void_p, ctypes.c_int64, c_void_p]),
     "odpl_pair_iou": (c_int32, [c_void_p, c_void_p, c_void_p, ctypes.c_int64, ctypes.c_int64, c_int32, c_int32, c_int32, c_void_p]),
     "odpl_bbox_wh_iou": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, ctypes.c_int64, c_void_p]),
@@ -228,6 +246,7 @@ def require_cuda(*tensors):
 
 YOLO_STATE_CLEAN = 1
 RETINA_STATE_CLEAN = 1
+RETINA_ROWS_ONLY = 2
 YOLOV5_STATE_CLEAN = 1
 IOU_MODES = {"iou": 0, "giou": 1, "diou": 2, "ciou": 3}
 TUNE_KEYS = {"yolo_fill_f4_per_block": 0, "yolo_fill_nt": 1, "retina_fill_nt": 2, "bn_target_blocks": 3, "bn_stream_max_blocks": 4, "bn_max_rows_per_tile": 5, "bn_slice_from_c": 6, "bn_fused": 7,

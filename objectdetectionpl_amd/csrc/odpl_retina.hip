@@ -40,6 +40,7 @@ struct RParams {
     int* status;                   // [0] status bits (kept 0 between calls)
     float* part;                   // [B*An*2] (first num_pos*2 used): loc term, cls term per positive row
     float* out3; int* out_counts;
+    int* pos_anchor; int* num_pos_out;   // ODPL_RETINA_ROWS_ONLY: the positive rows (b * An + a, ascending) and their number
 };
 
 // ---- assign: thread = anchor; the image's boxes come straight from the target rows, compacted in row
@@ -164,6 +165,7 @@ __global__ __launch_bounds__(kT) void retina_main_kernel(const RParams P) {
             const int local = P.tile_pos[(size_t)tile * kT + (r - P.tile_off[tile])];
             const int b = tile / P.nblk_x, a = (tile - b * P.nblk_x) * kT + local;
             const size_t ga = (size_t)b * P.An + a;
+            if (P.pos_anchor && lane == 0) P.pos_anchor[r] = (int)ga;          // rows are walked in ascending (b, a) order of r
             const int cd = P.code[ga];
             const int trow = cd >> 12, label = (cd & 0xfff) - 1;
             const float* y = P.target + (size_t)trow * 6;
@@ -248,6 +250,7 @@ __global__ __launch_bounds__(256) void retina_finalize_kernel(const RParams P) {
         P.out3[1] = bad ? NAN : loc / npos;
         P.out3[2] = bad ? NAN : cls / npos;
         if (P.out_counts) { P.out_counts[0] = n; P.out_counts[1] = st; P.out_counts[2] = 0; P.out_counts[3] = 0; }
+        if (P.num_pos_out) P.num_pos_out[0] = n;
         P.status[0] = 0;                                      // clean for the next call
     }
 }
@@ -260,6 +263,7 @@ bool make_rplan(const odpl_retina_loss_desc_t* d, RPlan* p) {
     if (!d || d->B < 1 || d->An < 1 || d->C < 1 || d->C > 4094 || d->nT < 0 || d->nT > (1 << 19)) return false;
     if (!d->loc || !d->cls || !d->anchors || (d->nT > 0 && !d->target)) return false;
     if ((d->grad_loc == nullptr) != (d->grad_cls == nullptr)) return false;
+    if ((d->flags & ODPL_RETINA_ROWS_ONLY) && (!d->grad_cls || !d->pos_anchor || !d->num_pos)) return false;
     if ((long long)d->B * d->An * d->C > 0x7fffffffLL * 4) return false;
     p->nblk_x = (d->An + kT - 1) / kT;
     p->ntiles = p->nblk_x * d->B;
@@ -299,6 +303,8 @@ extern "C" int odpl_retina_loss(const odpl_retina_loss_desc_t* d, void* workspac
     P.row_tile = (int*)(ws + pl.row_tile); P.tile_pos = (unsigned char*)(ws + pl.tile_pos);
     P.status = (int*)(ws + pl.status); P.part = (float*)(ws + pl.part);
     P.out3 = out3; P.out_counts = out_counts;
+    const bool rows_only = (d->flags & ODPL_RETINA_ROWS_ONLY) != 0;
+    P.pos_anchor = rows_only ? d->pos_anchor : nullptr; P.num_pos_out = rows_only ? d->num_pos : nullptr;
     if (!(d->flags & ODPL_RETINA_STATE_CLEAN)) ODPL_HIP_TRY(odpl::fill_bytes(P.status, 0, 256, stream));
     const dim3 grid(pl.nblk_x, d->B);
     prof_begin(ODPL_PROF_RETINA_ASSIGN, stream);
@@ -307,7 +313,7 @@ extern "C" int odpl_retina_loss(const odpl_retina_loss_desc_t* d, void* workspac
     ODPL_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(retina_scan_kernel, dim3(1), dim3(1024), 0, stream, P);
     ODPL_HIP_TRY(hipGetLastError());
-    const int nmain = kRowWGs + (d->grad_cls ? pl.ntiles : 0);
+    const int nmain = kRowWGs + ((d->grad_cls && !rows_only) ? pl.ntiles : 0);      // rows only: no zero stream
     prof_begin(ODPL_PROF_RETINA_MAIN, stream);
     if (g_retina_fill_nt) hipLaunchKernelGGL(retina_main_kernel<true>, dim3(nmain), dim3(kT), 0, stream, P);
     else hipLaunchKernelGGL(retina_main_kernel<false>, dim3(nmain), dim3(kT), 0, stream, P);

@@ -14,6 +14,7 @@ from ..LightningFunc import step as _step
 from ..LightningFunc.losses import configure_loss
 from ..LightningFunc.nms import greedy_non_max_suppression
 from ..LightningFunc.utils import bnact as _bnact
+from ..LightningFunc.utils import retinahead as _rh
 from ..LightningFunc.utils.RetinaUtils import get_anchor_boxes
 
 try:
@@ -134,21 +135,34 @@ class RetinaNet(_Base):
         return nn.Sequential(*layers)
 
     @staticmethod
-    def _run_head(head, fm):
-        """[Conv2d(256,256,3,1,1), ReLU] x 4 + Conv2d (RetinaNet.py:93-99); on the device each conv + bias + ReLU unit runs as the
-        MIOpen convolution + one fused epilogue (utils/bnact.py:conv_bias_act)."""
-        if not fm.is_cuda:
-            return head(fm)
+    def _run_tower(head, fm):
+        """the four [Conv2d(256,256,3,1,1), ReLU] units of a head (RetinaNet.py:93-99): MIOpen convolution + one fused epilogue each
+        (utils/bnact.py:conv_bias_act)"""
         mods = list(head)
         for i in range(0, len(mods) - 1, 2):
             fm = _bnact.conv_bias_act(fm, mods[i], "relu")
-        return mods[-1](fm)
+        return fm
+
+    @classmethod
+    def _run_head(cls, head, fm):
+        """[Conv2d(256,256,3,1,1), ReLU] x 4 + Conv2d (RetinaNet.py:93-99)"""
+        if not fm.is_cuda:
+            return head(fm)
+        return list(head)[-1](cls._run_tower(head, fm))
 
     def forward(self, x):
         if x.is_cuda and (self.iou_boxes is None or self.iou_boxes.device != x.device):
             self._build_anchors(x.device)          # the anchor table (criterion / NMS side) lives on the HIP device only
+        feats = self.fpn(x)
+        if (x.is_cuda and _rh.enabled and self.num_anchors == 9 and _rh.is_hostable(self.loc_head[-1]) and _rh.is_hostable(self.cls_head[-1])
+                and feats[0].dtype == torch.float32):
+            # the two final convolutions of all levels hosted together: RetinaNetLoss can then run their backward from its structured
+            # gradient (utils/retinahead.py); same values as the loop below
+            xl = [self._run_tower(self.loc_head, fm) for fm in feats]
+            xc = [self._run_tower(self.cls_head, fm) for fm in feats]
+            return _rh.final_convs(self.loc_head[-1], self.cls_head[-1], xl, xc)
         loc, cls = [], []
-        for fm in self.fpn(x):
+        for fm in feats:
             loc.append(self._run_head(self.loc_head, fm).permute(0, 2, 3, 1).contiguous().view(x.size(0), -1, 4))
             cls.append(self._run_head(self.cls_head, fm).permute(0, 2, 3, 1).contiguous().view(x.size(0), -1, self.num_classes))
         return torch.cat(loc, 1), torch.cat(cls, 1)

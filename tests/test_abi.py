@@ -21,7 +21,7 @@ def test_header_symbols_exported_and_bound():
     for n in names:
         assert hasattr(raw, n), f"{n} declared in odpl_hip.h but not exported"
     assert sorted(_lib.SIGNATURES) == names, (set(names) ^ set(_lib.SIGNATURES))
-    assert _lib.lib().odpl_abi_version() == _lib.ABI_VERSION == 3
+    assert _lib.lib().odpl_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_struct_layout_matches_header():
@@ -34,6 +34,11 @@ def test_struct_layout_matches_header():
     # odpl_yolo_loss_desc_t: 8 int32 + 3 float (+pad) + pointer + 4 scales
     assert _lib.YoloLossDesc.target.offset == 48
     assert ctypes.sizeof(_lib.YoloLossDesc) == 56 + 4 * ctypes.sizeof(_lib.YoloScale)
+    # odpl_retina_loss_desc_t: 6 pointers + 6 int32 + 2 floats + 2 pointers (ABI 4)
+    assert ctypes.sizeof(_lib.RetinaLossDesc) == 96 and _lib.RetinaLossDesc.pos_anchor.offset == 80
+    # odpl_retina_head_t: 5 + 5 + 4 pointers, 4 int64 strides, int32 (+pad); odpl_retina_heads_desc_t: 14 int32 + 3 pointers
+    assert ctypes.sizeof(_lib.RetinaHead) == 152 and _lib.RetinaHead.w_stride.offset == 112
+    assert ctypes.sizeof(_lib.RetinaHeadsDesc) == 80 and _lib.RetinaHeadsDesc.pos_anchor.offset == 56
 
 
 def test_workspace_query_is_host_only():
