@@ -313,8 +313,8 @@ int odpl_yolov5_compact_view(const odpl_yolov5_loss_desc_t* desc, const void* co
  * onto (level, pixel, anchor k) and only the num_pos rows of pos_anchor are non-zero.  What aten::convolution_backward computes from the
  * dense tensors, from those rows alone:  dW[k*no + c, :, ky, kx] += g[c] * X[b, y+ky-1, x+kx-1, :],  db[k*no + c] += g[c],
  * dX[b, y+ky-1, x+kx-1, :] += sum_c g[c] * W[k*no + c, :, ky, kx].  Every output is fully written (dX is zero away from the positives);
- * no float atomics.  X / dX: channels-last fp32 [B, H_l, W_l, Cin] per level; weights through their element strides (NCHW-contiguous
- * or channels-last parameters). */
+ * no float atomics.  X / dX: channels-last fp32 [B, H_l, W_l, Cin] per level, Cin % 4 == 0, Cin <= 448; weights through their element
+ * strides (NCHW-contiguous or channels-last parameters).  The workspace query returns 0 for a descriptor outside these limits. */
 #define ODPL_RETINA_LEVELS 5
 typedef struct {
     const float* x[ODPL_RETINA_LEVELS];      /* the convolution's input on each level */
@@ -336,6 +336,9 @@ typedef struct {
 size_t odpl_retina_heads_backward_workspace_bytes(const odpl_retina_heads_desc_t* desc, int32_t n_heads, const odpl_retina_head_t* heads);
 int odpl_retina_heads_backward(const odpl_retina_heads_desc_t* desc, int32_t n_heads, const odpl_retina_head_t* heads,
                                void* workspace, size_t workspace_bytes, void* stream);
+/* positive rows that own staging slots in the workspace (default 4096: 9 x 2 x Cin floats each); rows beyond are summed in place by the
+ * dx launch -- same arithmetic, slower.  Call before querying the workspace size. */
+int odpl_retina_heads_tune(int32_t stage_rows);
 
 /* ---- SSD loss: losses.py:159-315 ---------------------------------------------------------------- */
 

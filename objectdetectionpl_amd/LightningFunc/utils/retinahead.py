@@ -88,7 +88,7 @@ def fusable_source(loc, cls):
     xs = src["xs"]
     cin = xs[0].shape[1]
     for x in xs:
-        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == cin and cin % 4 == 0
+        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == cin and cin % 4 == 0 and cin <= 448
                 and x.is_contiguous(memory_format=torch.channels_last) and x.data_ptr() % 16 == 0):
             return None
     for w in src["w"]:

@@ -136,6 +136,7 @@ SIGNATURES = {
     "odpl_retina_loss": (c_int32, [POINTER(RetinaLossDesc), c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "odpl_retina_heads_backward_workspace_bytes": (c_size_t, [POINTER(RetinaHeadsDesc), c_int32, c_void_p]),
     "odpl_retina_heads_backward": (c_int32, [POINTER(RetinaHeadsDesc), c_int32, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "odpl_retina_heads_tune": (c_int32, [c_int32]),
     "odpl_retina_anchors": (c_int32, [POINTER(c_int32), POINTER(c_float), POINTER(c_float), c_void_p, ctypes.c_int64, c_void_p]),
     "odpl_pair_iou": (c_int32, [c_void_p, c_void_p, c_void_p, ctypes.c_int64, ctypes.c_int64, c_int32, c_int32, c_int32, c_void_p]),
     "odpl_bbox_wh_iou": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, ctypes.c_int64, c_void_p]),

@@ -12,11 +12,14 @@
 // Three launches for both heads and all levels, no float atomics (bitwise reproducible):
 //   map   the positive rows arrive sorted by (image, anchor index) = (image, level, pixel, k): the rows of one pixel are consecutive.
 //         One thread per row marks the first row of its pixel and counts the pixel's rows in an int32 map over all level pixels
+//   pair  one WAVE per (positive row, tap): the row's contribution to ONE input pixel, sum_c g[c] * W[k*no + c, :, tap] for both heads, into a
+//         staging slot (eight weight rows in flight, lanes along Cin): 7.8 k independent waves at config 4 instead of a few dozen
+//         serial chains on the pixels that many rows reach
 //   dx    one WAVE per level pixel: it looks at the <= 9 map entries of its 3 x 3 neighbourhood; nothing there -> a zero row (the dense
 //         dX the previous layer's backward expects is written exactly once: an HBM write stream, 2 x 91 MB at config 4); otherwise the
-//         contributions are summed in (tap, row, channel) order, lanes along Cin
-//   dw    one workgroup per (head, anchor k, four output channels): the rows of anchor k are compacted into LDS in row order, then
-//         summed four rows at a time (twelve X vectors in flight), taps split over the four waves, lanes along Cin
+//         staged contributions are summed in (tap, row) order
+//   dw    one workgroup per (head, anchor k, four output channels, tap): the rows of anchor k are compacted into LDS in row order; wave w
+//         takes rows w, w + 4, ... eight at a time (eight X vectors in flight, lanes along Cin); the four waves are combined in wave order
 #include "odpl_common.hpp"
 #include "../../include/odpl_hip.h"
 
@@ -24,7 +27,9 @@ namespace {
 using namespace odpl;
 constexpr int kT = 256;
 constexpr int kMaxHeads = 2;
-constexpr int kRowChunk = 2048;         // positive rows a dw workgroup stages in LDS at a time
+constexpr int kRowChunk = 512;          // positive rows a dw workgroup stages in LDS at a time
+int g_stage_rows = 4096;                // positive rows with staging slots (9 taps x 2 heads x Cin floats each: 75 MB at Cin = 256); the rows
+                                        // beyond are summed in place by the dx launch (slower, same arithmetic): BASELINE config 4 has 863
 
 struct Level { int H, W, HW, first, pix0; };      // first: anchor index of the level's first anchor; pix0: its first pixel in the map (per image: + b * HW)
 struct HeadP {
@@ -37,7 +42,9 @@ struct GP {
     HeadP h[kMaxHeads]; Level lv[ODPL_RETINA_LEVELS];
     const int* pos; const int* num_pos; const float* upstream;
     int* map_first; int* map_cnt;
-    int B, A, Cin, cv, nlevels, nheads, An, npix_img, npix;      // npix_img = sum HW; npix = B * npix_img
+    float* stage;                                                // [cap * 9][kMaxHeads][Cin]: one row's contribution through one tap
+    int B, A, Cin, cv, nlevels, nheads, An, npix_img, npix, cap; // npix_img = sum HW; npix = B * npix_img; cap: rows that own staging slots
+    int pair_head;                                               // the head a pair launch works on
 };
 
 // anchor index a (within an image) -> level, cell, k
@@ -79,65 +86,194 @@ __device__ __forceinline__ float4 ld_w4(const float* w, long long off, long long
     return make_float4(w[off], w[off + ws_i], w[off + 2 * ws_i], w[off + 3 * ws_i]);
 }
 
+// sum_c g[c] * W[(k * no + c), 4v .. 4v+3, ky, kx] for one head: eight weight rows in flight
+__device__ __forceinline__ float4 pair_contrib(const HeadP& Hd, const float* g, int k, int ky, int kx, int v) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const long long base = (long long)k * Hd.no * Hd.ws_o + ky * Hd.ws_ky + kx * Hd.ws_kx + (long long)(4 * v) * Hd.ws_i;
+    int c = 0;
+    for (; c + 7 < Hd.no; c += 8) {
+        float4 w[8]; float gc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { w[u] = ld_w4(Hd.w, base + (long long)(c + u) * Hd.ws_o, Hd.ws_i); gc[u] = g[c + u]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { acc.x += gc[u] * w[u].x; acc.y += gc[u] * w[u].y; acc.z += gc[u] * w[u].z; acc.w += gc[u] * w[u].w; }
+    }
+    for (; c < Hd.no; ++c) {
+        const float4 w0 = ld_w4(Hd.w, base + (long long)c * Hd.ws_o, Hd.ws_i);
+        const float g0 = g[c];
+        acc.x += g0 * w0.x; acc.y += g0 * w0.y; acc.z += g0 * w0.z; acc.w += g0 * w0.w;
+    }
+    return acc;
+}
+
+// The staged contributions as small GEMMs.  For one (head, anchor k, tap) the weight slab W[k*no .. k*no+no, :, tap] (no x Cin floats:
+// 80 KB for the class head) is the B operand of EVERY row of anchor k; one wave per (row, tap) re-read it per row -- 652 MB through L2s
+// that hold 4 MB each.  Here a workgroup owns (head, k, tap, slot): it compacts the rows of anchor k (list order), loads the slab
+// into LDS ONCE (in blocks of kSlabRows output channels) and walks the batches slot, slot + kPairSlots, ... of 16 rows: wave w takes
+// rows w, w + 4, w + 8, w + 12 of a batch, lanes along Cin, gradients broadcast from LDS.  52 MB of weight reads at config 4.
+constexpr int kPairSlots = 8;
+constexpr int kSlabRows = 80;           // output channels of a slab block held in LDS (x Cin floats)
+constexpr int kPairChunk = 512;         // rows of anchor k listed in LDS at a time
+
+__global__ __launch_bounds__(kT) void rh_pair_kernel(const GP P) {
+    __shared__ int s_ga[kPairChunk], s_r[kPairChunk];
+    __shared__ int s_wave[kT / 64];
+    extern __shared__ __align__(16) float s_dyn[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int bid = blockIdx.x;
+    const int slot = bid % kPairSlots; bid /= kPairSlots;
+    const int t = bid % 9; bid /= 9;
+    const int k = bid % P.A, h = P.pair_head;                           // one launch per head: the LDS slab is sized by that head's rows
+    const HeadP& Hd = P.h[h];
+    const int ky = t / 3, kx = t - 3 * ky;
+    const int n = *P.num_pos, nlim = n < P.cap ? n : P.cap;
+    const int cv = P.cv;
+    const int slab = Hd.no < kSlabRows ? Hd.no : kSlabRows;
+    float4* s_w = reinterpret_cast<float4*>(s_dyn);                     // [slab][cv]
+    float* s_gb = s_dyn + (size_t)slab * cv * 4;                        // [16][kSlabRows]  gradients of the batch, channel block
+    int seen = 0;                                                       // rows of anchor k listed so far (over the chunks)
+    for (int r0 = 0; r0 < nlim; r0 += kPairChunk) {
+        // ---- rows of anchor k in [r0, r0 + kPairChunk), ascending (ballot compaction)
+        int base = 0;
+        for (int t0 = r0; t0 < r0 + kPairChunk && t0 < nlim; t0 += kT) {
+            const int r = t0 + tid;
+            int ga = 0; bool keep = false;
+            if (r < nlim && r < r0 + kPairChunk) {
+                ga = P.pos[r];
+                const int a = ga - (ga / P.An) * P.An;
+                int l, cell, kk; decode_anchor(P, a, l, cell, kk);
+                keep = kk == k;
+            }
+            const unsigned long long m = __ballot(keep);
+            if (lane == 0) s_wave[wv] = __popcll(m);
+            __syncthreads();
+            int off = base, tot = 0;
+            for (int w = 0; w < kT / 64; ++w) { if (w < wv) off += s_wave[w]; tot += s_wave[w]; }
+            if (keep) { const int p = off + __popcll(m & ((1ull << lane) - 1ull)); s_ga[p] = ga; s_r[p] = r; }
+            base += tot;
+            __syncthreads();
+        }
+        const int cnt = base;
+        // batches of this chunk that belong to this slot: global batch index (seen + i0) / 16
+        for (int i0 = 0; i0 < cnt; i0 += 16) {
+            if (((seen + i0) / 16) % kPairSlots != slot) continue;      // uniform
+            const int nb = cnt - i0 < 16 ? cnt - i0 : 16;
+            for (int v0 = 0; v0 < cv; v0 += 64) {
+                const int v = v0 + lane;
+                const bool ok = v < cv;
+                float4 acc[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int c0 = 0; c0 < Hd.no; c0 += kSlabRows) {
+                    const int nc = Hd.no - c0 < kSlabRows ? Hd.no - c0 : kSlabRows;
+                    __syncthreads();                                    // the previous block / batch is consumed
+                    for (int e = tid; e < nc * cv; e += kT) {           // slab block: rows c0 .. c0 + nc of (k, tap), coalesced along Cin
+                        const int c = e / cv, vv = e - c * cv;
+                        s_w[c * cv + vv] = ld_w4(Hd.w, (long long)(k * Hd.no + c0 + c) * Hd.ws_o + ky * Hd.ws_ky + kx * Hd.ws_kx + (long long)(4 * vv) * Hd.ws_i, Hd.ws_i);
+                    }
+                    for (int e = tid; e < nb * nc; e += kT) {
+                        const int u = e / nc, c = e - u * nc;
+                        s_gb[u * kSlabRows + c] = Hd.rows[(size_t)s_ga[i0 + u] * Hd.no + c0 + c];
+                    }
+                    __syncthreads();
+                    if (ok) {
+                        for (int c = 0; c < nc; ++c) {
+                            const float4 w4 = s_w[c * cv + v];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const float g = s_gb[(wv + 4 * u) * kSlabRows + c];     // rows beyond nb read stale values: never stored
+                                acc[u].x += g * w4.x; acc[u].y += g * w4.y; acc[u].z += g * w4.z; acc[u].w += g * w4.w;
+                            }
+                        }
+                    }
+                }
+                if (ok) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int i = wv + 4 * u;
+                        if (i < nb) {
+                            const int ga = s_ga[i0 + i], b = ga / P.An, a = ga - b * P.An;
+                            int l, cell, kk; decode_anchor(P, a, l, cell, kk);
+                            const Level L = P.lv[l];
+                            const int y = cell / L.W, x = cell - y * L.W, yy = y + ky - 1, xx = x + kx - 1;
+                            if (yy >= 0 && yy < L.H && xx >= 0 && xx < L.W)         // else: reaches no pixel, the slot is never read
+                                reinterpret_cast<float4*>(P.stage)[((size_t)(s_r[i0 + i] * 9 + t) * kMaxHeads + h) * cv + v] = acc[u];
+                        }
+                    }
+                }
+            }
+        }
+        seen += cnt;
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(kT) void rh_dx_kernel(const GP P) {
-    const int lane = threadIdx.x & 63;
-    const int pix = blockIdx.x * (kT / 64) + (threadIdx.x >> 6);      // wave = one level pixel (wave-uniform from here on)
+    __shared__ int s_list[kT / 64][96];                                // per wave: the staging slots (r * 9 + tap) that reach its pixel
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int pix = blockIdx.x * (kT / 64) + wv;                       // wave = one level pixel (wave-uniform from here on)
     if (pix >= P.npix) return;
     int l = 0;
     for (int i = 1; i < P.nlevels; ++i) if (pix >= P.B * P.lv[i].pix0) l = i;
     const Level L = P.lv[l];
     const int rel = pix - P.B * L.pix0, b = rel / L.HW, cell = rel - b * L.HW, y = cell / L.W, x = cell - y * L.W;
     const float f = P.upstream ? *P.upstream : 1.0f;
-    // the 3 x 3 neighbourhood's map entries first: almost every pixel finds nothing and streams zeros
-    int cnt[9], fst[9], any = 0;
+    // the 3 x 3 neighbourhood's map entries first: almost every pixel finds nothing and streams zeros.  The others list their staging
+    // slots in (tap, row) order -- every lane writes the same list; rows without a slot (r >= cap) send the pixel down the in-place path
+    int M = 0; bool unstaged = false;
+    int* list = s_list[wv];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         const int ky = t / 3, kx = t - 3 * ky, yp = y - ky + 1, xp = x - kx + 1;      // the positive at (yp, xp) reaches (y, x) through tap (ky, kx)
-        cnt[t] = 0; fst[t] = 0;
         if (yp >= 0 && yp < L.H && xp >= 0 && xp < L.W) {
             const int s = map_slot(P, l, b, yp * L.W + xp);
-            cnt[t] = P.map_cnt[s];
-            if (cnt[t]) fst[t] = P.map_first[s];
+            const int m = P.map_cnt[s];
+            if (m) {
+                const int f0 = P.map_first[s];
+                for (int j = 0; j < m && M < 96; ++j) { list[M++] = (f0 + j) * 9 + t; unstaged |= f0 + j >= P.cap; }
+            }
         }
-        any |= cnt[t];
     }
     const size_t row = ((size_t)b * L.HW + cell) * P.cv;
     for (int v0 = 0; v0 < P.cv; v0 += 64) {
         const int v = v0 + lane;
         const bool ok = v < P.cv;
+        const int vc = ok ? v : P.cv - 1;
         float4 acc[kMaxHeads];
 #pragma unroll
         for (int h = 0; h < kMaxHeads; ++h) acc[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (any && ok) {
+        if (M && !unstaged) {
+            // eight staged contributions per head in flight (unconditional loads clamped to the list's last entry), added in list order
+            for (int i0 = 0; i0 < M; i0 += 8) {
+                float4 c4[kMaxHeads][8];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int ky = t / 3, kx = t - 3 * ky;
-                for (int j = 0; j < cnt[t]; ++j) {
-                    const int ga = __builtin_amdgcn_readfirstlane(P.pos[fst[t] + j]);
-                    const int a = ga - (ga / P.An) * P.An;
-                    const int k = (a - L.first) % P.A;
+                for (int u = 0; u < 8; ++u) {
+                    const int e = list[i0 + u < M ? i0 + u : M - 1];
 #pragma unroll
-                    for (int h = 0; h < kMaxHeads; ++h) {
-                        if (h >= P.nheads || !P.h[h].gx[0]) continue;
-                        const HeadP& Hd = P.h[h];
-                        const float* g = Hd.rows + (size_t)ga * Hd.no;
-                        const long long base = (long long)k * Hd.no * Hd.ws_o + ky * Hd.ws_ky + kx * Hd.ws_kx + (long long)(4 * v) * Hd.ws_i;
-                        int c = 0;
-                        for (; c + 3 < Hd.no; c += 4) {                          // four weight rows in flight
-                            const float4 w0 = ld_w4(Hd.w, base + (long long)c * Hd.ws_o, Hd.ws_i), w1 = ld_w4(Hd.w, base + (long long)(c + 1) * Hd.ws_o, Hd.ws_i);
-                            const float4 w2 = ld_w4(Hd.w, base + (long long)(c + 2) * Hd.ws_o, Hd.ws_i), w3 = ld_w4(Hd.w, base + (long long)(c + 3) * Hd.ws_o, Hd.ws_i);
-                            const float g0 = g[c], g1 = g[c + 1], g2 = g[c + 2], g3 = g[c + 3];
-                            acc[h].x += g0 * w0.x; acc[h].y += g0 * w0.y; acc[h].z += g0 * w0.z; acc[h].w += g0 * w0.w;
-                            acc[h].x += g1 * w1.x; acc[h].y += g1 * w1.y; acc[h].z += g1 * w1.z; acc[h].w += g1 * w1.w;
-                            acc[h].x += g2 * w2.x; acc[h].y += g2 * w2.y; acc[h].z += g2 * w2.z; acc[h].w += g2 * w2.w;
-                            acc[h].x += g3 * w3.x; acc[h].y += g3 * w3.y; acc[h].z += g3 * w3.z; acc[h].w += g3 * w3.w;
-                        }
-                        for (; c < Hd.no; ++c) {
-                            const float4 w0 = ld_w4(Hd.w, base + (long long)c * Hd.ws_o, Hd.ws_i);
-                            const float g0 = g[c];
-                            acc[h].x += g0 * w0.x; acc[h].y += g0 * w0.y; acc[h].z += g0 * w0.z; acc[h].w += g0 * w0.w;
-                        }
+                    for (int h = 0; h < kMaxHeads; ++h)
+                        c4[h][u] = (h < P.nheads && P.h[h].gx[0]) ? reinterpret_cast<const float4*>(P.stage)[((size_t)e * kMaxHeads + h) * P.cv + vc] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (i0 + u < M) {
+#pragma unroll
+                        for (int h = 0; h < kMaxHeads; ++h) { acc[h].x += c4[h][u].x; acc[h].y += c4[h][u].y; acc[h].z += c4[h][u].z; acc[h].w += c4[h][u].w; }
                     }
+            }
+        } else if (M && ok) {
+            for (int i = 0; i < M; ++i) {                              // more rows than staging slots: in place (same arithmetic per contribution)
+                const int e = list[i], r = e / 9, t = e - 9 * r, ky = t / 3, kx = t - 3 * ky;
+#pragma unroll
+                for (int h = 0; h < kMaxHeads; ++h) {
+                    if (h >= P.nheads || !P.h[h].gx[0]) continue;
+                    float4 c4;
+                    if (r < P.cap) c4 = reinterpret_cast<const float4*>(P.stage)[((size_t)e * kMaxHeads + h) * P.cv + v];
+                    else {
+                        const int ga = __builtin_amdgcn_readfirstlane(P.pos[r]);
+                        const int a = ga - (ga / P.An) * P.An;
+                        c4 = pair_contrib(P.h[h], P.h[h].rows + (size_t)ga * P.h[h].no, (a - L.first) % P.A, ky, kx, v);
+                    }
+                    acc[h].x += c4.x; acc[h].y += c4.y; acc[h].z += c4.z; acc[h].w += c4.w;
                 }
             }
         }
@@ -156,27 +292,28 @@ __global__ __launch_bounds__(kT) void rh_dw_kernel(const GP P) {
     __shared__ int s_ga[kRowChunk];
     __shared__ int s_wave[kT / 64];
     __shared__ float s_sum[kT / 64][4];
-    extern __shared__ __align__(16) float s_g[];                        // [kRowChunk][4]  the rows' gradients of this workgroup's four channels
+    extern __shared__ __align__(16) float s_dyn[];
+    float* s_g = s_dyn;                                                 // [kRowChunk][4]  the rows' gradients of this workgroup's four channels
+    float4* s_part = reinterpret_cast<float4*>(s_dyn + kRowChunk * 4);  // [4 waves][4 channels][64 lanes]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, bid = blockIdx.x;
     int hi = 0;
     for (int i = 1; i < P.nheads; ++i) if (bid >= P.h[i].dw_blk0) hi = i;
     const HeadP& Hd = P.h[hi];
-    const int local = bid - Hd.dw_blk0, k = local / Hd.chunks, c0 = (local - k * Hd.chunks) * 4;
+    int local = bid - Hd.dw_blk0;
+    const int tap = local % 9; local /= 9;
+    const int k = local / Hd.chunks, c0 = (local - k * Hd.chunks) * 4;
     const int ncc = Hd.no - c0 < 4 ? Hd.no - c0 : 4;                    // live channels of this chunk
+    const int ky = tap / 3, kx = tap - 3 * ky;
     const int n = *P.num_pos;
     const float f = P.upstream ? *P.upstream : 1.0f;
-    // taps of this wave: wv, wv + 4, wv + 8 (< 9)
-    int tap[3], ntap = 0;
-    for (int t = wv; t < 9; t += 4) tap[ntap++] = t;
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
     for (int v0 = 0; v0 < P.cv; v0 += 64) {
         const int v = v0 + lane;
         const bool ok = v < P.cv;
-        float4 acc[3][4];
+        const int vc = ok ? v : P.cv - 1;
+        float4 acc[4];
 #pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[t][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c = 0; c < 4; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int r0 = 0; r0 < n; r0 += kRowChunk) {
             // ---- rows of anchor k in [r0, r0 + kRowChunk), ascending, into LDS (ballot compaction)
             int base = 0;
@@ -204,59 +341,57 @@ __global__ __launch_bounds__(kT) void rh_dw_kernel(const GP P) {
                 float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
                 gv.x = g[0]; if (ncc > 1) gv.y = g[1]; if (ncc > 2) gv.z = g[2]; if (ncc > 3) gv.w = g[3];
                 reinterpret_cast<float4*>(s_g)[i] = gv;
-                if (v0 == 0) { bsum[0] += gv.x; bsum[1] += gv.y; bsum[2] += gv.z; bsum[3] += gv.w; }
+                if (v0 == 0 && tap == 0) { bsum[0] += gv.x; bsum[1] += gv.y; bsum[2] += gv.z; bsum[3] += gv.w; }
             }
             __syncthreads();
-            if (Hd.gw && ok) {
-                for (int i0 = 0; i0 < cnt; i0 += 4) {                           // four rows at a time: up to twelve X vectors in flight
-                    float4 xv[4][3];
+            if (Hd.gw) {
+                // wave wv: rows wv, wv + 4, ... of the list, eight at a time (unconditional loads: out-of-image taps and the ragged end read
+                // a valid address and are masked by a zero gradient)
+                for (int i0 = wv; i0 < cnt; i0 += 32) {
+                    float4 xv[8]; float4 gv[8];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int i = i0 + u < cnt ? i0 + u : cnt - 1;            // clamped (unconditional loads); masked below
-                        const int ga = s_ga[i], b = ga / P.An, a = ga - b * P.An;
+                    for (int u = 0; u < 8; ++u) {
+                        const int i = i0 + 4 * u;
+                        const bool live = i < cnt;
+                        const int ga = s_ga[live ? i : i0], b = ga / P.An, a = ga - b * P.An;
                         int l, cell, kk; decode_anchor(P, a, l, cell, kk);
                         const Level L = P.lv[l];
-                        const int y = cell / L.W, x = cell - y * L.W;
-#pragma unroll
-                        for (int t = 0; t < 3; ++t) {
-                            xv[u][t] = make_float4(0.f, 0.f, 0.f, 0.f);
-                            if (t < ntap) {
-                                const int ky = tap[t] / 3, kx = tap[t] - 3 * ky, yy = y + ky - 1, xx = x + kx - 1;
-                                if (yy >= 0 && yy < L.H && xx >= 0 && xx < L.W)
-                                    xv[u][t] = reinterpret_cast<const float4*>(Hd.x[l])[((size_t)b * L.HW + yy * L.W + xx) * P.cv + v];
-                            }
-                        }
+                        const int y = cell / L.W, x = cell - y * L.W, yy = y + ky - 1, xx = x + kx - 1;
+                        const bool in = yy >= 0 && yy < L.H && xx >= 0 && xx < L.W;
+                        const size_t prow = (size_t)b * L.HW + (in ? yy * L.W + xx : cell);
+                        xv[u] = reinterpret_cast<const float4*>(Hd.x[l])[prow * P.cv + vc];
+                        gv[u] = (live && in) ? reinterpret_cast<const float4*>(s_g)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        if (i0 + u >= cnt) break;
-                        const float4 gv = reinterpret_cast<const float4*>(s_g)[i0 + u];
-                        const float gc[4] = {gv.x, gv.y, gv.z, gv.w};
+                    for (int u = 0; u < 8; ++u) {
+                        const float gc[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
 #pragma unroll
-                        for (int t = 0; t < 3; ++t)
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) {
-                                acc[t][c].x += gc[c] * xv[u][t].x; acc[t][c].y += gc[c] * xv[u][t].y;
-                                acc[t][c].z += gc[c] * xv[u][t].z; acc[t][c].w += gc[c] * xv[u][t].w;
-                            }
+                        for (int c = 0; c < 4; ++c) {
+                            acc[c].x += gc[c] * xv[u].x; acc[c].y += gc[c] * xv[u].y; acc[c].z += gc[c] * xv[u].z; acc[c].w += gc[c] * xv[u].w;
+                        }
                     }
                 }
             }
             __syncthreads();                                                    // the next chunk overwrites the lists
         }
-        if (Hd.gw && ok) {
-            for (int t = 0; t < ntap; ++t) {
-                const int ky = tap[t] / 3, kx = tap[t] - 3 * ky;
+        if (Hd.gw) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s_part[(wv * 4 + c) * 64 + lane] = acc[c];
+            __syncthreads();
+            if (wv == 0 && ok) {
                 for (int c = 0; c < ncc; ++c) {
+                    float4 t = s_part[c * 64 + lane];
+                    for (int w = 1; w < kT / 64; ++w) { const float4 u = s_part[(w * 4 + c) * 64 + lane]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
                     const long long off = (long long)(k * Hd.no + c0 + c) * Hd.ws_o + ky * Hd.ws_ky + kx * Hd.ws_kx + (long long)(4 * v) * Hd.ws_i;
-                    const float4 o = make_float4(acc[t][c].x * f, acc[t][c].y * f, acc[t][c].z * f, acc[t][c].w * f);
+                    const float4 o = make_float4(t.x * f, t.y * f, t.z * f, t.w * f);
                     if (Hd.ws_i == 1) *reinterpret_cast<float4*>(Hd.gw + off) = o;
                     else { Hd.gw[off] = o.x; Hd.gw[off + Hd.ws_i] = o.y; Hd.gw[off + 2 * Hd.ws_i] = o.z; Hd.gw[off + 3 * Hd.ws_i] = o.w; }
                 }
             }
+            __syncthreads();
         }
     }
-    if (Hd.gb) {                                                                // bias: the same rows without X (fixed tree + wave order)
+    if (Hd.gb && tap == 0) {                                                    // bias: the same rows without X (fixed tree + wave order)
 #pragma unroll
         for (int c = 0; c < 4; ++c) bsum[c] = wave_sum(bsum[c]);
         if (lane == 0) { for (int c = 0; c < 4; ++c) s_sum[wv][c] = bsum[c]; }
@@ -273,7 +408,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 bool valid(const odpl_retina_heads_desc_t* d, int n, const odpl_retina_head_t* h, long long* npix_img, long long* An) {
     if (!d || !h || n < 1 || n > kMaxHeads) return false;
-    if (d->B < 1 || d->A < 1 || d->A > 64 || d->Cin < 4 || (d->Cin & 3) || d->nlevels < 1 || d->nlevels > ODPL_RETINA_LEVELS) return false;
+    if (d->B < 1 || d->A < 1 || d->A > 64 || d->Cin < 4 || (d->Cin & 3) || d->Cin > 448 || d->nlevels < 1 || d->nlevels > ODPL_RETINA_LEVELS) return false;      // Cin: the pair launch's LDS slab
     if (!d->pos_anchor || !d->num_pos) return false;
     long long pix = 0;
     for (int l = 0; l < d->nlevels; ++l) { if (d->H[l] < 1 || d->W[l] < 1) return false; pix += (long long)d->H[l] * d->W[l]; }
@@ -293,7 +428,7 @@ bool valid(const odpl_retina_heads_desc_t* d, int n, const odpl_retina_head_t* h
 extern "C" size_t odpl_retina_heads_backward_workspace_bytes(const odpl_retina_heads_desc_t* d, int32_t n, const odpl_retina_head_t* h) {
     long long pix, An;
     if (!valid(d, n, h, &pix, &An)) return 0;
-    return 2 * align_up((size_t)pix * d->B * sizeof(int), 256);
+    return 2 * align_up((size_t)pix * d->B * sizeof(int), 256) + (size_t)g_stage_rows * 9 * kMaxHeads * d->Cin * sizeof(float);
 }
 
 extern "C" int odpl_retina_heads_backward(const odpl_retina_heads_desc_t* d, int32_t n, const odpl_retina_head_t* heads,
@@ -312,8 +447,11 @@ extern "C" int odpl_retina_heads_backward(const odpl_retina_heads_desc_t* d, int
         P.lv[l].H = d->H[l]; P.lv[l].W = d->W[l]; P.lv[l].HW = d->H[l] * d->W[l]; P.lv[l].first = first; P.lv[l].pix0 = pix0;
         first += P.lv[l].HW * d->A; pix0 += P.lv[l].HW;
     }
+    const size_t map_bytes = align_up((size_t)pix * d->B * sizeof(int), 256);
     P.map_first = (int*)workspace;
-    P.map_cnt = (int*)((char*)workspace + need / 2);
+    P.map_cnt = (int*)((char*)workspace + map_bytes);
+    P.stage = (float*)((char*)workspace + 2 * map_bytes);
+    P.cap = g_stage_rows;
     int ndw = 0;
     bool want_x = false;
     for (int i = 0; i < n; ++i) {
@@ -326,19 +464,40 @@ extern "C" int odpl_retina_heads_backward(const odpl_retina_heads_desc_t* d, int
         H.ws_o = heads[i].w_stride[0]; H.ws_i = heads[i].w_stride[1]; H.ws_ky = heads[i].w_stride[2]; H.ws_kx = heads[i].w_stride[3];
         if (H.ws_i == 1 && ((((uintptr_t)H.w | (uintptr_t)H.gw) & 15) || (H.ws_o & 3) || (H.ws_ky & 3) || (H.ws_kx & 3))) return ODPL_EINVAL;
         H.no = heads[i].no; H.chunks = (H.no + 3) / 4;
-        H.dw_blk0 = ndw; H.dw_nblk = (H.gw || H.gb) ? d->A * H.chunks : 0; ndw += H.dw_nblk;
+        H.dw_blk0 = ndw; H.dw_nblk = (H.gw || H.gb) ? d->A * H.chunks * 9 : 0; ndw += H.dw_nblk;
         want_x |= H.gx[0] != nullptr;
     }
-    ODPL_HIP_TRY(odpl::fill_bytes(P.map_cnt, 0, need / 2, stream));
+    ODPL_HIP_TRY(odpl::fill_bytes(P.map_cnt, 0, map_bytes, stream));
     hipLaunchKernelGGL(rh_map_kernel, dim3(256), dim3(kT), 0, stream, P);
     ODPL_HIP_TRY(hipGetLastError());
     if (want_x) {
+        static size_t lds_allowed = 64 * 1024;
+        for (int i = 0; i < n; ++i) {
+            if (!P.h[i].gx[0]) continue;
+            const int slab = P.h[i].no < kSlabRows ? P.h[i].no : kSlabRows;
+            const size_t lds_pair = ((size_t)slab * P.cv * 4 + 16 * kSlabRows) * sizeof(float);
+            if (lds_pair > 150 * 1024) return ODPL_EINVAL;          // Cin <= 448 with 80-row slabs (valid() checks it)
+            if (lds_pair > lds_allowed) {
+                ODPL_HIP_TRY(hipFuncSetAttribute((const void*)rh_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pair));
+                lds_allowed = lds_pair;
+            }
+            P.pair_head = i;
+            hipLaunchKernelGGL(rh_pair_kernel, dim3(d->A * 9 * kPairSlots), dim3(kT), lds_pair, stream, P);
+            ODPL_HIP_TRY(hipGetLastError());
+        }
         hipLaunchKernelGGL(rh_dx_kernel, dim3((unsigned)((P.npix + 3) / 4)), dim3(kT), 0, stream, P);
         ODPL_HIP_TRY(hipGetLastError());
     }
     if (ndw > 0) {
-        hipLaunchKernelGGL(rh_dw_kernel, dim3(ndw), dim3(kT), (size_t)kRowChunk * 4 * sizeof(float), stream, P);
+        hipLaunchKernelGGL(rh_dw_kernel, dim3(ndw), dim3(kT), (size_t)kRowChunk * 4 * sizeof(float) + (size_t)16 * 64 * sizeof(float4), stream, P);
         ODPL_HIP_TRY(hipGetLastError());
     }
+    return 0;
+}
+
+// rows with staging slots in the workspace (default 4096; tests use a handful to exercise the in-place path of the dx launch)
+extern "C" int odpl_retina_heads_tune(int32_t stage_rows) {
+    if (stage_rows < 1 || stage_rows > (1 << 16)) return ODPL_EINVAL;
+    g_stage_rows = stage_rows;
     return 0;
 }

@@ -39,7 +39,8 @@ def _ref_forward(xl, xc, wl, bl, wc, bc, C):
     return loc, cls
 
 
-@pytest.mark.parametrize("wh,cin,C,B,weights_cl", [((128, 128), 16, 5, 2, True), ((160, 96), 24, 3, 3, False), ((256, 256), 256, 80, 2, True)])
+@pytest.mark.parametrize("wh,cin,C,B,weights_cl", [((128, 128), 16, 5, 2, True), ((160, 96), 24, 3, 3, False), ((256, 256), 256, 80, 2, True),
+                                                   ((1333, 800), 256, 80, 4, True)])     # the last: BASELINE config 4 at full size (200 700 anchors)
 def test_structured_backward_equals_dense_route_and_oracle(wh, cin, C, B, weights_cl):
     from objectdetectionpl_amd import _lib
     from objectdetectionpl_amd.LightningFunc.losses_dense import RetinaNetLoss, focal_loss
@@ -53,7 +54,7 @@ def test_structured_backward_equals_dense_route_and_oracle(wh, cin, C, B, weight
     xc = [torch.randn(B, cin, h, w, generator=g) * 0.5 for h, w in levels]
     torch.manual_seed(1)
     loc_conv, cls_conv = nn.Conv2d(cin, 36, 3, 1, 1), nn.Conv2d(cin, 9 * C, 3, 1, 1)
-    tgt = _targets(g, B, 3, C)
+    tgt = _targets(g, B, 8 if wh[0] > 1000 else 3, C)
     crit = RetinaNetLoss(anchors, focal_loss, "smooth_l1_loss", C, wh if wh[0] != wh[1] else wh[0])
 
     def run(fused, scale=1.0):
@@ -78,8 +79,8 @@ def test_structured_backward_equals_dense_route_and_oracle(wh, cin, C, B, weight
     of, xf, pf, (locf, clsf) = run(True)
     od, xd, pd, _ = run(False)
     assert int(crit.last_counts[0]) > 0, "no positive anchor: the test would be vacuous"
-    for k in of:
-        assert of[k].item() == od[k].item()
+    for k in of:                                                       # (the 256-channel forward convolutions are not run-to-run identical)
+        assert of[k].item() == od[k].item() or (cin >= 256 and abs(of[k].item() - od[k].item()) <= 1e-6 * abs(od[k].item()))
     for a, b in zip(xf, xd):
         assert a.grad.stride() == a.stride()
         _close(a.grad, b.grad)
@@ -90,9 +91,12 @@ def test_structured_backward_equals_dense_route_and_oracle(wh, cin, C, B, weight
     o3, x3, p3, _ = run(True, 2.5)
     for a, b in zip(x3 + p3, xf + pf):
         _close(a.grad, b.grad * 2.5, 1e-5, 1e-6)
-    o4, x4, p4, _ = run(True)
-    for a, b in zip(x4 + p4, xf + pf):
-        assert torch.equal(a.grad, b.grad)
+    o4, x4, p4, (loc4, cls4) = run(True)
+    if torch.equal(loc4, locf) and torch.equal(cls4, clsf):            # (MIOpen's forward convolution is not always run-to-run identical)
+        for a, b in zip(x4 + p4, xf + pf):
+            assert torch.equal(a.grad, b.grad)
+    else:
+        assert cin >= 256, "the small forward convolutions are deterministic"
     # the oracle, end to end on the CPU
     xlc, xcc = [x.clone().requires_grad_() for x in xl], [x.clone().requires_grad_() for x in xc]
     wl, bl, wc, bc = (t.detach().clone().requires_grad_() for t in (loc_conv.weight, loc_conv.bias, cls_conv.weight, cls_conv.bias))
@@ -107,6 +111,38 @@ def test_structured_backward_equals_dense_route_and_oracle(wh, cin, C, B, weight
             _close(a.grad, b.grad)
         for a, b in zip(pf, (wl, bl, wc, bc)):
             _close(a.grad, b.grad)
+
+
+def test_more_positive_rows_than_staging_slots():
+    """With 5 staging slots every later row's contribution is summed in place by the dx launch: same numbers as with slots for all."""
+    from objectdetectionpl_amd import _lib
+    from objectdetectionpl_amd.LightningFunc.losses_dense import RetinaNetLoss, focal_loss
+    from objectdetectionpl_amd.LightningFunc.utils import retinahead as rh
+    from objectdetectionpl_amd.LightningFunc.utils.RetinaUtils import get_anchor_boxes
+    g = torch.Generator().manual_seed(4)
+    wh, cin, C, B = (128, 128), 16, 5, 2
+    anchors = get_anchor_boxes(torch.Tensor(list(wh)), torch.device(DEV))
+    xl = [(torch.randn(B, cin, h, w, generator=g) * 0.5).to(DEV).contiguous(memory_format=torch.channels_last) for h, w in _levels(*wh)]
+    xc = [(torch.randn(B, cin, h, w, generator=g) * 0.5).to(DEV).contiguous(memory_format=torch.channels_last) for h, w in _levels(*wh)]
+    torch.manual_seed(1)
+    lc, cc = nn.Conv2d(cin, 36, 3, 1, 1).to(DEV), nn.Conv2d(cin, 9 * C, 3, 1, 1).to(DEV)
+    tgt = _targets(g, B, 3, C).to(DEV)
+    crit = RetinaNetLoss(anchors, focal_loss, "smooth_l1_loss", C, 128)
+    res = []
+    try:
+        for rows in (4096, 5):
+            _lib.check(_lib.lib().odpl_retina_heads_tune(rows), "tune")
+            a = [x.clone().requires_grad_() for x in xl + xc]
+            for p in list(lc.parameters()) + list(cc.parameters()):
+                p.grad = None
+            loc, cls = rh.final_convs(lc, cc, a[:5], a[5:])
+            crit((loc, cls), tgt)["loss"].backward()
+            assert int(crit.last_counts[0]) > 5
+            res.append([t.grad.clone() for t in a] + [lc.weight.grad.clone(), cc.weight.grad.clone()])
+    finally:
+        _lib.lib().odpl_retina_heads_tune(4096)
+    for u, v in zip(*res):
+        assert torch.equal(u, v)
 
 
 def test_retinanet_model_takes_the_structured_route():
@@ -135,7 +171,7 @@ def test_retinanet_model_takes_the_structured_route():
             finally:
                 RetinaNetLoss.fuse_head_backward = True
             res.append((d["loss"].item(), {n: p.grad.clone() for n, p in model.named_parameters() if n.startswith(("loc_head.8", "cls_head.8"))}))
-        assert res[0][0] == res[1][0] and len(res[0][1]) == 4
+        assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[1][0]) and len(res[0][1]) == 4      # (two MIOpen forward passes, not always identical)
         for n in res[0][1]:
             _close(res[0][1][n], res[1][1][n], 1e-3, 1e-4)
         assert all(p.grad is not None for p in model.parameters())
