@@ -195,9 +195,10 @@ def cpu_baseline(B_sample, C, img, steps, warmup=1):
 
 def rocprof_row(kernel):
     """Average duration of `kernel` in the committed `rocprofv3 --kernel-trace --stats` summary of this command
-    (profiles/r02_rocprof_stats_bench.csv), so the live event timing and the profiler's figure sit side by side."""
+    (profiles/r03_rocprof_stats_bench.csv; the dense route's expand kernel: the round-2 pass of `--no-fused-head-backward`), so the live
+    event timing and the profiler's figure sit side by side."""
     import csv
-    for name in ("r02_rocprof_stats_bench.csv", "r02dense_rocprof_stats_bench.csv"):
+    for name in ("r03_rocprof_stats_bench.csv", "r02dense_rocprof_stats_bench.csv"):
         try:
             with open(os.path.join(REPO, "profiles", name)) as f:
                 for row in csv.DictReader(f):
@@ -210,10 +211,10 @@ def rocprof_row(kernel):
 
 def conv_portion(batch):
     """MFMA utilisation of the convolution portion, reported separately -- from the committed steady-state table of
-    this command under rocprofv3 (profiles/r02_bench_steady_state.csv): MIOpen / CK / Tensile kernel time per step against
+    this command under rocprofv3 (profiles/r03_bench_steady_state.csv): MIOpen / CK / Tensile kernel time per step against
     3 x 2 x 30.05 GMAC per image (forward + two backward products, SURVEY a-21) and the 157.3 TFLOP/s fp32 MFMA peak."""
     import csv
-    path = os.path.join(REPO, "profiles", "r02_bench_steady_state.csv")
+    path = os.path.join(REPO, "profiles", "r03_bench_steady_state.csv")
     try:
         with open(path) as f:
             head = f.readline()
@@ -222,7 +223,7 @@ def conv_portion(batch):
         ms = us / steps / 1e3
         tf = 3 * 2 * 30.05e9 * batch / (ms * 1e-3) / 1e12
         return {"ms_per_step": round(ms, 3), "tflops": round(tf, 1), "frac_of_fp32_mfma_peak": round(tf / 157.3, 3),
-                "source": "profiles/r02_bench_steady_state.csv (committed rocprofv3 pass of this command at bs 16; not re-measured in this run)"}
+                "source": "profiles/r03_bench_steady_state.csv (committed rocprofv3 pass of this command at bs 16; not re-measured in this run)"}
     except Exception:  # noqa: BLE001
         return None
 
