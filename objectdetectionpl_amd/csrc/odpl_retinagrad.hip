@@ -208,81 +208,99 @@ __global__ __launch_bounds__(kT) void rh_pair_kernel(const GP P) {
     }
 }
 
+// The dense dX writer.  A wave owns kPixPerWave consecutive level pixels; lane 9 p + t looks up the map entry that reaches pixel p through
+// tap t, so ONE trip to memory tells the wave which of its pixels anything reaches (almost none: those rows are streamed as zeros, 2 heads x
+// Cin floats each); the others list their staging slots in (tap, row) order and sum them eight in flight per head.
+constexpr int kPixPerWave = 7;
+
 __global__ __launch_bounds__(kT) void rh_dx_kernel(const GP P) {
-    __shared__ int s_list[kT / 64][96];                                // per wave: the staging slots (r * 9 + tap) that reach its pixel
+    __shared__ int s_list[kT / 64][96];                                // per wave: the staging slots (r * 9 + tap) that reach the current pixel
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int pix = blockIdx.x * (kT / 64) + wv;                       // wave = one level pixel (wave-uniform from here on)
-    if (pix >= P.npix) return;
-    int l = 0;
-    for (int i = 1; i < P.nlevels; ++i) if (pix >= P.B * P.lv[i].pix0) l = i;
-    const Level L = P.lv[l];
-    const int rel = pix - P.B * L.pix0, b = rel / L.HW, cell = rel - b * L.HW, y = cell / L.W, x = cell - y * L.W;
+    const int pix0 = (blockIdx.x * (kT / 64) + wv) * kPixPerWave;      // wave-uniform
+    if (pix0 >= P.npix) return;
     const float f = P.upstream ? *P.upstream : 1.0f;
-    // the 3 x 3 neighbourhood's map entries first: almost every pixel finds nothing and streams zeros.  The others list their staging
-    // slots in (tap, row) order -- every lane writes the same list; rows without a slot (r >= cap) send the pixel down the in-place path
-    int M = 0; bool unstaged = false;
-    int* list = s_list[wv];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const int ky = t / 3, kx = t - 3 * ky, yp = y - ky + 1, xp = x - kx + 1;      // the positive at (yp, xp) reaches (y, x) through tap (ky, kx)
-        if (yp >= 0 && yp < L.H && xp >= 0 && xp < L.W) {
-            const int s = map_slot(P, l, b, yp * L.W + xp);
-            const int m = P.map_cnt[s];
-            if (m) {
-                const int f0 = P.map_first[s];
-                for (int j = 0; j < m && M < 96; ++j) { list[M++] = (f0 + j) * 9 + t; unstaged |= f0 + j >= P.cap; }
+    // ---- lane 9 p + t: map entry of the cell whose positives reach pixel pix0 + p through tap t
+    int my_cnt = 0, my_fst = 0;
+    {
+        const int p = lane / 9, t = lane - 9 * p, pix = pix0 + p;
+        if (p < kPixPerWave && pix < P.npix) {
+            int l = 0;
+            for (int i = 1; i < P.nlevels; ++i) if (pix >= P.B * P.lv[i].pix0) l = i;
+            const Level L = P.lv[l];
+            const int rel = pix - P.B * L.pix0, b = rel / L.HW, cell = rel - b * L.HW, y = cell / L.W, x = cell - y * L.W;
+            const int ky = t / 3, kx = t - 3 * ky, yp = y - ky + 1, xp = x - kx + 1;
+            if (yp >= 0 && yp < L.H && xp >= 0 && xp < L.W) {
+                const int s = map_slot(P, l, b, yp * L.W + xp);
+                my_cnt = P.map_cnt[s];
+                if (my_cnt) my_fst = P.map_first[s];
             }
         }
     }
-    const size_t row = ((size_t)b * L.HW + cell) * P.cv;
-    for (int v0 = 0; v0 < P.cv; v0 += 64) {
-        const int v = v0 + lane;
-        const bool ok = v < P.cv;
-        const int vc = ok ? v : P.cv - 1;
-        float4 acc[kMaxHeads];
-#pragma unroll
-        for (int h = 0; h < kMaxHeads; ++h) acc[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (M && !unstaged) {
-            // eight staged contributions per head in flight (unconditional loads clamped to the list's last entry), added in list order
-            for (int i0 = 0; i0 < M; i0 += 8) {
-                float4 c4[kMaxHeads][8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int e = list[i0 + u < M ? i0 + u : M - 1];
-#pragma unroll
-                    for (int h = 0; h < kMaxHeads; ++h)
-                        c4[h][u] = (h < P.nheads && P.h[h].gx[0]) ? reinterpret_cast<const float4*>(P.stage)[((size_t)e * kMaxHeads + h) * P.cv + vc] : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (i0 + u < M) {
-#pragma unroll
-                        for (int h = 0; h < kMaxHeads; ++h) { acc[h].x += c4[h][u].x; acc[h].y += c4[h][u].y; acc[h].z += c4[h][u].z; acc[h].w += c4[h][u].w; }
-                    }
+    const unsigned long long hit = __ballot(my_cnt != 0);
+    int* list = s_list[wv];
+    for (int p = 0; p < kPixPerWave; ++p) {
+        const int pix = pix0 + p;
+        if (pix >= P.npix) break;                                      // uniform
+        int l = 0;
+        for (int i = 1; i < P.nlevels; ++i) if (pix >= P.B * P.lv[i].pix0) l = i;
+        const Level L = P.lv[l];
+        const size_t row = (size_t)(pix - P.B * L.pix0) * P.cv;        // (b * HW + cell) * cv inside the level's tensor
+        int M = 0; bool unstaged = false;
+        if ((hit >> (9 * p)) & 0x1ffull) {                             // something reaches this pixel: list its slots in (tap, row) order
+            for (int t = 0; t < 9; ++t) {
+                const int m = __shfl(my_cnt, 9 * p + t, 64), f0 = __shfl(my_fst, 9 * p + t, 64);
+                for (int j = 0; j < m && M < 96; ++j) { list[M++] = (f0 + j) * 9 + t; unstaged |= f0 + j >= P.cap; }
             }
-        } else if (M && ok) {
-            for (int i = 0; i < M; ++i) {                              // more rows than staging slots: in place (same arithmetic per contribution)
-                const int e = list[i], r = e / 9, t = e - 9 * r, ky = t / 3, kx = t - 3 * ky;
+        }
+        for (int v0 = 0; v0 < P.cv; v0 += 64) {
+            const int v = v0 + lane;
+            const bool ok = v < P.cv;
+            const int vc = ok ? v : P.cv - 1;
+            float4 acc[kMaxHeads];
+#pragma unroll
+            for (int h = 0; h < kMaxHeads; ++h) acc[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (M && !unstaged) {
+                // eight staged contributions per head in flight (unconditional loads clamped to the list's last entry), added in list order
+                for (int i0 = 0; i0 < M; i0 += 8) {
+                    float4 c4[kMaxHeads][8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int e = list[i0 + u < M ? i0 + u : M - 1];
+#pragma unroll
+                        for (int h = 0; h < kMaxHeads; ++h)
+                            c4[h][u] = (h < P.nheads && P.h[h].gx[0]) ? reinterpret_cast<const float4*>(P.stage)[((size_t)e * kMaxHeads + h) * P.cv + vc] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (i0 + u < M) {
+#pragma unroll
+                            for (int h = 0; h < kMaxHeads; ++h) { acc[h].x += c4[h][u].x; acc[h].y += c4[h][u].y; acc[h].z += c4[h][u].z; acc[h].w += c4[h][u].w; }
+                        }
+                }
+            } else if (M && ok) {
+                for (int i = 0; i < M; ++i) {                          // more rows than staging slots: in place (same arithmetic per contribution)
+                    const int e = list[i], r = e / 9, t = e - 9 * r, ky = t / 3, kx = t - 3 * ky;
+#pragma unroll
+                    for (int h = 0; h < kMaxHeads; ++h) {
+                        if (h >= P.nheads || !P.h[h].gx[0]) continue;
+                        float4 c4;
+                        if (r < P.cap) c4 = reinterpret_cast<const float4*>(P.stage)[((size_t)e * kMaxHeads + h) * P.cv + v];
+                        else {
+                            const int ga = __builtin_amdgcn_readfirstlane(P.pos[r]);
+                            const int a = ga - (ga / P.An) * P.An;
+                            c4 = pair_contrib(P.h[h], P.h[h].rows + (size_t)ga * P.h[h].no, (a - L.first) % P.A, ky, kx, v);
+                        }
+                        acc[h].x += c4.x; acc[h].y += c4.y; acc[h].z += c4.z; acc[h].w += c4.w;
+                    }
+                }
+            }
+            if (ok) {
 #pragma unroll
                 for (int h = 0; h < kMaxHeads; ++h) {
                     if (h >= P.nheads || !P.h[h].gx[0]) continue;
-                    float4 c4;
-                    if (r < P.cap) c4 = reinterpret_cast<const float4*>(P.stage)[((size_t)e * kMaxHeads + h) * P.cv + v];
-                    else {
-                        const int ga = __builtin_amdgcn_readfirstlane(P.pos[r]);
-                        const int a = ga - (ga / P.An) * P.An;
-                        c4 = pair_contrib(P.h[h], P.h[h].rows + (size_t)ga * P.h[h].no, (a - L.first) % P.A, ky, kx, v);
-                    }
-                    acc[h].x += c4.x; acc[h].y += c4.y; acc[h].z += c4.z; acc[h].w += c4.w;
+                    const v4f o = {acc[h].x * f, acc[h].y * f, acc[h].z * f, acc[h].w * f};
+                    __builtin_nontemporal_store(o, reinterpret_cast<v4f*>(P.h[h].gx[l]) + row + v);     // a pure write stream
                 }
-            }
-        }
-        if (ok) {
-#pragma unroll
-            for (int h = 0; h < kMaxHeads; ++h) {
-                if (h >= P.nheads || !P.h[h].gx[0]) continue;
-                const v4f o = {acc[h].x * f, acc[h].y * f, acc[h].z * f, acc[h].w * f};
-                __builtin_nontemporal_store(o, reinterpret_cast<v4f*>(P.h[h].gx[l]) + row + v);     // a pure write stream
             }
         }
     }
@@ -485,7 +503,8 @@ extern "C" int odpl_retina_heads_backward(const odpl_retina_heads_desc_t* d, int
             hipLaunchKernelGGL(rh_pair_kernel, dim3(d->A * 9 * kPairSlots), dim3(kT), lds_pair, stream, P);
             ODPL_HIP_TRY(hipGetLastError());
         }
-        hipLaunchKernelGGL(rh_dx_kernel, dim3((unsigned)((P.npix + 3) / 4)), dim3(kT), 0, stream, P);
+        const int dx_waves = (P.npix + kPixPerWave - 1) / kPixPerWave;
+        hipLaunchKernelGGL(rh_dx_kernel, dim3((unsigned)((dx_waves + kT / 64 - 1) / (kT / 64))), dim3(kT), 0, stream, P);
         ODPL_HIP_TRY(hipGetLastError());
     }
     if (ndw > 0) {
