@@ -581,6 +581,12 @@ int odpl_bn_act_backward_strided(const void* x, const void* grad_y, int64_t gy_r
                                  int32_t training, int32_t act, void* grad_x, float* grad_gamma, float* grad_beta,
                                  void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- PROBE (not used by the models: ties MIOpen, see csrc/odpl_gemm1x1.hip): 1x1 stride-1 convolutions on channels-last fp32 tensors as
+ * GEMMs on the fp32 matrix cores.  The Conv2d(Cin, Cout, 1) layers of the caller networks (utils/YoloV4Utils.py:208-236 Conv_Bn_Activation with kernel_size 1): x [M = N*H*W, Cin],
+ * w [Cout, Cin] (a 1x1 weight in either memory format), y [M, Cout].  tile: 0 = by shape, 64 or 128. */
+int odpl_conv1x1_forward(const float* x, const float* w, float* y, int64_t M, int32_t Cin, int32_t Cout, int32_t tile, void* stream);
+int odpl_conv1x1_backward_data(const float* dy, const float* w, float* dx, int64_t M, int32_t Cin, int32_t Cout, int32_t tile, void* stream);
+
 /* launch-geometry knobs (process-wide; defaults are the tuned values) */
 #define ODPL_TUNE_YOLO_FILL_F4_PER_BLOCK 0
 #define ODPL_TUNE_YOLO_FILL_NT 1

@@ -190,6 +190,8 @@ SIGNATURES = {
     "odpl_bn_act_backward": (c_int32, [c_void_p, c_void_p, ctypes.c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "odpl_tune_set": (c_int32, [c_int32, c_int32]),
+    "odpl_conv1x1_forward": (c_int32, [c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_int32, c_int32, c_int32, c_void_p]),
+    "odpl_conv1x1_backward_data": (c_int32, [c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_int32, c_int32, c_int32, c_void_p]),
     "odpl_bn_fused_stats": (c_int32, [POINTER(c_int32)]),
     "odpl_bn_fused_debug_stamps": (c_int32, [c_int32, c_void_p, c_int32]),
     "odpl_scale_inplace_if_not_one_bf16": (c_int32, [c_void_p, c_size_t, c_void_p, c_void_p]),
