@@ -340,6 +340,21 @@ int odpl_retina_heads_backward(const odpl_retina_heads_desc_t* desc, int32_t n_h
  * dx launch -- same arithmetic, slower.  Call before querying the workspace size. */
 int odpl_retina_heads_tune(int32_t stage_rows);
 
+/* ---- backward of a 3x3 (stride 1, pad 1, ungrouped) convolution over the pixels that carry a gradient (csrc/odpl_sparseconv.hip) ----
+ * The head towers of model/RetinaNet.py:93-99 receive a gradient that is zero on most pixels (it spreads one pixel per layer from the
+ * positive anchors).  `active` [B*H*W] bytes: non-zero where the row of grad_y may be non-zero (odpl_bias_act_backward_flags emits it);
+ * rows flagged inactive MUST be zero in grad_y.  grad_x is fully written (zero away from the active pixels' neighbourhoods), grad_w has
+ * the strides of w; either may be NULL.  What aten::convolution_backward computes, on the active pixels only; no float atomics.
+ * x / grad_x: channels-last [B, H, W, Cin], grad_y: [B, H, W, Cout], fp32; Cin, Cout multiples of 64. */
+typedef struct {
+    const float* x; const float* gy; const uint8_t* active; const float* w;
+    float* grad_x; float* grad_w;
+    int64_t w_stride[4];                     /* element strides of w / grad_w along (o, i, ky, kx) */
+    int32_t B, H, W, Cin, Cout;
+} odpl_sparse_conv3x3_t;
+size_t odpl_sparse_conv3x3_backward_workspace_bytes(const odpl_sparse_conv3x3_t* desc);
+int odpl_sparse_conv3x3_backward(const odpl_sparse_conv3x3_t* desc, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- SSD loss: losses.py:159-315 ---------------------------------------------------------------- */
 
 typedef struct {
@@ -522,6 +537,9 @@ int odpl_bias_act_forward(const float* x, int64_t R, int32_t C, const float* bia
  * (act: ODPL_ACT_LINEAR / _LEAKY / _RELU).  workspace: odpl_bn_act_workspace_bytes(R, C) + 4*C bytes; grad_x may alias grad_y. */
 int odpl_bias_act_backward(const float* y, const float* grad_y, int64_t R, int32_t C, int32_t act, float* grad_x, float* grad_bias,
                            void* workspace, size_t workspace_bytes, void* stream);
+/* the same + `active` [R] bytes: 1 where the row of grad_x holds a non-zero, 0 elsewhere (the pixel map odpl_sparse_conv3x3_backward walks) */
+int odpl_bias_act_backward_flags(const float* y, const float* grad_y, int64_t R, int32_t C, int32_t act, float* grad_x, float* grad_bias,
+                                 uint8_t* active, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Nearest-neighbour 2x upsampling of the necks on DENSE channels-last tensors: utils/YoloV4Utils.py:191-206 (`Upsample`,
  * F.interpolate(size, 'nearest') in training), nn.Upsample(scale_factor=2) of model/YOLOV3.py, utils/YoloV5Utils.py's neck.

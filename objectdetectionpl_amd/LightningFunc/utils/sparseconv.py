@@ -1,0 +1,85 @@
+"""`relu(conv3x3(x) + bias)` whose backward runs over the pixels that carry a gradient (RetinaNet's head towers, `model/RetinaNet.py:93-99`).
+
+forward   the MIOpen convolution + the in-place bias + activation epilogue (`odpl_bias_act_forward`), as `bnact.conv_bias_act`.
+backward  ONE autograd node for conv + bias + activation: `odpl_bias_act_backward_flags` turns grad_y into the convolution's output
+          gradient, the bias gradient and a byte map of the pixels whose gradient row is non-zero; `odpl_sparse_conv3x3_backward`
+          (csrc/odpl_sparseconv.hip) then computes dX and dW over those pixels only, as gathered GEMMs on the fp32 matrix cores.  Behind
+          RetinaNetLoss the gradient spreads one pixel per layer from the positive anchors: a few per cent of the pixels of the two
+          large FPN levels.  A dense gradient is still handled correctly (every pixel active), only slower than the library: the
+          switch `enabled` and the pixel threshold `min_pixels` bound where it is used.
+"""
+import ctypes
+
+import torch
+import torch.nn.functional as F
+
+from ... import _lib
+from .bnact import ACT, _ones_zeros, _workspace
+
+enabled = True            # A/B switch (tools/bench_retina_step.py --dense-tower-backward)
+min_pixels = 8192         # levels with fewer B*H*W pixels keep the library backward (they are 6 % of the towers' arithmetic at config 4)
+_ws2 = {}
+
+
+def applicable(x, conv):
+    return (enabled and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
+            and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is not None
+            and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0 and conv.weight.dtype == torch.float32
+            and x.shape[0] * x.shape[2] * x.shape[3] >= min_pixels and x.shape[2] > 1 and x.shape[3] > 1
+            and x.is_contiguous(memory_format=torch.channels_last) and torch.is_grad_enabled())
+
+
+class _ConvBiasActSparse(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, act):
+        z = F.conv2d(x, w, None, 1, 1)
+        N, C, H, W = z.shape
+        ones, zeros = _ones_zeros(z.device, C)
+        _lib.check(_lib.lib().odpl_bias_act_forward(_lib.ptr(z), N * H * W, C, _lib.ptr(b), _lib.ptr(ones), _lib.ptr(zeros), act, _lib.ptr(z),
+                                                    _lib.current_stream(z.device)), "odpl_bias_act_forward")
+        ctx.save_for_backward(x, w, z)
+        ctx.act = act
+        return z
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        N, C, H, W = y.shape
+        R = N * H * W
+        dev = y.device
+        L = _lib.lib()
+        if gy.dtype != torch.float32 or not gy.is_contiguous(memory_format=torch.channels_last):
+            gy = gy.float().contiguous(memory_format=torch.channels_last)
+        gz = torch.empty_like(y)
+        gb = torch.empty(C, dtype=torch.float32, device=dev)
+        active = torch.empty(R, dtype=torch.uint8, device=dev)
+        need = L.odpl_bn_act_workspace_bytes(R, C) + 4 * C
+        ws = _workspace(dev, need)
+        st = _lib.current_stream(dev)
+        _lib.check(L.odpl_bias_act_backward_flags(_lib.ptr(y), _lib.ptr(gy), R, C, ctx.act, _lib.ptr(gz), _lib.ptr(gb), _lib.ptr(active),
+                                                  _lib.ptr(ws), ws.numel(), st), "odpl_bias_act_backward_flags")
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        gx = torch.empty_like(x) if need_x else None
+        gw = torch.empty_like(w) if need_w else None
+        d = _lib.SparseConv3x3()
+        d.x, d.gy, d.active, d.w = x.data_ptr(), gz.data_ptr(), active.data_ptr(), w.data_ptr()
+        d.grad_x = gx.data_ptr() if gx is not None else None
+        d.grad_w = gw.data_ptr() if gw is not None else None
+        for k in range(4):
+            d.w_stride[k] = w.stride(k)
+        d.B, d.H, d.W, d.Cin, d.Cout = N, H, W, x.shape[1], C
+        nbytes = L.odpl_sparse_conv3x3_backward_workspace_bytes(ctypes.byref(d))
+        if nbytes == 0:
+            raise _lib.OdplError("odpl_sparse_conv3x3_backward_workspace_bytes rejected the descriptor")
+        key = (dev, "sc")
+        ws2 = _ws2.get(key)
+        if ws2 is None or ws2.numel() < nbytes:
+            ws2 = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=dev)
+            _ws2[key] = ws2
+        _lib.check(L.odpl_sparse_conv3x3_backward(ctypes.byref(d), _lib.ptr(ws2), ws2.numel(), st), "odpl_sparse_conv3x3_backward")
+        return gx, gw, gb, None
+
+
+def conv_bias_act(x, conv, act="relu"):
+    """`act(conv(x))` with the sparse backward; callers check `applicable(x, conv)` first."""
+    return _ConvBiasActSparse.apply(x, conv.weight, conv.bias, ACT[act])

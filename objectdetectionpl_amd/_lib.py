@@ -66,6 +66,12 @@ class RetinaHeadsDesc(ctypes.Structure):
                 ("pos_anchor", c_void_p), ("num_pos", c_void_p), ("upstream", c_void_p)]
 
 
+class SparseConv3x3(ctypes.Structure):
+    """odpl_sparse_conv3x3_t"""
+    _fields_ = [("x", c_void_p), ("gy", c_void_p), ("active", c_void_p), ("w", c_void_p), ("grad_x", c_void_p), ("grad_w", c_void_p),
+                ("w_stride", ctypes.c_int64 * 4), ("B", c_int32), ("H", c_int32), ("W", c_int32), ("Cin", c_int32), ("Cout", c_int32)]
+
+
 class YoloNmsDesc(ctypes.Structure):
     _fields_ = [("head", c_void_p * MAX_SCALES), ("G", c_int32 * MAX_SCALES),
                 ("nscales", c_int32), ("B", c_int32), ("A", c_int32), ("no", c_int32),
@@ -171,6 +177,9 @@ SIGNATURES = {
     "odpl_reorg": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, POINTER(ctypes.c_int64), c_int32, c_void_p]),
     "odpl_bias_act_forward": (c_int32, [c_void_p, ctypes.c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     "odpl_bias_act_backward": (c_int32, [c_void_p, c_void_p, ctypes.c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_void_p]),
+    "odpl_bias_act_backward_flags": (c_int32, [c_void_p, c_void_p, ctypes.c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_void_p]),
+    "odpl_sparse_conv3x3_backward_workspace_bytes": (c_size_t, [c_void_p]),
+    "odpl_sparse_conv3x3_backward": (c_int32, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "odpl_upsample2x_nearest": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, ctypes.c_int64, ctypes.c_int64, c_int32, c_void_p]),
     "odpl_spp_forward": (c_int32, [c_void_p, POINTER(ctypes.c_int64), c_int32, c_int32, c_int32, c_int32, c_void_p, POINTER(ctypes.c_int64), c_void_p]),
     "odpl_spp_backward": (c_int32, [c_void_p, POINTER(ctypes.c_int64), c_int32, c_int32, c_int32, c_int32, c_void_p, POINTER(ctypes.c_int64), c_void_p, c_void_p]),

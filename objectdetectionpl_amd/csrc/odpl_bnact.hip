@@ -301,6 +301,7 @@ __global__ __launch_bounds__(kT) void bias_act_bwd_kernel(const BnParams P) {
                         o.z = v[u].z > 0.f ? g[u].z : neg * g[u].z; o.w = v[u].w > 0.f ? g[u].w : neg * g[u].w;
                     }
                     *reinterpret_cast<float4*>(bo + ((unsigned)r * rs + (unsigned)q * 16u)) = o;
+                    if (P.flags && (o.x != 0.f || o.y != 0.f || o.z != 0.f || o.w != 0.f)) P.flags[r0 + r] = 1;     // every writer stores the same byte
                     a[0] += o.x; a[1] += o.y; a[2] += o.z; a[3] += o.w;
                 }
             }
@@ -555,6 +556,11 @@ extern "C" int odpl_bias_act_forward(const float* x, int64_t R, int32_t C, const
 // workspace: odpl_bn_act_workspace_bytes(R, C) + 4 * C bytes.  grad_x may alias grad_y.
 extern "C" int odpl_bias_act_backward(const float* y, const float* grad_y, int64_t R, int32_t C, int32_t act, float* grad_x, float* grad_bias,
                                       void* workspace, size_t workspace_bytes, void* stream_) {
+    return odpl_bias_act_backward_flags(y, grad_y, R, C, act, grad_x, grad_bias, nullptr, workspace, workspace_bytes, stream_);
+}
+
+extern "C" int odpl_bias_act_backward_flags(const float* y, const float* grad_y, int64_t R, int32_t C, int32_t act, float* grad_x, float* grad_bias,
+                                            uint8_t* active, void* workspace, size_t workspace_bytes, void* stream_) {
     RPlan pl;
     if (!y || !grad_y || !grad_x || !grad_bias || !plan(R, C, &pl)) return ODPL_EINVAL;
     if (act != ODPL_ACT_LINEAR && act != ODPL_ACT_LEAKY && act != ODPL_ACT_RELU) return ODPL_EINVAL;
@@ -564,6 +570,8 @@ extern "C" int odpl_bias_act_backward(const float* y, const float* grad_y, int64
     P.x = y; P.gy = grad_y; P.gx = grad_x; P.R = R; P.C = C; P.act = act; P.nblk = pl.nblk; P.rows_per_blk = pl.rows_per_blk; P.slice_q = pl.slice_q;
     P.part = (double*)workspace; P.dbeta = grad_bias; P.dgamma = (float*)((char*)workspace + part_bytes);     // dgamma: scratch (all zeros)
     hipStream_t stream = (hipStream_t)stream_;
+    P.flags = active;
+    if (active) ODPL_HIP_TRY(odpl::fill_bytes(active, 0, (size_t)R, stream));
     const dim3 grid(pl.nblk, pl.nslices);
     if (act == ODPL_ACT_RELU) hipLaunchKernelGGL(bias_act_bwd_kernel<ODPL_ACT_RELU>, grid, dim3(kT), pl.lds, stream, P);
     else if (act == ODPL_ACT_LEAKY) hipLaunchKernelGGL(bias_act_bwd_kernel<ODPL_ACT_LEAKY>, grid, dim3(kT), pl.lds, stream, P);

@@ -1,0 +1,312 @@
+// Backward of a 3x3 (stride 1, pad 1) convolution whose OUTPUT GRADIENT is zero on most pixels.
+//
+// RetinaNet's head towers (model/RetinaNet.py:93-99: four Conv2d(256, 256, 3, 1, 1) + ReLU per head, shared by the five FPN levels) sit
+// behind the two final convolutions, whose input gradient is non-zero only within one pixel of a positive anchor (csrc/odpl_retinagrad.hip).
+// Each 3x3 layer further back widens that support by one pixel: on the two large levels (94 % of the towers' arithmetic) a few per cent
+// of the pixels carry any gradient at all, yet a library convolution backward multiplies all of them -- 16 ms of the BASELINE config-4
+// step.  Here the two backward products run over the ACTIVE pixels only:
+//     dX[q, :]        = sum_tap W_tap^T . gY[q - d(tap), :]          for q within one pixel of an active pixel; zero elsewhere
+//     dW[:, :, tap]   = sum_{p active} gY[p, :] (x) X[p + d(tap), :]
+// as gathered GEMMs on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, the tiling of csrc/odpl_gemm1x1.hip: 64 x 64 tiles, K step 32,
+// padded LDS images, next tile prefetched into registers).  Which pixels are active is read from a byte map the preceding bias + ReLU
+// backward launch emits for free (odpl_bias_act_backward_flags).  Launches: tile counts -> scan -> ordered lists (ascending pixel: the
+// sums below run in list order, no float atomics, bitwise reproducible) -> zero fill of dX -> data GEMM -> weight GEMM (split over the
+// list, partials) -> fixed-order reduction.  Nothing is read back by the host: grids are sized for the worst case and walk device-side counts.
+#include "odpl_common.hpp"
+#include "../../include/odpl_hip.h"
+
+namespace {
+using namespace odpl;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kT = 256;
+constexpr int BK = 32;
+constexpr int kSplits = 8;              // pixel-list chunks of the weight GEMM (partials reduced in chunk order)
+
+struct SP {
+    const float* x; const float* gy; const unsigned char* act; const float* w; float* gx; float* gw;
+    long long ws_o, ws_i, ws_ky, ws_kx;
+    int B, H, W, Cin, Cout, P, ntile;    // P = B*H*W pixels; ntile = ceil(P / 256)
+    int* cnt_out; int* cnt_in;           // [ntile] active pixels / pixels within one pixel of an active one, per 256-pixel tile
+    int* off_out; int* off_in;           // [ntile + 1] exclusive scans; [ntile] = totals
+    int* list_out; int* list_in;         // [P] ascending pixel ids
+    float* part;                         // [kSplits][9][Cout][Cin]
+};
+
+__device__ __forceinline__ bool near_active(const SP& P, int p) {
+    const int hw = P.H * P.W, b = p / hw, r = p - b * hw, y = r / P.W, x = r - y * P.W;
+    bool any = false;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int yy = y + dy, xx = x + dx;
+            if (yy >= 0 && yy < P.H && xx >= 0 && xx < P.W) any |= P.act[(size_t)b * hw + yy * P.W + xx] != 0;
+        }
+    return any;
+}
+
+__global__ __launch_bounds__(kT) void sc_count_kernel(const SP P) {
+    __shared__ int s_w[2][kT / 64];
+    const int p = blockIdx.x * kT + threadIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool live = p < P.P;
+    const bool o = live && P.act[p] != 0, i = live && near_active(P, p);
+    const unsigned long long mo = __ballot(o), mi = __ballot(i);
+    if (lane == 0) { s_w[0][wv] = __popcll(mo); s_w[1][wv] = __popcll(mi); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int a = 0, c = 0;
+        for (int w = 0; w < kT / 64; ++w) { a += s_w[0][w]; c += s_w[1][w]; }
+        P.cnt_out[blockIdx.x] = a; P.cnt_in[blockIdx.x] = c;
+    }
+}
+
+__global__ __launch_bounds__(1024) void sc_scan_kernel(const SP P) {
+    __shared__ int s_w[2][16];
+    __shared__ int s_carry[2];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid < 2) s_carry[tid] = 0;
+    __syncthreads();
+    for (int base = 0; base < P.ntile; base += 1024) {
+        const int i = base + tid;
+        const int c0 = i < P.ntile ? P.cnt_out[i] : 0, c1 = i < P.ntile ? P.cnt_in[i] : 0;
+        int v0 = c0, v1 = c1;
+        for (int o = 1; o < 64; o <<= 1) { const int u0 = __shfl_up(v0, o, 64), u1 = __shfl_up(v1, o, 64); if (lane >= o) { v0 += u0; v1 += u1; } }
+        if (lane == 63) { s_w[0][wv] = v0; s_w[1][wv] = v1; }
+        __syncthreads();
+        int w0 = 0, w1 = 0;
+        for (int w = 0; w < wv; ++w) { w0 += s_w[0][w]; w1 += s_w[1][w]; }
+        const int e0 = s_carry[0] + w0 + v0 - c0, e1 = s_carry[1] + w1 + v1 - c1;
+        if (i < P.ntile) { P.off_out[i] = e0; P.off_in[i] = e1; }
+        __syncthreads();
+        if (tid == 1023) { s_carry[0] = e0 + c0; s_carry[1] = e1 + c1; }
+        __syncthreads();
+    }
+    if (tid == 0) { P.off_out[P.ntile] = s_carry[0]; P.off_in[P.ntile] = s_carry[1]; }
+}
+
+__global__ __launch_bounds__(kT) void sc_list_kernel(const SP P) {
+    __shared__ int s_w[2][kT / 64];
+    const int p = blockIdx.x * kT + threadIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool live = p < P.P;
+    const bool o = live && P.act[p] != 0, i = live && near_active(P, p);
+    const unsigned long long mo = __ballot(o), mi = __ballot(i);
+    if (lane == 0) { s_w[0][wv] = __popcll(mo); s_w[1][wv] = __popcll(mi); }
+    __syncthreads();
+    int b0 = P.off_out[blockIdx.x], b1 = P.off_in[blockIdx.x];
+    for (int w = 0; w < wv; ++w) { b0 += s_w[0][w]; b1 += s_w[1][w]; }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (o) P.list_out[b0 + __popcll(mo & below)] = p;
+    if (i) P.list_in[b1 + __popcll(mi & below)] = p;
+}
+
+// dX rows of the pixels in list_in: [n_in, 9 * Cout] (gathered rows of gY, one tap at a time) x [9 * Cout, Cin]
+__global__ __launch_bounds__(kT) void sc_data_kernel(const SP P) {
+    constexpr int BM = 64, BN = 64, LDA = BK + 1, LDB = BN + 4;
+    __shared__ float As[BM * LDA];
+    __shared__ float Bs[BK * LDB];
+    __shared__ int s_b[BM], s_y[BM], s_x[BM], s_q[BM];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = (wv >> 1) * 32, wn = (wv & 1) * 32, lr = lane & 31, lk = lane >> 5;
+    const int n_in = P.off_in[P.ntile];
+    const int tiles_n = P.Cin / BN, tiles_m = (n_in + BM - 1) / BM, ntiles = tiles_m * tiles_n;
+    const int hw = P.H * P.W, kpt = P.Cout / BK;                         // K steps per tap
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tm = tile / tiles_n, tn = tile - tm * tiles_n, bn = tn * BN;
+        __syncthreads();
+        if (tid < BM) {
+            int r = tm * BM + tid; if (r > n_in - 1) r = n_in - 1;       // clamped: the surplus rows are computed and not stored
+            const int q = P.list_in[r], b = q / hw, rem = q - b * hw, y = rem / P.W;
+            s_q[tid] = q; s_b[tid] = b; s_y[tid] = y; s_x[tid] = rem - y * P.W;
+        }
+        __syncthreads();
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        float4 ra[2], rb[2];
+        auto load_tiles = [&](int kt) {
+            const int t = kt / kpt, co0 = (kt - t * kpt) * BK, ky = t / 3, kx = t - 3 * ky;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int f = tid + kT * i, row = f >> 3, kq = f & 7;
+                const int yy = s_y[row] - (ky - 1), xx = s_x[row] - (kx - 1);                // dX[q] takes gY[q - d(tap)]
+                const bool in = yy >= 0 && yy < P.H && xx >= 0 && xx < P.W;
+                const size_t src = ((size_t)s_b[row] * hw + (in ? yy * P.W + xx : 0)) * P.Cout + co0 + 4 * kq;
+                const float4 v = *reinterpret_cast<const float4*>(P.gy + src);
+                ra[i] = in ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int f = tid + kT * i, kr = f >> 4, nq = f & 15;                        // W[co0 + kr][bn + 4 nq ..][ky][kx]
+                const long long off = (long long)(co0 + kr) * P.ws_o + ky * P.ws_ky + kx * P.ws_kx + (long long)(bn + 4 * nq) * P.ws_i;
+                rb[i] = P.ws_i == 1 ? *reinterpret_cast<const float4*>(P.w + off)
+                                    : make_float4(P.w[off], P.w[off + P.ws_i], P.w[off + 2 * P.ws_i], P.w[off + 3 * P.ws_i]);
+            }
+        };
+        auto store_tiles = [&]() {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int f = tid + kT * i, row = f >> 3, kq = f & 7;
+                float* d = As + row * LDA + 4 * kq;
+                d[0] = ra[i].x; d[1] = ra[i].y; d[2] = ra[i].z; d[3] = ra[i].w;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int f = tid + kT * i, kr = f >> 4, nq = f & 15;
+                *reinterpret_cast<float4*>(Bs + kr * LDB + 4 * nq) = rb[i];
+            }
+        };
+        const int nk = 9 * kpt;
+        load_tiles(0);
+        store_tiles();
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) load_tiles(kt + 1);
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 2) {
+                const float a = As[(wm + lr) * LDA + kk + lk], b = Bs[(kk + lk) * LDB + wn + lr];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            }
+            __syncthreads();
+            if (kt + 1 < nk) { store_tiles(); __syncthreads(); }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            if (tm * BM + row < n_in) P.gx[(size_t)s_q[row] * P.Cin + bn + wn + lr] = acc[r];
+        }
+    }
+}
+
+// partial dW of one tap over one chunk of list_out: [Cout, n] (gathered rows of gY) x [n, Cin] (rows of X at p + d(tap))
+__global__ __launch_bounds__(kT) void sc_weight_kernel(const SP P) {
+    constexpr int BM = 64, BN = 64, LD = 64 + 4;
+    __shared__ float As[BK * LD];                                        // [pixel][co]
+    __shared__ float Bs[BK * LD];                                        // [pixel][ci]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = (wv >> 1) * 32, wn = (wv & 1) * 32, lr = lane & 31, lk = lane >> 5;
+    const int tiles_m = P.Cout / BM, tiles_n = P.Cin / BN;
+    int bid = blockIdx.x;
+    const int tn = bid % tiles_n; bid /= tiles_n;
+    const int tm = bid % tiles_m; bid /= tiles_m;
+    const int t = bid % 9, s = bid / 9;
+    const int ky = t / 3, kx = t - 3 * ky, hw = P.H * P.W;
+    const int n_out = P.off_out[P.ntile];
+    const int chunk = ((n_out + kSplits - 1) / kSplits + BK - 1) / BK * BK;
+    const int r0 = s * chunk, r1 = r0 + chunk < n_out ? r0 + chunk : n_out;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float4 ra[2], rb[2];
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = tid + kT * i, kr = f >> 4, cq = f & 15;
+            const int r = k0 + kr;
+            const bool live = r < r1;
+            const int p = P.list_out[live ? r : r0 < n_out ? r0 : 0];
+            const float4 g = *reinterpret_cast<const float4*>(P.gy + (size_t)p * P.Cout + tm * BM + 4 * cq);
+            ra[i] = live ? g : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int b = p / hw, rem = p - b * hw, y = rem / P.W, x = rem - y * P.W, yy = y + ky - 1, xx = x + kx - 1;
+            const bool in = live && yy >= 0 && yy < P.H && xx >= 0 && xx < P.W;
+            const float4 v = *reinterpret_cast<const float4*>(P.x + ((size_t)b * hw + (in ? yy * P.W + xx : rem)) * P.Cin + tn * BN + 4 * cq);
+            rb[i] = in ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = tid + kT * i, kr = f >> 4, cq = f & 15;
+            *reinterpret_cast<float4*>(As + kr * LD + 4 * cq) = ra[i];
+            *reinterpret_cast<float4*>(Bs + kr * LD + 4 * cq) = rb[i];
+        }
+    };
+    if (r0 < r1) {
+        load_tiles(r0);
+        store_tiles();
+        __syncthreads();
+        for (int k0 = r0; k0 < r1; k0 += BK) {
+            if (k0 + BK < r1) load_tiles(k0 + BK);
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 2) {
+                const float a = As[(kk + lk) * LD + wm + lr], b = Bs[(kk + lk) * LD + wn + lr];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            }
+            __syncthreads();
+            if (k0 + BK < r1) { store_tiles(); __syncthreads(); }
+        }
+    }
+    float* o = P.part + ((size_t)(s * 9 + t) * P.Cout + tm * BM) * P.Cin + tn * BN;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[(size_t)(wm + (r & 3) + 8 * (r >> 2) + 4 * lk) * P.Cin + wn + lr] = acc[r];
+}
+
+__global__ __launch_bounds__(kT) void sc_reduce_kernel(const SP P) {
+    const long long n = 9LL * P.Cout * P.Cin;
+    for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < n; i += (long long)gridDim.x * kT) {
+        float v = P.part[i];
+        for (int s = 1; s < kSplits; ++s) v += P.part[(long long)s * n + i];
+        const int ci = (int)(i % P.Cin); const long long r = i / P.Cin; const int co = (int)(r % P.Cout), t = (int)(r / P.Cout);
+        P.gw[(long long)co * P.ws_o + (long long)ci * P.ws_i + (t / 3) * P.ws_ky + (t % 3) * P.ws_kx] = v;
+    }
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+struct Plan { size_t cnt_out, cnt_in, off_out, off_in, list_out, list_in, part, total; int P, ntile; };
+
+bool make_plan(const odpl_sparse_conv3x3_t* d, Plan* p) {
+    if (!d || d->B < 1 || d->H < 1 || d->W < 1 || d->Cin < 64 || (d->Cin % 64) || d->Cout < 64 || (d->Cout % 64)) return false;
+    const long long P = (long long)d->B * d->H * d->W;
+    if (P * d->Cin > 0x7fffffffLL * 4 || P * d->Cout > 0x7fffffffLL * 4 || P > 0x7fffffffLL - 256) return false;
+    if (!d->x || !d->gy || !d->active || !d->w) return false;
+    p->P = (int)P; p->ntile = (int)((P + kT - 1) / kT);
+    size_t off = 0;
+    p->cnt_out = off; off += align_up((size_t)p->ntile * 4, 256);
+    p->cnt_in = off; off += align_up((size_t)p->ntile * 4, 256);
+    p->off_out = off; off += align_up(((size_t)p->ntile + 1) * 4, 256);
+    p->off_in = off; off += align_up(((size_t)p->ntile + 1) * 4, 256);
+    p->list_out = off; off += align_up((size_t)P * 4, 256);
+    p->list_in = off; off += align_up((size_t)P * 4, 256);
+    p->part = off; off += align_up((size_t)kSplits * 9 * d->Cout * d->Cin * 4, 256);
+    p->total = off;
+    return true;
+}
+}  // namespace
+
+extern "C" size_t odpl_sparse_conv3x3_backward_workspace_bytes(const odpl_sparse_conv3x3_t* d) {
+    Plan p;
+    return make_plan(d, &p) ? p.total : 0;     // (host only: reads no device memory)
+}
+
+extern "C" int odpl_sparse_conv3x3_backward(const odpl_sparse_conv3x3_t* d, void* workspace, size_t workspace_bytes, void* stream_) {
+    Plan pl;
+    if (!make_plan(d, &pl) || !workspace || workspace_bytes < pl.total) return ODPL_EINVAL;
+    if ((((uintptr_t)workspace | (uintptr_t)d->x | (uintptr_t)d->gy | (uintptr_t)d->grad_x) & 15)) return ODPL_EINVAL;
+    if (d->w_stride[1] == 1 && ((((uintptr_t)d->w) & 15) || (d->w_stride[0] & 3) || (d->w_stride[2] & 3) || (d->w_stride[3] & 3))) return ODPL_EINVAL;
+    hipStream_t stream = (hipStream_t)stream_;
+    char* ws = (char*)workspace;
+    SP P;
+    P.x = d->x; P.gy = d->gy; P.act = d->active; P.w = d->w; P.gx = d->grad_x; P.gw = d->grad_w;
+    P.ws_o = d->w_stride[0]; P.ws_i = d->w_stride[1]; P.ws_ky = d->w_stride[2]; P.ws_kx = d->w_stride[3];
+    P.B = d->B; P.H = d->H; P.W = d->W; P.Cin = d->Cin; P.Cout = d->Cout; P.P = pl.P; P.ntile = pl.ntile;
+    P.cnt_out = (int*)(ws + pl.cnt_out); P.cnt_in = (int*)(ws + pl.cnt_in); P.off_out = (int*)(ws + pl.off_out); P.off_in = (int*)(ws + pl.off_in);
+    P.list_out = (int*)(ws + pl.list_out); P.list_in = (int*)(ws + pl.list_in); P.part = (float*)(ws + pl.part);
+    hipLaunchKernelGGL(sc_count_kernel, dim3(pl.ntile), dim3(kT), 0, stream, P);
+    ODPL_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(sc_scan_kernel, dim3(1), dim3(1024), 0, stream, P);
+    ODPL_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(sc_list_kernel, dim3(pl.ntile), dim3(kT), 0, stream, P);
+    ODPL_HIP_TRY(hipGetLastError());
+    if (d->grad_x) {
+        ODPL_HIP_TRY(odpl::fill_bytes(d->grad_x, 0, (size_t)pl.P * d->Cin * sizeof(float), stream));
+        long long worst = ((long long)pl.P + 63) / 64 * (d->Cin / 64);
+        hipLaunchKernelGGL(sc_data_kernel, dim3((unsigned)(worst < 2048 ? worst : 2048)), dim3(kT), 0, stream, P);
+        ODPL_HIP_TRY(hipGetLastError());
+    }
+    if (d->grad_w) {
+        hipLaunchKernelGGL(sc_weight_kernel, dim3(kSplits * 9 * (d->Cout / 64) * (d->Cin / 64)), dim3(kT), 0, stream, P);
+        ODPL_HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(sc_reduce_kernel, dim3(1024), dim3(kT), 0, stream, P);
+        ODPL_HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}

@@ -15,6 +15,7 @@ from ..LightningFunc.losses import configure_loss
 from ..LightningFunc.nms import greedy_non_max_suppression
 from ..LightningFunc.utils import bnact as _bnact
 from ..LightningFunc.utils import retinahead as _rh
+from ..LightningFunc.utils import sparseconv as _sc
 from ..LightningFunc.utils.RetinaUtils import get_anchor_boxes
 
 try:
@@ -140,7 +141,8 @@ class RetinaNet(_Base):
         (utils/bnact.py:conv_bias_act)"""
         mods = list(head)
         for i in range(0, len(mods) - 1, 2):
-            fm = _bnact.conv_bias_act(fm, mods[i], "relu")
+            # on the large levels the backward of conv + bias + ReLU walks the pixels that carry a gradient only (utils/sparseconv.py)
+            fm = _sc.conv_bias_act(fm, mods[i], "relu") if _sc.applicable(fm, mods[i]) else _bnact.conv_bias_act(fm, mods[i], "relu")
         return fm
 
     @classmethod

@@ -33,7 +33,10 @@ def main():
     ap.add_argument("--no-hosted-heads", action="store_true", help="A/B: the final head convolutions as plain nn.Conv2d modules + cat (round 2)")
     ap.add_argument("--dense-head-backward", action="store_true",
                     help="A/B: hosted final convolutions, but the criterion hands autograd the dense d loss/d preds (aten convolution_backward)")
+    ap.add_argument("--dense-tower-backward", action="store_true", help="A/B: the head towers' 3x3 convolutions keep MIOpen's backward on every level")
     a = ap.parse_args()
+    from objectdetectionpl_amd.LightningFunc.utils import sparseconv
+    sparseconv.enabled = not a.dense_tower_backward
     from objectdetectionpl_amd.LightningFunc.utils import retinahead
     retinahead.enabled = not a.no_hosted_heads
     RetinaNetLoss.fuse_head_backward = not a.dense_head_backward
@@ -83,7 +86,8 @@ def main():
     print(json.dumps({"workload": f"RetinaNet-R50-FPN {a.height}x{a.width} bs={a.batch} training step, fp32, C=80, {anchors.shape[0]} anchors",
                       "img_per_s": round(a.batch / dt, 2), "ms_per_step": round(dt * 1e3, 2), "loss": round(float(d["loss"].detach()), 4),
                       "num_pos": int(crit.last_counts[0]), "miopen_find": bool(a.miopen_find),
-                      "hosted_heads": not a.no_hosted_heads, "structured_head_backward": not (a.no_hosted_heads or a.dense_head_backward), **kern}))
+                      "hosted_heads": not a.no_hosted_heads, "structured_head_backward": not (a.no_hosted_heads or a.dense_head_backward),
+                      "sparse_tower_backward": not a.dense_tower_backward, **kern}))
 
 
 if __name__ == "__main__":
