@@ -88,9 +88,17 @@ class FPN(nn.Module):
         p6 = self.conv6(c5)
         p7 = self.conv7(F.relu(p6))
         p5 = self.latlayer1(c5)
-        p4 = self.toplayer1(self._up_add(p5, self.latlayer2(c4)))
-        p3 = self.toplayer2(self._up_add(p4, self.latlayer3(c3)))
+        p4 = self._smooth(self.toplayer1, self._up_add(p5, self.latlayer2(c4)))
+        p3 = self._smooth(self.toplayer2, self._up_add(p4, self.latlayer3(c3)))
         return p3, p4, p5, p6, p7
+
+    @staticmethod
+    def _smooth(conv, x):
+        """toplayer1 / toplayer2 (RetinaNetbone.py: Conv2d(256, 256, 3, 1, 1) on the merged maps): their output gradient is the sum of the two
+        head towers' input gradients -- still a few per cent of the pixels on the large levels -- so their backward also walks the
+        active pixels only (utils/sparseconv.py; act = linear)"""
+        from ..LightningFunc.utils import sparseconv as _sc
+        return _sc.conv_bias_act(x, conv, "linear") if _sc.applicable(x, conv) else conv(x)
 
 
 class RetinaNet(_Base):
