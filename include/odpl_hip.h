@@ -351,6 +351,8 @@ typedef struct {
     float* grad_x; float* grad_w;
     int64_t w_stride[4];                     /* element strides of w / grad_w along (o, i, ky, kx) */
     int32_t B, H, W, Cin, Cout;
+    int32_t* stats;                          /* optional device int32 [2]: active pixels, pixels within one pixel of an active one -- what the host
+                                              * reads LATER (asynchronously) to decide whether this route still pays; NULL = not wanted */
 } odpl_sparse_conv3x3_t;
 size_t odpl_sparse_conv3x3_backward_workspace_bytes(const odpl_sparse_conv3x3_t* desc);
 int odpl_sparse_conv3x3_backward(const odpl_sparse_conv3x3_t* desc, void* workspace, size_t workspace_bytes, void* stream);

@@ -18,10 +18,43 @@ from .bnact import ACT, _ones_zeros, _workspace
 
 enabled = True            # A/B switch (tools/bench_retina_step.py --dense-tower-backward)
 min_pixels = 8192         # levels with fewer B*H*W pixels keep the library backward (they are 6 % of the towers' arithmetic at config 4)
+max_density = 0.5         # above this share of pixels within reach of a gradient the library's dense backward is the faster one
+reprobe_every = 200       # a layer sent to the dense route tries the sparse one again after this many calls
 _ws2 = {}
+_density = {}             # (weight id, H, W) -> {"d": last observed share, "pending": (pinned tensor, event, pixels), "dense_calls": n}
+
+
+def _observe(key):
+    """fold a finished asynchronous read-back of the pixel counts into the layer's record (never waits)"""
+    rec = _density.get(key)
+    if rec and rec.get("pending") is not None:
+        pinned, ev, pixels = rec["pending"]
+        if ev.query():
+            rec["d"] = float(pinned[1]) / max(pixels, 1)
+            rec["pending"] = None
+    return rec
+
+
+def _route_sparse(key):
+    """the gradient's density is a property of the loss behind the layer: it is read back WITHOUT a sync (pinned copy + event, looked at
+    on a later call) and a layer whose gradient turns out dense is sent to the library route, re-probed now and then"""
+    rec = _observe(key)
+    if rec is None or rec.get("d") is None or rec["d"] <= max_density:
+        return True
+    rec["dense_calls"] = rec.get("dense_calls", 0) + 1
+    if rec["dense_calls"] >= reprobe_every:
+        rec["dense_calls"] = 0
+        return True
+    return False
 
 
 def applicable(x, conv):
+    if not _applicable(x, conv):
+        return False
+    return _route_sparse((id(conv.weight), x.shape[2], x.shape[3]))
+
+
+def _applicable(x, conv):
     return (enabled and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
             and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is not None
             and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0 and conv.weight.dtype == torch.float32
@@ -31,7 +64,8 @@ def applicable(x, conv):
 
 class _ConvBiasActSparse(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, act):
+    def forward(ctx, x, w, b, act, key):
+        ctx.key = key
         z = F.conv2d(x, w, None, 1, 1)
         N, C, H, W = z.shape
         ones, zeros = _ones_zeros(z.device, C)
@@ -68,6 +102,8 @@ class _ConvBiasActSparse(torch.autograd.Function):
         for k in range(4):
             d.w_stride[k] = w.stride(k)
         d.B, d.H, d.W, d.Cin, d.Cout = N, H, W, x.shape[1], C
+        stats = torch.empty(2, dtype=torch.int32, device=dev)
+        d.stats = stats.data_ptr()
         nbytes = L.odpl_sparse_conv3x3_backward_workspace_bytes(ctypes.byref(d))
         if nbytes == 0:
             raise _lib.OdplError("odpl_sparse_conv3x3_backward_workspace_bytes rejected the descriptor")
@@ -77,9 +113,16 @@ class _ConvBiasActSparse(torch.autograd.Function):
             ws2 = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=dev)
             _ws2[key] = ws2
         _lib.check(L.odpl_sparse_conv3x3_backward(ctypes.byref(d), _lib.ptr(ws2), ws2.numel(), st), "odpl_sparse_conv3x3_backward")
-        return gx, gw, gb, None
+        rec = _density.setdefault(ctx.key, {"d": None, "pending": None, "dense_calls": 0})
+        if rec["pending"] is None and not torch.cuda.is_current_stream_capturing():       # one read-back in flight per layer, never waited for
+            pinned = torch.empty(2, dtype=torch.int32, pin_memory=True)
+            pinned.copy_(stats, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            rec["pending"] = (pinned, ev, R)
+        return gx, gw, gb, None, None
 
 
 def conv_bias_act(x, conv, act="relu"):
     """`act(conv(x))` with the sparse backward; callers check `applicable(x, conv)` first."""
-    return _ConvBiasActSparse.apply(x, conv.weight, conv.bias, ACT[act])
+    return _ConvBiasActSparse.apply(x, conv.weight, conv.bias, ACT[act], (id(conv.weight), x.shape[2], x.shape[3]))

@@ -69,7 +69,8 @@ class RetinaHeadsDesc(ctypes.Structure):
 class SparseConv3x3(ctypes.Structure):
     """odpl_sparse_conv3x3_t"""
     _fields_ = [("x", c_void_p), ("gy", c_void_p), ("active", c_void_p), ("w", c_void_p), ("grad_x", c_void_p), ("grad_w", c_void_p),
-                ("w_stride", ctypes.c_int64 * 4), ("B", c_int32), ("H", c_int32), ("W", c_int32), ("Cin", c_int32), ("Cout", c_int32)]
+                ("w_stride", ctypes.c_int64 * 4), ("B", c_int32), ("H", c_int32), ("W", c_int32), ("Cin", c_int32), ("Cout", c_int32),
+                ("stats", c_void_p)]
 
 
 class YoloNmsDesc(ctypes.Structure):

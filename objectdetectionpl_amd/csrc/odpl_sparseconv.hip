@@ -30,6 +30,7 @@ struct SP {
     int* off_out; int* off_in;           // [ntile + 1] exclusive scans; [ntile] = totals
     int* list_out; int* list_in;         // [P] ascending pixel ids
     float* part;                         // [kSplits][9][Cout][Cin]
+    int* stats;                          // optional [2]: active pixels, pixels within one pixel of an active one (for the caller's route choice)
 };
 
 __device__ __forceinline__ bool near_active(const SP& P, int p) {
@@ -81,7 +82,10 @@ __global__ __launch_bounds__(1024) void sc_scan_kernel(const SP P) {
         if (tid == 1023) { s_carry[0] = e0 + c0; s_carry[1] = e1 + c1; }
         __syncthreads();
     }
-    if (tid == 0) { P.off_out[P.ntile] = s_carry[0]; P.off_in[P.ntile] = s_carry[1]; }
+    if (tid == 0) {
+        P.off_out[P.ntile] = s_carry[0]; P.off_in[P.ntile] = s_carry[1];
+        if (P.stats) { P.stats[0] = s_carry[0]; P.stats[1] = s_carry[1]; }
+    }
 }
 
 __global__ __launch_bounds__(kT) void sc_list_kernel(const SP P) {
@@ -290,6 +294,7 @@ extern "C" int odpl_sparse_conv3x3_backward(const odpl_sparse_conv3x3_t* d, void
     P.B = d->B; P.H = d->H; P.W = d->W; P.Cin = d->Cin; P.Cout = d->Cout; P.P = pl.P; P.ntile = pl.ntile;
     P.cnt_out = (int*)(ws + pl.cnt_out); P.cnt_in = (int*)(ws + pl.cnt_in); P.off_out = (int*)(ws + pl.off_out); P.off_in = (int*)(ws + pl.off_in);
     P.list_out = (int*)(ws + pl.list_out); P.list_in = (int*)(ws + pl.list_in); P.part = (float*)(ws + pl.part);
+    P.stats = d->stats;
     hipLaunchKernelGGL(sc_count_kernel, dim3(pl.ntile), dim3(kT), 0, stream, P);
     ODPL_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(sc_scan_kernel, dim3(1), dim3(1024), 0, stream, P);

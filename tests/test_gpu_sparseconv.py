@@ -50,3 +50,25 @@ def test_sparse_backward_equals_dense_backward(B, cin, cout, H, W, density, weig
         assert torch.equal(x3.grad, got[0]) and torch.equal(conv.weight.grad, got[1])
     finally:
         sc.min_pixels = old
+
+
+def test_a_layer_whose_gradient_is_dense_is_sent_to_the_library_route():
+    """The share of pixels within reach of a gradient is read back asynchronously; once it is seen above `max_density` the layer stops
+    qualifying (`applicable` -> False: the caller takes the dense route) until the next re-probe; a sparse layer keeps qualifying."""
+    import time
+    from objectdetectionpl_amd.LightningFunc.utils import sparseconv as sc
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(2, 64, 40, 40, generator=g)).to(DEV).contiguous(memory_format=torch.channels_last)
+    old = sc.min_pixels
+    sc.min_pixels = 1
+    try:
+        for density, expect in ((1.0, False), (0.01, True)):
+            conv = nn.Conv2d(64, 64, 3, 1, 1).to(DEV).to(memory_format=torch.channels_last)
+            gy = (torch.randn(2, 64, 40, 40, generator=g) * (torch.rand(2, 1, 40, 40, generator=g) < density).float()).to(DEV).contiguous(memory_format=torch.channels_last)
+            assert sc.applicable(x, conv)                                      # nothing known yet
+            xi = x.clone().requires_grad_()
+            sc.conv_bias_act(xi, conv, "relu").backward(gy)
+            torch.cuda.synchronize(); time.sleep(0.05)
+            assert sc.applicable(x, conv) is expect
+    finally:
+        sc.min_pixels = old
