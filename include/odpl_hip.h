@@ -27,8 +27,9 @@
 extern "C" {
 #endif
 
-#define ODPL_ABI_VERSION 4   /* 3: memory-format strides + compact (structured) gradients on the YOLO losses, head-conv backward from them;
-                              * 4: odpl_retina_loss_desc_t grew pos_anchor / num_pos (ODPL_RETINA_ROWS_ONLY), odpl_retina_heads_backward */
+#define ODPL_ABI_VERSION 5   /* 3: memory-format strides + compact (structured) gradients on the YOLO losses, head-conv backward from them;
+                              * 4: odpl_retina_loss_desc_t grew pos_anchor / num_pos (ODPL_RETINA_ROWS_ONLY), odpl_retina_heads_backward
+                              * 5: odpl_sparse_conv3x3_t grew stats; ODPL_RETINA_ASSIGN_ONLY / _ASSIGNED, odpl_pixel_support, odpl_sparse_conv3x3_forward */
 #define ODPL_EINVAL (-1)
 #define ODPL_MAX_SCALES 4
 #define ODPL_MAX_ANCHORS 8
@@ -214,6 +215,11 @@ typedef struct {
  * on those rows ONLY (no zero stream: the other rows are left untouched) and the rows are listed in pos_anchor / num_pos -- the
  * structured form odpl_retina_heads_backward consumes. */
 #define ODPL_RETINA_ROWS_ONLY 2
+/* Split call for a loss-driven step (odpl_pixel_support): ASSIGN_ONLY runs the target assignment (losses.py:423-446) and lists the
+ * positive rows in pos_anchor / num_pos -- loc, cls and the gradients may be NULL, out3 is not written; a later call on the SAME
+ * workspace, targets and anchors with ASSIGNED set skips the assignment and evaluates the loss on the predictions given then. */
+#define ODPL_RETINA_ASSIGN_ONLY 4
+#define ODPL_RETINA_ASSIGNED 8
 
 size_t odpl_retina_loss_workspace_bytes(const odpl_retina_loss_desc_t* desc);
 
@@ -356,6 +362,42 @@ typedef struct {
 } odpl_sparse_conv3x3_t;
 size_t odpl_sparse_conv3x3_backward_workspace_bytes(const odpl_sparse_conv3x3_t* desc);
 int odpl_sparse_conv3x3_backward(const odpl_sparse_conv3x3_t* desc, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- loss-driven forward of the RetinaNet heads (csrc/odpl_sparsefwd.hip) ---------------------------------------------------
+ * step.py:14-25 is forward -> criterion and nothing else reads the predictions; RetinaNetLoss reads its POSITIVE rows only
+ * (losses.py:336-339, 458-461).  Assignment needs anchors and boxes only, so a training step can run it first
+ * (odpl_retina_loss, ODPL_RETINA_ASSIGN_ONLY), turn the positive rows into per-level pixel lists (odpl_pixel_support) and evaluate
+ * the heads' 3x3 convolutions (model/RetinaNet.py:93-99) on those pixels only (odpl_sparse_conv3x3_forward): same values there as
+ * the dense convolution, nothing computed elsewhere. */
+typedef struct {
+    const int32_t* pos_anchor;               /* device: b * An + a of the positive anchors (odpl_retina_loss, ODPL_RETINA_ASSIGN_ONLY) */
+    const int32_t* num_pos;                  /* device int32 [1] */
+    int32_t B, An, A, n_levels;              /* A anchors per pixel; An = A * sum_l H[l] * W[l] (checked) */
+    int32_t H[8], W[8];                      /* the level maps, in the order of the anchor table (RetinaUtils.py:6-31) */
+    int32_t depth;                           /* D <= 8: lists for reach 0 .. D-1 */
+    int32_t level_mask;                      /* bit l set: lists wanted for level l */
+    int32_t* lists;                          /* out, device int32 [D * B * sum_l H W]: level l owns D slots of B*H[l]*W[l] entries starting at
+                                              * D * B * sum_{l' < l} H W; slot j = the pixels (b*H + y)*W + x of that level within Chebyshev
+                                              * distance j of a pixel that owns a positive anchor -- in NO defined order (work queues) */
+    int32_t* counts;                         /* out, device int32 [n_levels * D]: entries of slot (l, j) */
+} odpl_pixel_support_t;
+size_t odpl_pixel_support_workspace_bytes(const odpl_pixel_support_t* desc);
+int odpl_pixel_support(const odpl_pixel_support_t* desc, void* workspace, size_t workspace_bytes, void* stream);
+
+typedef struct {
+    const float* x;                          /* [B, Cin, H, W] channels-last (dense), Cin % 32 == 0, 16-byte aligned */
+    const float* w;                          /* [Cout, Cin, 3, 3] in any dense layout (w_stride) */
+    const float* bias;                       /* [Cout] or NULL */
+    int64_t w_stride[4];
+    float* y;                                /* y[b * y_batch_stride + (yy * W + xx) * y_pixel_stride + co]: a channels-last map
+                                              * (H*W*Cout, Cout) or a slice of the [B, An, no] prediction table (An*no, A*no) */
+    int64_t y_batch_stride, y_pixel_stride;
+    const int32_t* list;                     /* device: pixels (b*H + y)*W + x to evaluate */
+    const int32_t* count;                    /* device int32 [1]: how many */
+    int32_t B, H, W, Cin, Cout;
+    int32_t act;                             /* ODPL_ACT_LINEAR / _RELU / _LEAKY on conv + bias */
+} odpl_sparse_conv3x3_fwd_t;
+int odpl_sparse_conv3x3_forward(const odpl_sparse_conv3x3_fwd_t* desc, void* stream);
 
 /* ---- SSD loss: losses.py:159-315 ---------------------------------------------------------------- */
 

@@ -62,13 +62,17 @@ class _RetinaLossHeadFn(torch.autograd.Function):
     stream); backward runs both convolutions' backward from those rows (`odpl_retina_heads_backward`)."""
 
     @staticmethod
-    def forward(ctx, owner, target, loc, cls, src, *diff):
+    def forward(ctx, owner, target, loc, cls, src, held, *diff):
         B, An = loc.shape[0], loc.shape[1]
         dev = loc.device
         g_loc, g_cls = torch.empty_like(loc), torch.empty_like(cls)          # only the positive rows will be written -- and read
-        pos = torch.empty(B * An, dtype=torch.int32, device=dev)
-        npos = torch.empty(1, dtype=torch.int32, device=dev)
-        out3, counts = owner._launch(loc, cls, g_loc, g_cls, target, rows_only=(pos, npos))
+        if held is not None:                                                  # the assignment was made before the heads ran (owner.assign)
+            pos, npos = held[2], held[3]
+            out3, counts = owner._launch(loc, cls, g_loc, g_cls, target, rows_only=(pos, npos), mode="assigned")
+        else:
+            pos = torch.empty(B * An, dtype=torch.int32, device=dev)
+            npos = torch.empty(1, dtype=torch.int32, device=dev)
+            out3, counts = owner._launch(loc, cls, g_loc, g_cls, target, rows_only=(pos, npos))
         ctx.src, ctx.aux = src, (g_loc, g_cls, pos, npos)
         ctx.has = [t is not None for t in diff]
         ctx.save_for_backward(*[t for t in diff if t is not None])              # version-checked by autograd
@@ -87,9 +91,9 @@ class _RetinaLossHeadFn(torch.autograd.Function):
         src = ctx.src
         ctx.aux = ctx.src = None
         _ = ctx.saved_tensors                                                    # raises if an input was edited in place since forward
-        need = ctx.needs_input_grad[5:]
+        need = ctx.needs_input_grad[6:]
         gw, gx = heads_backward(src, g_loc, g_cls, pos, npos, g_loss.contiguous().float(), need[:4], need[4:])
-        return (None, None, None, None, None) + tuple(gw) + tuple(gx)
+        return (None, None, None, None, None, None) + tuple(gw) + tuple(gx)
 
 
 class RetinaNetLoss(nn.Module):
@@ -125,20 +129,40 @@ class RetinaNetLoss(nn.Module):
 
     fuse_head_backward = True      # class switch: False = always hand autograd the dense d loss/d preds
 
-    def _launch(self, loc, cls, g_loc, g_cls, target, rows_only=None):
-        _lib.require_cuda(loc, cls, target)
+    def assign(self, target, B):
+        """Target assignment alone (losses.py:423-446), BEFORE any prediction exists: -> (pos_anchor, num_pos, token).  The next
+        forward whose predictions carry this token (utils/retinahead.final_convs(..., assignment=token)) reuses the assignment held
+        in the workspace instead of running it again."""
+        _lib.require_cuda(target)
+        dev = target.device
+        An = self._anchors_on(dev).shape[0]
+        pos = torch.empty(B * An, dtype=torch.int32, device=dev)
+        npos = torch.empty(1, dtype=torch.int32, device=dev)
+        tgt = target.float().contiguous()
+        self._launch(None, None, None, None, tgt, rows_only=(pos, npos), mode="assign", B=B)
+        token = object()
+        self._assignment = (token, tgt, pos, npos)
+        return pos, npos, token
+
+    def _launch(self, loc, cls, g_loc, g_cls, target, rows_only=None, mode=None, B=None):
         L = _lib.lib()
-        dev = loc.device
-        if loc.dtype != torch.float32 or cls.dtype != torch.float32:
-            raise TypeError("loc/cls predictions must be fp32")
-        anchors = self._anchors_on(dev)
-        B, An = loc.shape[0], loc.shape[1]
-        C = self.num_classes
-        if loc.shape != (B, An, 4) or cls.shape != (B, An, C) or anchors.shape != (An, 4):
-            raise ValueError(f"shape mismatch: loc {tuple(loc.shape)}, cls {tuple(cls.shape)}, anchors {tuple(anchors.shape)}")
+        if mode == "assign":
+            dev = target.device
+            anchors = self._anchors_on(dev)
+            An, C = anchors.shape[0], self.num_classes
+        else:
+            _lib.require_cuda(loc, cls, target)
+            dev = loc.device
+            if loc.dtype != torch.float32 or cls.dtype != torch.float32:
+                raise TypeError("loc/cls predictions must be fp32")
+            anchors = self._anchors_on(dev)
+            B, An = loc.shape[0], loc.shape[1]
+            C = self.num_classes
+            if loc.shape != (B, An, 4) or cls.shape != (B, An, C) or anchors.shape != (An, 4):
+                raise ValueError(f"shape mismatch: loc {tuple(loc.shape)}, cls {tuple(cls.shape)}, anchors {tuple(anchors.shape)}")
         tgt = target.float().contiguous()
         d = _lib.RetinaLossDesc()
-        d.loc, d.cls = loc.data_ptr(), cls.data_ptr()
+        d.loc, d.cls = (loc.data_ptr(), cls.data_ptr()) if loc is not None else (None, None)
         d.grad_loc = g_loc.data_ptr() if g_loc is not None else None
         d.grad_cls = g_cls.data_ptr() if g_cls is not None else None
         d.anchors = anchors.data_ptr()
@@ -149,6 +173,9 @@ class RetinaNetLoss(nn.Module):
             d.img_size, d.img_size_y = float(self.img_size[0]), float(self.img_size[1])
         else:
             d.img_size, d.img_size_y = float(self.img_size), 0.0
+        if mode == "assign":
+            d.flags = _lib.RETINA_ASSIGN_ONLY
+            d.pos_anchor, d.num_pos = rows_only[0].data_ptr(), rows_only[1].data_ptr()
         need = L.odpl_retina_loss_workspace_bytes(ctypes.byref(d))
         if need == 0:
             raise OdplError("odpl_retina_loss_workspace_bytes rejected the descriptor")
@@ -161,6 +188,17 @@ class RetinaNetLoss(nn.Module):
             d.flags |= _lib.RETINA_ROWS_ONLY
             d.pos_anchor, d.num_pos = rows_only[0].data_ptr(), rows_only[1].data_ptr()
         self._clean_key = None
+        if mode == "assign":
+            d.flags |= _lib.RETINA_ASSIGN_ONLY
+            _lib.check(L.odpl_retina_loss(ctypes.byref(d), _lib.ptr(self._ws), self._ws.numel(), None, None, _lib.current_stream(dev)),
+                       "odpl_retina_loss")
+            self._assigned_ws = (self._ws.data_ptr(), key)
+            return None, None
+        if mode == "assigned":
+            if getattr(self, "_assigned_ws", None) != (self._ws.data_ptr(), key):
+                raise OdplError("the assignment this forward was promised is gone (workspace or stream changed since RetinaNetLoss.assign)")
+            d.flags = (d.flags & ~_lib.RETINA_STATE_CLEAN) | _lib.RETINA_ASSIGNED
+        self._assigned_ws = None
         out3 = torch.empty(3, dtype=torch.float32, device=dev)
         counts = torch.empty(4, dtype=torch.int32, device=dev)
         _lib.check(L.odpl_retina_loss(ctypes.byref(d), _lib.ptr(self._ws), self._ws.numel(), _lib.ptr(out3),
@@ -173,8 +211,18 @@ class RetinaNetLoss(nn.Module):
         from .utils.retinahead import fusable_source
         loc_preds, cls_preds = outputs
         src = fusable_source(loc_preds, cls_preds) if self.fuse_head_backward else None
+        promised = getattr(loc_preds, "_odpl_retina_src", None)
+        if promised is not None and promised.get("assignment") is not None:
+            # predictions of a loss-driven step: they exist on this assignment's positive rows only -- no other consumer is valid
+            held = getattr(self, "_assignment", None)
+            self._assignment = None
+            if src is None or held is None or held[0] is not promised["assignment"]:
+                raise OdplError("these predictions were computed for one RetinaNetLoss.assign call only (its positive rows); "
+                                "run the dense forward for any other consumer")
+            loss, metrics, _ = _RetinaLossHeadFn.apply(self, held[1], loc_preds.detach(), cls_preds.detach(), src, held, *src["w"], *src["xs"])
+            return {"loss": loss, "Localization": metrics[0], "Classification": metrics[1]}
         if src is not None:
-            loss, metrics, _ = _RetinaLossHeadFn.apply(self, targets, loc_preds.detach(), cls_preds.detach(), src, *src["w"], *src["xs"])
+            loss, metrics, _ = _RetinaLossHeadFn.apply(self, targets, loc_preds.detach(), cls_preds.detach(), src, None, *src["w"], *src["xs"])
             return {"loss": loss, "Localization": metrics[0], "Classification": metrics[1]}
         loc_preds, cls_preds = (_widen(t) for t in outputs)
         loss, metrics, _ = _RetinaLossFn.apply(self, targets, loc_preds, cls_preds)

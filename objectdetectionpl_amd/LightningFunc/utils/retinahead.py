@@ -17,14 +17,64 @@ from ... import _lib
 enabled = True          # A/B switch (tools/bench_retina_step.py --no-hosted-heads): False = the plain nn.Conv2d modules + cat
 
 
+class PixelSupport:
+    """Per level l and reach j: the pixels within Chebyshev distance j of a pixel that owns a positive anchor (`odpl_pixel_support`),
+    as device lists.  `pair(l, j)` -> (list, count) for `sparseconv.forward_on_pixels`; `has(l)`: lists exist for that level."""
+
+    def __init__(self, pos, npos, B, shapes, depth, mask, A=9):
+        L = _lib.lib()
+        dev = pos.device
+        self.B, self.depth, self.mask, self.shapes = B, depth, mask, list(shapes)
+        pix = [B * h * w for h, w in shapes]
+        self.base = [depth * sum(pix[:i]) for i in range(len(pix))]
+        self.pix = pix
+        self.lists = torch.empty(depth * sum(pix), dtype=torch.int32, device=dev)
+        self.counts = torch.empty(len(pix) * depth, dtype=torch.int32, device=dev)
+        d = _lib.PixelSupport()
+        d.pos_anchor, d.num_pos = pos.data_ptr(), npos.data_ptr()
+        d.B, d.An, d.A, d.n_levels = B, A * sum(h * w for h, w in shapes), A, len(pix)
+        for i, (h, w) in enumerate(shapes):
+            d.H[i], d.W[i] = h, w
+        d.depth, d.level_mask = depth, mask
+        d.lists, d.counts = self.lists.data_ptr(), self.counts.data_ptr()
+        n = L.odpl_pixel_support_workspace_bytes(ctypes.byref(d))
+        if n == 0:
+            raise _lib.OdplError("odpl_pixel_support_workspace_bytes rejected the descriptor")
+        ws = torch.empty(n, dtype=torch.uint8, device=dev)
+        _lib.check(L.odpl_pixel_support(ctypes.byref(d), _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)), "odpl_pixel_support")
+
+    def has(self, l):
+        return bool((self.mask >> l) & 1)
+
+    def pair(self, l, j):
+        o = self.base[l] + j * self.pix[l]
+        return self.lists[o:o + self.pix[l]], self.counts[l * self.depth + j:l * self.depth + j + 1]
+
+
 class _FinalConvsFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, wl, bl, wc, bc, n, *xs):
+    def forward(ctx, wl, bl, wc, bc, n, support, *xs):
         B = xs[0].shape[0]
         outs = []
         for w, b, group in ((wl, bl, xs[:n]), (wc, bc, xs[n:])):
             no = w.shape[0] // 9
-            outs.append(torch.cat([F.conv2d(x, w, b, padding=1).permute(0, 2, 3, 1).reshape(B, -1, no) for x in group], 1))
+            if support is None:
+                outs.append(torch.cat([F.conv2d(x, w, b, padding=1).permute(0, 2, 3, 1).reshape(B, -1, no) for x in group], 1))
+                continue
+            # loss-driven step: on the levels with pixel lists only the pixels that own a positive anchor are evaluated (the rows the
+            # criterion reads); the other rows of those levels stay zero
+            from .sparseconv import forward_on_pixels
+            An = 9 * sum(x.shape[2] * x.shape[3] for x in group)
+            out = torch.zeros((B, An, no), dtype=torch.float32, device=xs[0].device)
+            first = 0
+            for l, x in enumerate(group):
+                rows = 9 * x.shape[2] * x.shape[3]
+                if support.has(l):
+                    forward_on_pixels(x, w, b, 0, support.pair(l, 0), out=out[:, first:first + rows], out_strides=(An * no, 9 * no))
+                else:
+                    out[:, first:first + rows] = F.conv2d(x, w, b, padding=1).permute(0, 2, 3, 1).reshape(B, rows, no)
+                first += rows
+            outs.append(out)
         ctx.save_for_backward(wl, bl, wc, bc, *xs)
         ctx.n = n
         return outs[0], outs[1]
@@ -54,15 +104,17 @@ class _FinalConvsFn(torch.autograd.Function):
                 gw = gwl if gw is None else gw + gwl
                 gb = gbl if gb is None else gb + gbl
             grads[name] = (gw, gb)
-        return (grads["l"][0], grads["l"][1], grads["c"][0], grads["c"][1], None) + tuple(gxs)
+        return (grads["l"][0], grads["l"][1], grads["c"][0], grads["c"][1], None, None) + tuple(gxs)
 
 
-def final_convs(loc_conv, cls_conv, xl, xc):
-    """-> (loc_preds, cls_preds); the outputs carry what the criterion needs to run both convolutions' backward itself."""
+def final_convs(loc_conv, cls_conv, xl, xc, support=None, assignment=None):
+    """-> (loc_preds, cls_preds); the outputs carry what the criterion needs to run both convolutions' backward itself.
+    support (PixelSupport) + assignment (RetinaNetLoss.assign's token): the loss-driven step -- predictions exist on the positive
+    pixels of the listed levels only, and ONLY the criterion that made the assignment may consume them."""
     n = len(xl)
-    loc, cls = _FinalConvsFn.apply(loc_conv.weight, loc_conv.bias, cls_conv.weight, cls_conv.bias, n, *xl, *xc)
+    loc, cls = _FinalConvsFn.apply(loc_conv.weight, loc_conv.bias, cls_conv.weight, cls_conv.bias, n, support, *xl, *xc)
     src = {"w": (loc_conv.weight, loc_conv.bias, cls_conv.weight, cls_conv.bias), "xs": tuple(xl) + tuple(xc), "n": n,
-           "versions": (loc._version, cls._version)}
+           "versions": (loc._version, cls._version), "assignment": assignment}
     loc._odpl_retina_src = src
     cls._odpl_retina_src = src
     return loc, cls

@@ -64,13 +64,18 @@ def _applicable(x, conv):
 
 class _ConvBiasActSparse(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, act, key):
+    def forward(ctx, x, w, b, act, key, support=None):
         ctx.key = key
-        z = F.conv2d(x, w, None, 1, 1)
-        N, C, H, W = z.shape
-        ones, zeros = _ones_zeros(z.device, C)
-        _lib.check(_lib.lib().odpl_bias_act_forward(_lib.ptr(z), N * H * W, C, _lib.ptr(b), _lib.ptr(ones), _lib.ptr(zeros), act, _lib.ptr(z),
-                                                    _lib.current_stream(z.device)), "odpl_bias_act_forward")
+        if support is not None:
+            # loss-driven step (utils/retinahead.py:pixel_support): act(conv(x) + b) on the listed pixels only, zero elsewhere -- the
+            # backward below never reads a pixel off that list
+            z = forward_on_pixels(x, w, b, act, support)
+        else:
+            z = F.conv2d(x, w, None, 1, 1)
+            N, C, H, W = z.shape
+            ones, zeros = _ones_zeros(z.device, C)
+            _lib.check(_lib.lib().odpl_bias_act_forward(_lib.ptr(z), N * H * W, C, _lib.ptr(b), _lib.ptr(ones), _lib.ptr(zeros), act, _lib.ptr(z),
+                                                        _lib.current_stream(z.device)), "odpl_bias_act_forward")
         ctx.save_for_backward(x, w, z)
         ctx.act = act
         return z
@@ -120,9 +125,29 @@ class _ConvBiasActSparse(torch.autograd.Function):
             ev = torch.cuda.Event()
             ev.record()
             rec["pending"] = (pinned, ev, R)
-        return gx, gw, gb, None, None
+        return gx, gw, gb, None, None, None
 
 
-def conv_bias_act(x, conv, act="relu"):
-    """`act(conv(x))` with the sparse backward; callers check `applicable(x, conv)` first."""
-    return _ConvBiasActSparse.apply(x, conv.weight, conv.bias, ACT[act], (id(conv.weight), x.shape[2], x.shape[3]))
+def forward_on_pixels(x, w, b, act, support, out=None, out_strides=None):
+    """`odpl_sparse_conv3x3_forward`: act(conv3x3(x) + b) at the pixels of support = (list, count) (device int32 tensors), written into
+    `out` (default: a zeroed channels-last map) with element strides out_strides = (batch, pixel)."""
+    N, Cin, H, W = x.shape
+    C = w.shape[0]
+    if out is None:
+        out = torch.zeros((N, H, W, C), dtype=torch.float32, device=x.device).permute(0, 3, 1, 2)        # channels-last [N, C, H, W]
+        out_strides = (H * W * C, C)
+    d = _lib.SparseConv3x3Fwd()
+    d.x, d.w, d.bias, d.y = x.data_ptr(), w.data_ptr(), (b.data_ptr() if b is not None else None), out.data_ptr()
+    for k in range(4):
+        d.w_stride[k] = w.stride(k)
+    d.y_batch_stride, d.y_pixel_stride = out_strides
+    d.list, d.count = support[0].data_ptr(), support[1].data_ptr()
+    d.B, d.H, d.W, d.Cin, d.Cout, d.act = N, H, W, Cin, C, act
+    _lib.check(_lib.lib().odpl_sparse_conv3x3_forward(ctypes.byref(d), _lib.current_stream(x.device)), "odpl_sparse_conv3x3_forward")
+    return out
+
+
+def conv_bias_act(x, conv, act="relu", support=None):
+    """`act(conv(x))` with the sparse backward; callers check `applicable(x, conv)` first.  support = (pixel list, count): evaluate
+    the forward on those pixels only (a loss-driven training step)."""
+    return _ConvBiasActSparse.apply(x, conv.weight, conv.bias, ACT[act], (id(conv.weight), x.shape[2], x.shape[3]), support)

@@ -6,7 +6,7 @@ from ctypes import POINTER, c_float, c_int32, c_size_t, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libodpl_hip.so")
 
-ABI_VERSION = 4            # include/odpl_hip.h: ODPL_ABI_VERSION
+ABI_VERSION = 5            # include/odpl_hip.h: ODPL_ABI_VERSION
 LAYOUT_PLANAR, LAYOUT_INTERLEAVED = 0, 1
 MAX_SCALES = 4
 MAX_ANCHORS = 8
@@ -71,6 +71,19 @@ class SparseConv3x3(ctypes.Structure):
     _fields_ = [("x", c_void_p), ("gy", c_void_p), ("active", c_void_p), ("w", c_void_p), ("grad_x", c_void_p), ("grad_w", c_void_p),
                 ("w_stride", ctypes.c_int64 * 4), ("B", c_int32), ("H", c_int32), ("W", c_int32), ("Cin", c_int32), ("Cout", c_int32),
                 ("stats", c_void_p)]
+
+
+class PixelSupport(ctypes.Structure):
+    """odpl_pixel_support_t"""
+    _fields_ = [("pos_anchor", c_void_p), ("num_pos", c_void_p), ("B", c_int32), ("An", c_int32), ("A", c_int32), ("n_levels", c_int32),
+                ("H", c_int32 * 8), ("W", c_int32 * 8), ("depth", c_int32), ("level_mask", c_int32), ("lists", c_void_p), ("counts", c_void_p)]
+
+
+class SparseConv3x3Fwd(ctypes.Structure):
+    """odpl_sparse_conv3x3_fwd_t"""
+    _fields_ = [("x", c_void_p), ("w", c_void_p), ("bias", c_void_p), ("w_stride", ctypes.c_int64 * 4), ("y", c_void_p),
+                ("y_batch_stride", ctypes.c_int64), ("y_pixel_stride", ctypes.c_int64), ("list", c_void_p), ("count", c_void_p),
+                ("B", c_int32), ("H", c_int32), ("W", c_int32), ("Cin", c_int32), ("Cout", c_int32), ("act", c_int32)]
 
 
 class YoloNmsDesc(ctypes.Structure):
@@ -181,6 +194,9 @@ SIGNATURES = {
     "odpl_bias_act_backward_flags": (c_int32, [c_void_p, c_void_p, ctypes.c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_size_t, c_void_p]),
     "odpl_sparse_conv3x3_backward_workspace_bytes": (c_size_t, [c_void_p]),
     "odpl_sparse_conv3x3_backward": (c_int32, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "odpl_pixel_support_workspace_bytes": (c_size_t, [c_void_p]),
+    "odpl_pixel_support": (c_int32, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "odpl_sparse_conv3x3_forward": (c_int32, [c_void_p, c_void_p]),
     "odpl_upsample2x_nearest": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, ctypes.c_int64, ctypes.c_int64, c_int32, c_void_p]),
     "odpl_spp_forward": (c_int32, [c_void_p, POINTER(ctypes.c_int64), c_int32, c_int32, c_int32, c_int32, c_void_p, POINTER(ctypes.c_int64), c_void_p]),
     "odpl_spp_backward": (c_int32, [c_void_p, POINTER(ctypes.c_int64), c_int32, c_int32, c_int32, c_int32, c_void_p, POINTER(ctypes.c_int64), c_void_p, c_void_p]),
@@ -260,6 +276,8 @@ def require_cuda(*tensors):
 YOLO_STATE_CLEAN = 1
 RETINA_STATE_CLEAN = 1
 RETINA_ROWS_ONLY = 2
+RETINA_ASSIGN_ONLY = 4
+RETINA_ASSIGNED = 8
 YOLOV5_STATE_CLEAN = 1
 IOU_MODES = {"iou": 0, "giou": 1, "diou": 2, "ciou": 3}
 TUNE_KEYS = {"yolo_fill_f4_per_block": 0, "yolo_fill_nt": 1, "retina_fill_nt": 2, "bn_target_blocks": 3, "bn_stream_max_blocks": 4, "bn_max_rows_per_tile": 5, "bn_slice_from_c": 6, "bn_fused": 7,

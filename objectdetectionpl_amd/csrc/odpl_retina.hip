@@ -233,6 +233,18 @@ __global__ __launch_bounds__(kT) void retina_main_kernel(const RParams P) {
     }
 }
 
+// ODPL_RETINA_ASSIGN_ONLY: the positive rows in ascending (b, a) order and their number, before any prediction exists
+__global__ __launch_bounds__(kT) void retina_poslist_kernel(const RParams P) {
+    const int num_pos = P.tile_off[P.ntiles];
+    for (int r = blockIdx.x * kT + threadIdx.x; r < num_pos; r += gridDim.x * kT) {
+        const int tile = P.row_tile[r];
+        const int local = P.tile_pos[(size_t)tile * kT + (r - P.tile_off[tile])];
+        const int b = tile / P.nblk_x, a = (tile - b * P.nblk_x) * kT + local;
+        P.pos_anchor[r] = b * P.An + a;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) P.num_pos_out[0] = num_pos;
+}
+
 __global__ __launch_bounds__(256) void retina_finalize_kernel(const RParams P) {
     __shared__ double sh[2 * 4];
     const int tid = threadIdx.x, n = P.tile_off[P.ntiles];
@@ -261,9 +273,16 @@ struct RPlan { size_t status, code, tile_cnt, tile_off, row_tile, tile_pos, part
 
 bool make_rplan(const odpl_retina_loss_desc_t* d, RPlan* p) {
     if (!d || d->B < 1 || d->An < 1 || d->C < 1 || d->C > 4094 || d->nT < 0 || d->nT > (1 << 19)) return false;
-    if (!d->loc || !d->cls || !d->anchors || (d->nT > 0 && !d->target)) return false;
-    if ((d->grad_loc == nullptr) != (d->grad_cls == nullptr)) return false;
-    if ((d->flags & ODPL_RETINA_ROWS_ONLY) && (!d->grad_cls || !d->pos_anchor || !d->num_pos)) return false;
+    const bool assign_only = (d->flags & ODPL_RETINA_ASSIGN_ONLY) != 0;
+    if (assign_only && (d->flags & ODPL_RETINA_ASSIGNED)) return false;
+    if (!d->anchors || (d->nT > 0 && !d->target)) return false;
+    if (assign_only) {
+        if (!d->pos_anchor || !d->num_pos) return false;
+    } else {
+        if (!d->loc || !d->cls) return false;
+        if ((d->grad_loc == nullptr) != (d->grad_cls == nullptr)) return false;
+        if ((d->flags & ODPL_RETINA_ROWS_ONLY) && (!d->grad_cls || !d->pos_anchor || !d->num_pos)) return false;
+    }
     if ((long long)d->B * d->An * d->C > 0x7fffffffLL * 4) return false;
     p->nblk_x = (d->An + kT - 1) / kT;
     p->ntiles = p->nblk_x * d->B;
@@ -289,7 +308,9 @@ extern "C" size_t odpl_retina_loss_workspace_bytes(const odpl_retina_loss_desc_t
 extern "C" int odpl_retina_loss(const odpl_retina_loss_desc_t* d, void* workspace, size_t workspace_bytes,
                                 float* out3, int32_t* out_counts, void* stream_) {
     RPlan pl;
-    if (!make_rplan(d, &pl) || !workspace || workspace_bytes < pl.total || !out3) return ODPL_EINVAL;
+    if (!make_rplan(d, &pl) || !workspace || workspace_bytes < pl.total) return ODPL_EINVAL;
+    const bool assign_only = (d->flags & ODPL_RETINA_ASSIGN_ONLY) != 0, assigned = (d->flags & ODPL_RETINA_ASSIGNED) != 0;
+    if (!assign_only && !out3) return ODPL_EINVAL;
     const uintptr_t al = (uintptr_t)workspace | (uintptr_t)d->anchors | (uintptr_t)d->grad_loc | (uintptr_t)d->grad_cls;
     if (al & 15) return ODPL_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
@@ -304,15 +325,22 @@ extern "C" int odpl_retina_loss(const odpl_retina_loss_desc_t* d, void* workspac
     P.status = (int*)(ws + pl.status); P.part = (float*)(ws + pl.part);
     P.out3 = out3; P.out_counts = out_counts;
     const bool rows_only = (d->flags & ODPL_RETINA_ROWS_ONLY) != 0;
-    P.pos_anchor = rows_only ? d->pos_anchor : nullptr; P.num_pos_out = rows_only ? d->num_pos : nullptr;
-    if (!(d->flags & ODPL_RETINA_STATE_CLEAN)) ODPL_HIP_TRY(odpl::fill_bytes(P.status, 0, 256, stream));
-    const dim3 grid(pl.nblk_x, d->B);
-    prof_begin(ODPL_PROF_RETINA_ASSIGN, stream);
-    hipLaunchKernelGGL(retina_assign_kernel, grid, dim3(kT), 0, stream, P);
-    prof_end(ODPL_PROF_RETINA_ASSIGN, stream);
-    ODPL_HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(retina_scan_kernel, dim3(1), dim3(1024), 0, stream, P);
-    ODPL_HIP_TRY(hipGetLastError());
+    P.pos_anchor = (rows_only || assign_only) ? d->pos_anchor : nullptr; P.num_pos_out = (rows_only || assign_only) ? d->num_pos : nullptr;
+    if (!assigned) {                                  // (an ASSIGNED call finds the status word as the ASSIGN_ONLY call left it)
+        if (!(d->flags & ODPL_RETINA_STATE_CLEAN)) ODPL_HIP_TRY(odpl::fill_bytes(P.status, 0, 256, stream));
+        const dim3 grid(pl.nblk_x, d->B);
+        prof_begin(ODPL_PROF_RETINA_ASSIGN, stream);
+        hipLaunchKernelGGL(retina_assign_kernel, grid, dim3(kT), 0, stream, P);
+        prof_end(ODPL_PROF_RETINA_ASSIGN, stream);
+        ODPL_HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(retina_scan_kernel, dim3(1), dim3(1024), 0, stream, P);
+        ODPL_HIP_TRY(hipGetLastError());
+    }
+    if (assign_only) {
+        hipLaunchKernelGGL(retina_poslist_kernel, dim3(32), dim3(kT), 0, stream, P);
+        ODPL_HIP_TRY(hipGetLastError());
+        return 0;
+    }
     const int nmain = kRowWGs + ((d->grad_cls && !rows_only) ? pl.ntiles : 0);      // rows only: no zero stream
     prof_begin(ODPL_PROF_RETINA_MAIN, stream);
     if (g_retina_fill_nt) hipLaunchKernelGGL(retina_main_kernel<true>, dim3(nmain), dim3(kT), 0, stream, P);

@@ -144,13 +144,19 @@ class RetinaNet(_Base):
         return nn.Sequential(*layers)
 
     @staticmethod
-    def _run_tower(head, fm):
+    def _run_tower(head, fm, support=None, level=0):
         """the four [Conv2d(256,256,3,1,1), ReLU] units of a head (RetinaNet.py:93-99): MIOpen convolution + one fused epilogue each
-        (utils/bnact.py:conv_bias_act)"""
+        (utils/bnact.py:conv_bias_act).  support (utils/retinahead.PixelSupport, a loss-driven training step): on the levels it lists,
+        unit t of n is evaluated within n - t pixels of a positive anchor only -- what the units after it and the criterion will read."""
         mods = list(head)
-        for i in range(0, len(mods) - 1, 2):
+        n = (len(mods) - 1) // 2
+        for t, i in enumerate(range(0, len(mods) - 1, 2)):
             # on the large levels the backward of conv + bias + ReLU walks the pixels that carry a gradient only (utils/sparseconv.py)
-            fm = _sc.conv_bias_act(fm, mods[i], "relu") if _sc.applicable(fm, mods[i]) else _bnact.conv_bias_act(fm, mods[i], "relu")
+            if _sc.applicable(fm, mods[i]):
+                sup = support.pair(level, n - t) if support is not None and support.has(level) else None
+                fm = _sc.conv_bias_act(fm, mods[i], "relu", sup)
+            else:
+                fm = _bnact.conv_bias_act(fm, mods[i], "relu")
         return fm
 
     @classmethod
@@ -163,7 +169,9 @@ class RetinaNet(_Base):
     def forward(self, x):
         if x.is_cuda and (self.iou_boxes is None or self.iou_boxes.device != x.device):
             self._build_anchors(x.device)          # the anchor table (criterion / NMS side) lives on the HIP device only
-        feats = self.fpn(x)
+        return self._heads(x, self.fpn(x))
+
+    def _heads(self, x, feats):
         if (x.is_cuda and _rh.enabled and self.num_anchors == 9 and _rh.is_hostable(self.loc_head[-1]) and _rh.is_hostable(self.cls_head[-1])
                 and feats[0].dtype == torch.float32):
             # the two final convolutions of all levels hosted together: RetinaNetLoss can then run their backward from its structured
@@ -176,6 +184,47 @@ class RetinaNet(_Base):
             loc.append(self._run_head(self.loc_head, fm).permute(0, 2, 3, 1).contiguous().view(x.size(0), -1, 4))
             cls.append(self._run_head(self.cls_head, fm).permute(0, 2, 3, 1).contiguous().view(x.size(0), -1, self.num_classes))
         return torch.cat(loc, 1), torch.cat(cls, 1)
+
+    loss_driven_step = True        # class switch (tools/bench_retina_step.py --dense-forward): False = training_step is forward + criterion
+
+    def _loss_driven_mask(self, x, y, feats):
+        """Levels of the heads a training step may evaluate on the criterion's pixels only (0 = take the dense route): the criterion
+        is the fused RetinaNetLoss over THIS input's anchor table, fp32 outside autocast, both heads hostable with 4 units each."""
+        from ..LightningFunc.losses_dense import RetinaNetLoss
+        crit = self.criterion
+        if not (self.loss_driven_step and self.training and torch.is_grad_enabled() and x.is_cuda and _rh.enabled and _sc.enabled
+                and type(crit) is RetinaNetLoss and crit.fuse_head_backward and self.num_anchors == 9 and torch.is_tensor(y) and y.is_cuda
+                and feats[0].dtype == torch.float32 and not torch.is_autocast_enabled()
+                and _rh.is_hostable(self.loc_head[-1]) and _rh.is_hostable(self.cls_head[-1])
+                and len(self.loc_head) == 9 and len(self.cls_head) == 9 and crit.num_classes == self.num_classes):
+            return 0
+        if 9 * sum(f.shape[2] * f.shape[3] for f in feats) != len(crit.iou_boxes) or any(f.shape[1] % 32 or f.shape[1] > 448 for f in feats):
+            return 0
+        mask = 0
+        for l, f in enumerate(feats):
+            if _sc._applicable(f, self.loc_head[0]) and _sc._applicable(f, self.cls_head[0]):
+                mask |= 1 << l
+        return mask
+
+    def forward_and_loss(self, x, y):
+        """`criterion(forward(x), y)` (step.py:17-18) for a training step.  RetinaNetLoss reads the positive anchor rows of the
+        predictions and nothing else (losses.py:336-339, 458-461), and which rows those are depends on anchors and boxes only: the
+        assignment runs first and the heads are evaluated where the loss will look (csrc/odpl_sparsefwd.hip) -- same loss, same
+        gradients, the predictions of the other rows are never formed.  Anything else about the step falls back to forward + criterion."""
+        if x.is_cuda and (self.iou_boxes is None or self.iou_boxes.device != x.device):
+            self._build_anchors(x.device)
+        feats = self.fpn(x) if x.is_cuda else None
+        mask = self._loss_driven_mask(x, y, feats) if feats is not None else 0
+        if not mask:
+            return self.criterion(self._heads(x, feats) if feats is not None else self.forward(x), y)
+        crit = self.criterion
+        pos, npos, token = crit.assign(y, x.shape[0])
+        n_units = (len(self.loc_head) - 1) // 2
+        sup = _rh.PixelSupport(pos, npos, x.shape[0], [(f.shape[2], f.shape[3]) for f in feats], n_units + 1, mask)
+        xl = [self._run_tower(self.loc_head, fm, sup, l) for l, fm in enumerate(feats)]
+        xc = [self._run_tower(self.cls_head, fm, sup, l) for l, fm in enumerate(feats)]
+        out = _rh.final_convs(self.loc_head[-1], self.cls_head[-1], xl, xc, support=sup, assignment=token)
+        return crit(out, y)
 
     def freeze_bn(self):
         for m in self.modules():

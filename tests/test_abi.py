@@ -21,7 +21,7 @@ def test_header_symbols_exported_and_bound():
     for n in names:
         assert hasattr(raw, n), f"{n} declared in odpl_hip.h but not exported"
     assert sorted(_lib.SIGNATURES) == names, (set(names) ^ set(_lib.SIGNATURES))
-    assert _lib.lib().odpl_abi_version() == _lib.ABI_VERSION == 4
+    assert _lib.lib().odpl_abi_version() == _lib.ABI_VERSION == 5
 
 
 def test_struct_layout_matches_header():
@@ -39,6 +39,31 @@ def test_struct_layout_matches_header():
     # odpl_retina_head_t: 5 + 5 + 4 pointers, 4 int64 strides, int32 (+pad); odpl_retina_heads_desc_t: 14 int32 + 3 pointers
     assert ctypes.sizeof(_lib.RetinaHead) == 152 and _lib.RetinaHead.w_stride.offset == 112
     assert ctypes.sizeof(_lib.RetinaHeadsDesc) == 80 and _lib.RetinaHeadsDesc.pos_anchor.offset == 56
+
+
+def test_ctypes_layouts_against_the_compiled_header(tmp_path):
+    """sizeof / offsetof as gcc sees include/odpl_hip.h, against the ctypes mirrors (last field of each struct pins the whole layout)"""
+    import subprocess
+    from objectdetectionpl_amd import _lib
+    cases = [("odpl_retina_loss_desc_t", _lib.RetinaLossDesc, "num_pos"), ("odpl_retina_head_t", _lib.RetinaHead, "no"),
+             ("odpl_retina_heads_desc_t", _lib.RetinaHeadsDesc, "upstream"), ("odpl_sparse_conv3x3_t", _lib.SparseConv3x3, "stats"),
+             ("odpl_pixel_support_t", _lib.PixelSupport, "counts"), ("odpl_sparse_conv3x3_fwd_t", _lib.SparseConv3x3Fwd, "act"),
+             ("odpl_yolo_scale_t", _lib.YoloScale, "stride"), ("odpl_sparse_grad_t", _lib.SparseGrad, None)]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{REPO}/include/odpl_hip.h"', 'int main(void) {']
+    for cname, _, last in cases:
+        off = f"offsetof({cname}, {last})" if last else "(size_t)0"
+        lines.append(f'  printf("%zu %zu\\n", sizeof({cname}), {off});')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-o", str(exe), str(src)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    for (cname, ct, last), line in zip(cases, out):
+        size, off = (int(v) for v in line.split())
+        assert ctypes.sizeof(ct) == size, cname
+        if last:
+            assert getattr(ct, last).offset == off, (cname, last)
 
 
 def test_workspace_query_is_host_only():

@@ -1,0 +1,302 @@
+"""The loss-driven training step of RetinaNet (csrc/odpl_sparsefwd.hip, model/RetinaNet.py:forward_and_loss): assignment first,
+then the heads evaluated only where RetinaNetLoss (losses.py:405-472) will read -- against the dense forward + criterion."""
+import argparse
+import ctypes
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from objectdetectionpl_amd import _lib
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _close(a, b, rtol=1e-4, atol_scale=1e-5):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    assert a.shape == b.shape
+    tol = atol_scale * float(b.abs().max()) + 1e-12
+    assert torch.allclose(a, b, rtol=rtol, atol=tol), float((a - b).abs().max())
+
+
+def _targets(g, B, per, C):
+    n = B * per
+    wh = torch.rand(n, 2, generator=g) * 0.35 + 0.15
+    cxy = torch.rand(n, 2, generator=g) * (1 - wh) + wh / 2
+    return torch.cat([torch.arange(B).repeat_interleave(per).float()[:, None], torch.randint(0, C, (n, 1), generator=g).float(), cxy, wh], 1)
+
+
+@pytest.mark.parametrize("B,shapes,depth,mask,npos", [(2, [(16, 20), (8, 10), (4, 5)], 5, 0b011, 40), (3, [(33, 7), (5, 5)], 3, 0b11, 9),
+                                                      (1, [(64, 64), (32, 32), (16, 16), (8, 8), (4, 4)], 5, 0b00101, 300),
+                                                      (2, [(9, 9)], 8, 1, 0)])
+def test_pixel_support_lists_are_the_dilated_positive_pixels(B, shapes, depth, mask, npos):
+    """slot (l, j) = the pixels of level l within Chebyshev distance j of a pixel owning a positive anchor (numpy dilation); list
+    order is not defined, so sets are compared; levels off the mask get nothing."""
+    from objectdetectionpl_amd.LightningFunc.utils.retinahead import PixelSupport
+    A = 9
+    An = A * sum(h * w for h, w in shapes)
+    rng = np.random.default_rng(3)
+    rows = np.sort(rng.choice(B * An, size=npos, replace=False)).astype(np.int32)
+    pos = torch.zeros(B * An, dtype=torch.int32, device=DEV)
+    pos[:npos] = torch.from_numpy(rows).to(DEV)
+    cnt = torch.tensor([npos], dtype=torch.int32, device=DEV)
+    sup = PixelSupport(pos, cnt, B, shapes, depth, mask)
+    torch.cuda.synchronize()
+    first = np.cumsum([0] + [A * h * w for h, w in shapes])
+    for l, (h, w) in enumerate(shapes):
+        m0 = np.zeros((B, h, w), dtype=bool)
+        for r in rows:
+            b, a = divmod(int(r), An)
+            if first[l] <= a < first[l + 1]:
+                pix = (a - first[l]) // A
+                m0[b, pix // w, pix % w] = True
+        for j in range(depth):
+            lst, c = sup.pair(l, j)
+            n = int(c.item())
+            if not (mask >> l) & 1:
+                assert n == 0
+                continue
+            mj = np.zeros_like(m0)
+            for dy in range(-j, j + 1):
+                for dx in range(-j, j + 1):
+                    sh = np.zeros_like(m0)
+                    ys, xs = slice(max(dy, 0), h + min(dy, 0)), slice(max(dx, 0), w + min(dx, 0))
+                    yd, xd = slice(max(-dy, 0), h + min(-dy, 0)), slice(max(-dx, 0), w + min(-dx, 0))
+                    sh[:, yd, xd] = m0[:, ys, xs]
+                    mj |= sh
+            want = np.flatnonzero(mj.reshape(-1))
+            got = np.sort(lst[:n].cpu().numpy())
+            assert n == len(want) and np.array_equal(got, want), (l, j)
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,act,weights_cl,frac", [(2, 20, 24, 64, 64, "relu", True, 0.2), (1, 7, 9, 32, 36, "linear", False, 0.5),
+                                                                (2, 16, 16, 256, 720, "linear", True, 0.1), (1, 12, 12, 96, 100, "leaky", True, 1.0),
+                                                                (2, 10, 10, 64, 128, "relu", True, 0.0)])
+def test_forward_on_pixels_is_the_dense_convolution_there_and_nothing_elsewhere(B, H, W, cin, cout, act, weights_cl, frac):
+    from objectdetectionpl_amd.LightningFunc.utils import sparseconv as sc
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, cin, H, W, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    conv = nn.Conv2d(cin, cout, 3, 1, 1).to(DEV)
+    if weights_cl:
+        conv = conv.to(memory_format=torch.channels_last)
+    P = B * H * W
+    sel = torch.randperm(P, generator=g)[:int(round(frac * P))].to(torch.int32)
+    lst = torch.full((P,), -7, dtype=torch.int32, device=DEV)
+    lst[:sel.numel()] = sel.to(DEV)
+    cnt = torch.tensor([sel.numel()], dtype=torch.int32, device=DEV)
+    with torch.no_grad():
+        want = F.conv2d(x, conv.weight, conv.bias, padding=1)
+        want = {"relu": F.relu, "linear": lambda t: t, "leaky": lambda t: F.leaky_relu(t, 0.1)}[act](want)
+        got = sc.forward_on_pixels(x, conv.weight, conv.bias, sc.ACT[act], (lst, cnt))
+    on = torch.zeros(P, dtype=torch.bool)
+    on[sel.long()] = True
+    gm = got.permute(0, 2, 3, 1).reshape(P, cout).cpu()
+    wm = want.permute(0, 2, 3, 1).reshape(P, cout).cpu()
+    assert torch.count_nonzero(gm[~on]) == 0                                   # the zeros the caller put there
+    if on.any():
+        _close(gm[on], wm[on], 1e-4, 2e-6)
+
+
+def test_forward_on_pixels_writes_prediction_table_rows():
+    """the final convolutions write straight into a level's slice of the [B, An, no] table (batch stride An * no, pixel stride 9 * no)"""
+    from objectdetectionpl_amd.LightningFunc.utils import sparseconv as sc
+    g = torch.Generator().manual_seed(6)
+    B, H, W, cin, no = 2, 6, 5, 32, 4
+    An = 9 * (H * W + 11)
+    x = torch.randn(B, cin, H, W, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    conv = nn.Conv2d(cin, 9 * no, 3, 1, 1).to(DEV)
+    table = torch.zeros(B, An, no, device=DEV)
+    first = 9 * 11
+    P = B * H * W
+    lst = torch.arange(0, P, 3, dtype=torch.int32, device=DEV)
+    cnt = torch.tensor([lst.numel()], dtype=torch.int32, device=DEV)
+    with torch.no_grad():
+        sc.forward_on_pixels(x, conv.weight, conv.bias, 0, (lst, cnt), out=table[:, first:first + 9 * H * W], out_strides=(An * no, 9 * no))
+        want = conv(x).permute(0, 2, 3, 1).reshape(B, H * W * 9, no)
+    got = table[:, first:first + 9 * H * W].reshape(B * H * W, 9 * no).cpu()
+    want = want.reshape(B * H * W, 9 * no).cpu()
+    on = torch.zeros(P, dtype=torch.bool)
+    on[lst.long().cpu()] = True
+    _close(got[on], want[on], 1e-4, 2e-6)
+    assert torch.count_nonzero(got[~on]) == 0 and torch.count_nonzero(table[:, :first]) == 0
+
+
+def test_split_assignment_gives_the_one_call_loss_bit_for_bit():
+    """ODPL_RETINA_ASSIGN_ONLY, then ODPL_RETINA_ASSIGNED on the same workspace == one odpl_retina_loss call: loss, positive rows, the
+    gradient on those rows"""
+    from objectdetectionpl_amd.LightningFunc.losses_dense import RetinaNetLoss, focal_loss
+    from objectdetectionpl_amd.LightningFunc.utils.RetinaUtils import get_anchor_boxes
+    g = torch.Generator().manual_seed(7)
+    B, C, size = 3, 6, 192
+    anchors = get_anchor_boxes(torch.Tensor([size, size]), torch.device(DEV))
+    An = anchors.shape[0]
+    loc = torch.randn(B, An, 4, generator=g).to(DEV) * 0.3
+    cls = torch.randn(B, An, C, generator=g).to(DEV)
+    y = _targets(g, B, 4, C).to(DEV)
+    crit = RetinaNetLoss(anchors, focal_loss, "smooth_l1_loss", C, size)
+    res = []
+    for split in (False, True):
+        g_loc, g_cls = torch.zeros_like(loc), torch.zeros_like(cls)
+        pos = torch.zeros(B * An, dtype=torch.int32, device=DEV)
+        npos = torch.zeros(1, dtype=torch.int32, device=DEV)
+        if split:
+            pos, npos, _ = crit.assign(y, B)
+            first = (pos.clone(), npos.clone())
+            out3, counts = crit._launch(loc, cls, g_loc, g_cls, y, rows_only=(pos, npos), mode="assigned")
+            assert torch.equal(first[0][:int(first[1])], pos[:int(npos)]) and torch.equal(first[1], npos)
+        else:
+            out3, counts = crit._launch(loc, cls, g_loc, g_cls, y, rows_only=(pos, npos))
+        res.append((out3.clone(), counts.clone(), pos[:int(npos)].clone(), g_loc, g_cls))
+    assert int(res[0][1][0]) > 10
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+    with pytest.raises(_lib.OdplError):                                          # nothing promised any more
+        crit._launch(loc, cls, torch.zeros_like(loc), torch.zeros_like(cls), y, rows_only=(pos, npos), mode="assigned")
+
+
+def _model(C, size):
+    from objectdetectionpl_amd.model.RetinaNet import RetinaNet
+    args = argparse.Namespace(model_name="RetinaNet", cls_criterion="focal_loss", coord_criterion="smooth_l1_loss", data_module="synthetic")
+    RetinaNet.img_size = size
+    try:
+        return RetinaNet([str(i) for i in range(C)], args).to(DEV).to(memory_format=torch.channels_last).train()
+    finally:
+        RetinaNet.img_size = 600
+
+
+@pytest.mark.parametrize("size,B,mask", [(256, 2, 0b11111), (320, 3, 0b00001), (256, 1, 0b00110)])
+def test_heads_on_the_loss_pixels_give_the_dense_loss_and_gradients(size, B, mask):
+    """Both heads on FIXED feature maps: assignment -> pixel lists -> towers and final convolutions on those pixels -> criterion,
+    against the dense heads + criterion: loss, the predictions on the positive rows, d loss / d (every head parameter) and
+    d loss / d (every feature map).  (Fixed inputs: the backbone's library kernels are not run-to-run reproducible, and a ReLU that
+    flips on a 1e-7 difference moves a gradient by far more than rounding.)"""
+    from objectdetectionpl_amd.LightningFunc.utils import retinahead as rh
+    from objectdetectionpl_amd.LightningFunc.utils import sparseconv as sc
+    torch.manual_seed(0)
+    C = 5
+    model = _model(C, size)
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand(B, 3, size, size, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    y = _targets(g, B, 3, C).to(DEV)
+    with torch.no_grad():
+        feats = [f.clone() for f in model.fpn(x)]
+    old = sc.min_pixels, sc.max_density
+    sc.min_pixels, sc.max_density = 1, 2.0
+    res = {}
+    try:
+        for mode in ("dense", "driven"):
+            fs = [f.clone().requires_grad_() for f in feats]
+            model.zero_grad(set_to_none=True)
+            crit = model.criterion
+            if mode == "driven":
+                pos, npos, token = crit.assign(y, B)
+                sup = rh.PixelSupport(pos, npos, B, [(f.shape[2], f.shape[3]) for f in fs], 5, mask)
+                xl = [model._run_tower(model.loc_head, fm, sup, l) for l, fm in enumerate(fs)]
+                xc = [model._run_tower(model.cls_head, fm, sup, l) for l, fm in enumerate(fs)]
+                out = rh.final_convs(model.loc_head[-1], model.cls_head[-1], xl, xc, support=sup, assignment=token)
+            else:
+                out = rh.final_convs(model.loc_head[-1], model.cls_head[-1], [model._run_tower(model.loc_head, fm) for fm in fs],
+                                     [model._run_tower(model.cls_head, fm) for fm in fs])
+            d = crit(out, y)
+            d["loss"].backward()
+            n = int(crit.last_counts[0])
+            res[mode] = ({k: float(v.detach()) for k, v in d.items()}, [o.detach().clone() for o in out], [f.grad.clone() for f in fs],
+                         {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}, n,
+                         (pos[:n].long().clone() if mode == "driven" else None))
+    finally:
+        sc.min_pixels, sc.max_density = old
+    dn, dr = res["dense"], res["driven"]
+    assert dn[4] == dr[4] > 20
+    for k in dn[0]:
+        assert abs(dn[0][k] - dr[0][k]) <= 1e-5 * abs(dn[0][k]), (k, dn[0], dr[0])
+    rows = dr[5]
+    _close(dr[1][0].reshape(-1, 4)[rows], dn[1][0].reshape(-1, 4)[rows], 1e-4, 1e-5)
+    _close(dr[1][1].reshape(-1, C)[rows], dn[1][1].reshape(-1, C)[rows], 1e-4, 1e-5)
+    assert len(dn[3]) == len(dr[3]) == 20
+    for k in dn[3]:
+        _close(dr[3][k], dn[3][k], 1e-3, 2e-5)
+    for a, b in zip(dr[2], dn[2]):
+        _close(a, b, 1e-3, 2e-5)
+
+
+def test_training_step_takes_the_loss_driven_route():
+    """`training_step` (step.py:14-25) end to end on both routes: same loss dict and positive count, every parameter gets a gradient,
+    and the two full gradients point the same way (cosine; element-wise equality is not defined across two runs of the backbone)."""
+    from objectdetectionpl_amd.LightningFunc.utils import sparseconv as sc
+    from objectdetectionpl_amd.model.RetinaNet import RetinaNet
+    torch.manual_seed(0)
+    C, size, B = 5, 384, 3
+    model = _model(C, size)
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand(B, 3, size, size, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    y = _targets(g, B, 3, C).to(DEV)
+    old = sc.min_pixels
+    sc.min_pixels = 1500                                                         # levels 48^2 and 24^2 x 3 images on pixel lists
+    res = []
+    try:
+        for driven in (True, False):
+            RetinaNet.loss_driven_step = driven
+            model.zero_grad(set_to_none=True)
+            calls = []
+            orig = sc.forward_on_pixels
+            sc.forward_on_pixels = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+            try:
+                d = model.training_step((x, y), 0)
+            finally:
+                sc.forward_on_pixels = orig
+            d["loss"].backward()
+            assert len(calls) == (20 if driven else 0)                            # 2 levels x 2 heads x (4 tower units + the final convolution)
+            assert all(p.grad is not None for p in model.parameters())
+            res.append(({k: float(v.detach()) for k, v in d.items()}, torch.cat([p.grad.flatten().double() for p in model.parameters()]),
+                        int(model.criterion.last_counts[0])))
+    finally:
+        RetinaNet.loss_driven_step = True
+        sc.min_pixels = old
+    assert res[0][2] == res[1][2] > 0
+    for k in res[1][0]:
+        assert abs(res[0][0][k] - res[1][0][k]) <= 2e-5 * abs(res[1][0][k]), (k, res[0][0], res[1][0])
+    cos = float(torch.dot(res[0][1], res[1][1]) / (res[0][1].norm() * res[1][1].norm()))
+    assert cos > 0.9995, cos
+
+
+def test_predictions_of_a_loss_driven_step_serve_that_assignment_only():
+    from objectdetectionpl_amd.LightningFunc.utils import retinahead as rh
+    from objectdetectionpl_amd.LightningFunc.utils import sparseconv as sc
+    torch.manual_seed(0)
+    model = _model(3, 128)
+    g = torch.Generator().manual_seed(12)
+    x = torch.rand(2, 3, 128, 128, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    y = _targets(g, 2, 2, 3).to(DEV)
+    crit = model.criterion
+    old = sc.min_pixels
+    sc.min_pixels = 1
+    try:
+        feats = model.fpn(x)
+        pos, npos, token = crit.assign(y, 2)
+        sup = rh.PixelSupport(pos, npos, 2, [(f.shape[2], f.shape[3]) for f in feats], 5, 0b00011)
+        xl = [model._run_tower(model.loc_head, f, sup, l) for l, f in enumerate(feats)]
+        xc = [model._run_tower(model.cls_head, f, sup, l) for l, f in enumerate(feats)]
+        out = rh.final_convs(model.loc_head[-1], model.cls_head[-1], xl, xc, support=sup, assignment=token)
+        crit.assign(y, 2)                                                     # a newer assignment replaces the one these rows were computed for
+        with pytest.raises(_lib.OdplError, match="one RetinaNetLoss.assign call only"):
+            crit(out, y)
+    finally:
+        sc.min_pixels = old
+
+
+def test_eval_and_no_grad_steps_stay_dense():
+    model = _model(3, 128)
+    g = torch.Generator().manual_seed(13)
+    x = torch.rand(2, 3, 128, 128, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    y = _targets(g, 2, 2, 3).to(DEV)
+    assert model._loss_driven_mask(x, y, model.fpn(x)) == 0                    # 128^2: every level is below sparseconv.min_pixels
+    with torch.no_grad():
+        d = model.forward_and_loss(x, y)
+    assert math.isfinite(float(d["loss"]))
+    model.eval()
+    out = model(x)
+    assert out[0].shape == (2, model.iou_boxes.shape[0] if model.iou_boxes.shape[0] != 0 else 0, 4) or out[0].shape[0] == 2

@@ -33,6 +33,9 @@ def main():
     ap.add_argument("--no-hosted-heads", action="store_true", help="A/B: the final head convolutions as plain nn.Conv2d modules + cat (round 2)")
     ap.add_argument("--dense-head-backward", action="store_true",
                     help="A/B: hosted final convolutions, but the criterion hands autograd the dense d loss/d preds (aten convolution_backward)")
+    ap.add_argument("--dense-forward", action="store_true",
+                    help="A/B: training_step = forward + criterion on all 200 700 anchors (round 3 before the loss-driven step); default: the "
+                         "assignment runs first and the heads are evaluated on the pixels RetinaNetLoss reads (model/RetinaNet.py:forward_and_loss)")
     ap.add_argument("--dense-tower-backward", action="store_true", help="A/B: the head towers' 3x3 convolutions keep MIOpen's backward on every level")
     a = ap.parse_args()
     from objectdetectionpl_amd.LightningFunc.utils import sparseconv
@@ -40,6 +43,7 @@ def main():
     from objectdetectionpl_amd.LightningFunc.utils import retinahead
     retinahead.enabled = not a.no_hosted_heads
     RetinaNetLoss.fuse_head_backward = not a.dense_head_backward
+    RetinaNet.loss_driven_step = not a.dense_forward
     dev = torch.device("cuda:0")
     torch.backends.cudnn.benchmark = bool(a.miopen_find)
     torch.manual_seed(0)
@@ -54,18 +58,18 @@ def main():
     y = torch.cat([torch.arange(a.batch).repeat_interleave(8).float()[:, None], torch.randint(0, 80, (n, 1), generator=g).float(),
                    torch.rand(n, 2, generator=g) * 0.6 + 0.2, wh], 1).to(dev)
 
+    model.iou_boxes, model.criterion = anchors, crit      # the 1333 x 800 table and its criterion (the ctor builds img_size^2 ones)
+
     def step():
         opt.zero_grad(set_to_none=True)
-        model.iou_boxes = anchors                         # forward only needs the table to exist on the device
-        out = model(x)
-        d = crit(out, y)
+        d = model.training_step((x, y), 0)                # step.py:14-25
         d["loss"].backward()
         opt.step()
-        return d, out
+        return d
 
     t0 = time.perf_counter()
     for i in range(a.warmup):
-        d, out = step()
+        d = step()
         torch.cuda.synchronize()
         print(f"[{time.perf_counter() - t0:6.1f}s] warmup {i + 1}/{a.warmup}", file=sys.stderr, flush=True)
     PROF = ("retina_assign", "retina_main")
@@ -73,7 +77,7 @@ def main():
         _lib.profile_enable(k, True)
     t1 = time.perf_counter()
     for _ in range(a.steps):
-        d, out = step()
+        d = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t1) / a.steps
     kern = {}
@@ -82,12 +86,13 @@ def main():
         ms = _lib.profile_collect(k)[0]
         if ms:
             kern[k + "_us"] = round(1e3 * sum(ms) / len(ms), 2)
-    assert out[0].shape[1] == anchors.shape[0] == 200700 or (a.height, a.width) != (800, 1333)
+    assert anchors.shape[0] == 200700 or (a.height, a.width) != (800, 1333)
     print(json.dumps({"workload": f"RetinaNet-R50-FPN {a.height}x{a.width} bs={a.batch} training step, fp32, C=80, {anchors.shape[0]} anchors",
                       "img_per_s": round(a.batch / dt, 2), "ms_per_step": round(dt * 1e3, 2), "loss": round(float(d["loss"].detach()), 4),
                       "num_pos": int(crit.last_counts[0]), "miopen_find": bool(a.miopen_find),
                       "hosted_heads": not a.no_hosted_heads, "structured_head_backward": not (a.no_hosted_heads or a.dense_head_backward),
-                      "sparse_tower_backward": not a.dense_tower_backward, **kern}))
+                      "sparse_tower_backward": not a.dense_tower_backward,
+                      "loss_driven_forward": not (a.dense_forward or a.no_hosted_heads or a.dense_head_backward or a.dense_tower_backward), **kern}))
 
 
 if __name__ == "__main__":
