@@ -54,8 +54,10 @@ def _scalars(self):
 def training_step(self, batch, batch_idx):
     """step.py:14-25."""
     x, y = batch
-    fl = getattr(self, "forward_and_loss", None)       # a model may fold `criterion(forward(x), y)` into one call (model/RetinaNet.py)
-    result_dict = fl(x, y) if fl is not None else self.criterion(self.forward(x), y)
+    fl = getattr(self, "forward_and_loss", None)       # a model may fold `criterion(forward(x), y)` into one call (model/RetinaNet.py);
+    result_dict = fl(x, y) if fl is not None else None  # None = it declined before running anything
+    if result_dict is None:
+        result_dict = self.criterion(self.forward(x), y)
     step = getattr(self, "global_step", batch_idx)
     for key, val in result_dict.items():
         _scalars(self).add("Loss/%s" % ("total" if key == "loss" else key), "Train", val, step)

@@ -187,37 +187,54 @@ class RetinaNet(_Base):
 
     loss_driven_step = True        # class switch (tools/bench_retina_step.py --dense-forward): False = training_step is forward + criterion
 
-    def _loss_driven_mask(self, x, y, feats):
-        """Levels of the heads a training step may evaluate on the criterion's pixels only (0 = take the dense route): the criterion
-        is the fused RetinaNetLoss over THIS input's anchor table, fp32 outside autocast, both heads hostable with 4 units each."""
+    def loss_driven_mask(self, x, y):
+        """Levels of the heads a training step may evaluate on the criterion's pixels only; 0 = forward + criterion.  Decided from
+        shapes alone, before anything runs: training mode with gradients on, fp32 outside autocast, the criterion is exactly the fused
+        RetinaNetLoss over THIS input's anchor table, both heads hostable with four units; a level qualifies from
+        `sparseconv.min_pixels` pixels on."""
         from ..LightningFunc.losses_dense import RetinaNetLoss
         crit = self.criterion
-        if not (self.loss_driven_step and self.training and torch.is_grad_enabled() and x.is_cuda and _rh.enabled and _sc.enabled
-                and type(crit) is RetinaNetLoss and crit.fuse_head_backward and self.num_anchors == 9 and torch.is_tensor(y) and y.is_cuda
-                and feats[0].dtype == torch.float32 and not torch.is_autocast_enabled()
+        if not (self.loss_driven_step and self.training and torch.is_grad_enabled() and torch.is_tensor(x) and x.is_cuda and x.dim() == 4
+                and x.dtype == torch.float32 and not torch.is_autocast_enabled() and torch.is_tensor(y) and y.is_cuda
+                and _rh.enabled and _sc.enabled and type(crit) is RetinaNetLoss and crit.fuse_head_backward
+                and self.num_anchors == 9 and crit.num_classes == self.num_classes and len(self.loc_head) == 9 and len(self.cls_head) == 9
                 and _rh.is_hostable(self.loc_head[-1]) and _rh.is_hostable(self.cls_head[-1])
-                and len(self.loc_head) == 9 and len(self.cls_head) == 9 and crit.num_classes == self.num_classes):
+                and self.loc_head[0].weight.dtype == torch.float32):
             return 0
-        if 9 * sum(f.shape[2] * f.shape[3] for f in feats) != len(crit.iou_boxes) or any(f.shape[1] % 32 or f.shape[1] > 448 for f in feats):
+        shapes = self._level_shapes(x)
+        if 9 * sum(h * w for h, w in shapes) != len(crit.iou_boxes):
             return 0
         mask = 0
-        for l, f in enumerate(feats):
-            if _sc._applicable(f, self.loc_head[0]) and _sc._applicable(f, self.cls_head[0]):
+        for l, (h, w) in enumerate(shapes):
+            if x.shape[0] * h * w >= _sc.min_pixels and h > 1 and w > 1:
                 mask |= 1 << l
         return mask
 
+    @staticmethod
+    def _level_shapes(x):
+        """P3 .. P7 of an [B, 3, H, W] input: every stride-2 stage of the FPN (7x7 s2 p3, 3x3 pool s2 p1, 3x3 s2 p1) halves rounding up"""
+        H, W = x.shape[2], x.shape[3]
+        return [(-(-H // 2 ** (3 + l)), -(-W // 2 ** (3 + l))) for l in range(5)]
+
     def forward_and_loss(self, x, y):
-        """`criterion(forward(x), y)` (step.py:17-18) for a training step.  RetinaNetLoss reads the positive anchor rows of the
-        predictions and nothing else (losses.py:336-339, 458-461), and which rows those are depends on anchors and boxes only: the
-        assignment runs first and the heads are evaluated where the loss will look (csrc/odpl_sparsefwd.hip) -- same loss, same
-        gradients, the predictions of the other rows are never formed.  Anything else about the step falls back to forward + criterion."""
-        if x.is_cuda and (self.iou_boxes is None or self.iou_boxes.device != x.device):
-            self._build_anchors(x.device)
-        feats = self.fpn(x) if x.is_cuda else None
-        mask = self._loss_driven_mask(x, y, feats) if feats is not None else 0
+        """`criterion(forward(x), y)` (step.py:17-18) for a training step, or None when the step has to be forward + criterion
+        (`loss_driven_mask`; nothing has run then).  RetinaNetLoss reads the positive anchor rows of the predictions and nothing else
+        (losses.py:336-339, 458-461), and which rows those are depends on anchors and boxes only: the assignment runs first and the
+        heads are evaluated where the loss will look (csrc/odpl_sparsefwd.hip) -- same loss, same gradients, the predictions of the
+        other rows are never formed."""
+        mask = self.loss_driven_mask(x, y)
         if not mask:
-            return self.criterion(self._heads(x, feats) if feats is not None else self.forward(x), y)
+            return None
+        if self.iou_boxes is None or self.iou_boxes.device != x.device:
+            self._build_anchors(x.device)
+        feats = self.fpn(x)
         crit = self.criterion
+        ok = [(f.shape[2], f.shape[3]) for f in feats] == self._level_shapes(x) and feats[0].dtype == torch.float32
+        for l, f in enumerate(feats):
+            if (mask >> l) & 1 and not (_sc._applicable(f, self.loc_head[0]) and _sc._applicable(f, self.cls_head[0])):
+                ok = False
+        if not ok:                                   # (an FPN that does not produce what the shapes promised: dense heads on what it did)
+            return crit(self._heads(x, feats), y)
         pos, npos, token = crit.assign(y, x.shape[0])
         n_units = (len(self.loc_head) - 1) // 2
         sup = _rh.PixelSupport(pos, npos, x.shape[0], [(f.shape[2], f.shape[3]) for f in feats], n_units + 1, mask)

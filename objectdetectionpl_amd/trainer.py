@@ -46,6 +46,23 @@ class _ForwardVia:
 
     __call__ = forward
 
+    @property
+    def forward_and_loss(self):
+        """A model's folded `criterion(forward(x), y)` (model/RetinaNet.py) under data parallelism: `DataParallelHost` only needs its
+        buffer broadcast before the module runs (gradients are averaged by parameter hooks); torch's DDP must see `forward` itself,
+        so the fold is not offered there and `step.training_step` takes forward + criterion through the wrapper."""
+        fl = getattr(self._m, "forward_and_loss", None)
+        if fl is None or not isinstance(self._n, parallel.DataParallelHost):
+            return None
+
+        def run(x, y):
+            taken = getattr(self._m, "loss_driven_mask", None)
+            if taken is not None and not taken(x, y):
+                return None                              # declined: training_step goes through self.forward (which syncs the buffers)
+            self._n.sync_buffers()
+            return fl(x, y)
+        return run
+
     def __getattr__(self, k):
         return getattr(self._m, k)
 

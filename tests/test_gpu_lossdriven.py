@@ -288,15 +288,30 @@ def test_predictions_of_a_loss_driven_step_serve_that_assignment_only():
         sc.min_pixels = old
 
 
-def test_eval_and_no_grad_steps_stay_dense():
+def test_eval_no_grad_and_small_inputs_decline_before_running_anything():
     model = _model(3, 128)
     g = torch.Generator().manual_seed(13)
     x = torch.rand(2, 3, 128, 128, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
     y = _targets(g, 2, 2, 3).to(DEV)
-    assert model._loss_driven_mask(x, y, model.fpn(x)) == 0                    # 128^2: every level is below sparseconv.min_pixels
+    assert model.loss_driven_mask(x, y) == 0 and model.forward_and_loss(x, y) is None       # 128^2: every level is below sparseconv.min_pixels
+    d = model.training_step((x, y), 0)                                                     # ... and the step is forward + criterion
+    assert math.isfinite(float(d["loss"].detach()))
+    big = torch.rand(2, 3, 512, 512, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    assert model.loss_driven_mask(big, y) == 0                                             # the criterion's anchor table is for 128^2
+    model2 = _model(3, 512)
+    assert model2.loss_driven_mask(big, y) == 0b00001
     with torch.no_grad():
-        d = model.forward_and_loss(x, y)
-    assert math.isfinite(float(d["loss"]))
-    model.eval()
-    out = model(x)
-    assert out[0].shape == (2, model.iou_boxes.shape[0] if model.iou_boxes.shape[0] != 0 else 0, 4) or out[0].shape[0] == 2
+        assert model2.loss_driven_mask(big, y) == 0
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert model2.loss_driven_mask(big, y) == 0
+    model2.eval()
+    assert model2.loss_driven_mask(big, y) == 0
+
+
+@pytest.mark.parametrize("hw", [(800, 1333), (257, 300), (64, 96), (130, 129)])
+def test_level_shapes_are_what_the_fpn_produces(hw):
+    model = _model(3, 128)
+    x = torch.rand(1, 3, *hw).to(DEV).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        feats = model.fpn(x)
+    assert [(f.shape[2], f.shape[3]) for f in feats] == model._level_shapes(x)

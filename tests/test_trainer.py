@@ -195,3 +195,35 @@ print(d.n, d.has_setup_fit, m.global_step, m.current_epoch, m.logger, m2.l.in_fe
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr[-2000:]
     assert r.stdout.split() == ["2", "True", "3", "0", "None", "2", "True", "True"]
+
+
+def test_forward_via_offers_a_folded_step_to_the_bucketed_wrapper_only():
+    """`_ForwardVia.forward_and_loss`: the model's fold runs behind `DataParallelHost.sync_buffers()`; torch's DDP (which must see
+    `forward`) and a model that declines get None, i.e. `training_step` goes forward + criterion through the wrapper."""
+    from objectdetectionpl_amd import parallel
+    from objectdetectionpl_amd.trainer import _ForwardVia
+    calls = []
+
+    class M:
+        take = True
+
+        def loss_driven_mask(self, x, y):
+            return 1 if self.take else 0
+
+        def forward_and_loss(self, x, y):
+            calls.append("fold")
+            return {"loss": x + y}
+
+    host = object.__new__(parallel.DataParallelHost)
+    host.sync_buffers = lambda: calls.append("sync")
+    m = M()
+    via = _ForwardVia(m, host)
+    assert via.forward_and_loss(1, 2) == {"loss": 3} and calls == ["sync", "fold"]
+    m.take = False
+    del calls[:]
+    assert via.forward_and_loss(1, 2) is None and calls == []
+    assert _ForwardVia(m, object()).forward_and_loss is None                 # any other wrapper (torch DDP)
+
+    class Plain:
+        pass
+    assert _ForwardVia(Plain(), host).forward_and_loss is None

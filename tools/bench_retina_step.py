@@ -37,9 +37,12 @@ def main():
                     help="A/B: training_step = forward + criterion on all 200 700 anchors (round 3 before the loss-driven step); default: the "
                          "assignment runs first and the heads are evaluated on the pixels RetinaNetLoss reads (model/RetinaNet.py:forward_and_loss)")
     ap.add_argument("--dense-tower-backward", action="store_true", help="A/B: the head towers' 3x3 convolutions keep MIOpen's backward on every level")
+    ap.add_argument("--min-pixels", type=int, default=None, help="sparseconv.min_pixels: levels with fewer B*H*W pixels keep the library route")
     a = ap.parse_args()
     from objectdetectionpl_amd.LightningFunc.utils import sparseconv
     sparseconv.enabled = not a.dense_tower_backward
+    if a.min_pixels is not None:
+        sparseconv.min_pixels = a.min_pixels
     from objectdetectionpl_amd.LightningFunc.utils import retinahead
     retinahead.enabled = not a.no_hosted_heads
     RetinaNetLoss.fuse_head_backward = not a.dense_head_backward
