@@ -141,7 +141,7 @@ class RetinaNetLoss(nn.Module):
         tgt = target.float().contiguous()
         self._launch(None, None, None, None, tgt, rows_only=(pos, npos), mode="assign", B=B)
         token = object()
-        self._assignment = (token, tgt, pos, npos)
+        self._assignment = (token, tgt, pos, npos, target)
         return pos, npos, token
 
     def _launch(self, loc, cls, g_loc, g_cls, target, rows_only=None, mode=None, B=None):
@@ -216,8 +216,8 @@ class RetinaNetLoss(nn.Module):
             # predictions of a loss-driven step: they exist on this assignment's positive rows only -- no other consumer is valid
             held = getattr(self, "_assignment", None)
             self._assignment = None
-            if src is None or held is None or held[0] is not promised["assignment"]:
-                raise OdplError("these predictions were computed for one RetinaNetLoss.assign call only (its positive rows); "
+            if src is None or held is None or held[0] is not promised["assignment"] or held[4] is not targets:
+                raise OdplError("these predictions were computed for one RetinaNetLoss.assign call only (its positive rows, its targets); "
                                 "run the dense forward for any other consumer")
             loss, metrics, _ = _RetinaLossHeadFn.apply(self, held[1], loc_preds.detach(), cls_preds.detach(), src, held, *src["w"], *src["xs"])
             return {"loss": loss, "Localization": metrics[0], "Classification": metrics[1]}

@@ -12,6 +12,7 @@ import ctypes
 
 import torch
 import torch.nn.functional as F
+from torch.utils.weak import WeakIdKeyDictionary
 
 from ... import _lib
 from .bnact import ACT, _ones_zeros, _workspace
@@ -21,12 +22,12 @@ min_pixels = 8192         # levels with fewer B*H*W pixels keep the library back
 max_density = 0.5         # above this share of pixels within reach of a gradient the library's dense backward is the faster one
 reprobe_every = 200       # a layer sent to the dense route tries the sparse one again after this many calls
 _ws2 = {}
-_density = {}             # (weight id, H, W) -> {"d": last observed share, "pending": (pinned tensor, event, pixels), "dense_calls": n}
+_density = WeakIdKeyDictionary()    # weight -> {(H, W): {"d": last observed share, "pending": (pinned, event, pixels), "dense_calls": n}}
 
 
 def _observe(key):
     """fold a finished asynchronous read-back of the pixel counts into the layer's record (never waits)"""
-    rec = _density.get(key)
+    rec = _density.get(key[0], {}).get(key[1:])
     if rec and rec.get("pending") is not None:
         pinned, ev, pixels = rec["pending"]
         if ev.query():
@@ -51,7 +52,7 @@ def _route_sparse(key):
 def applicable(x, conv):
     if not _applicable(x, conv):
         return False
-    return _route_sparse((id(conv.weight), x.shape[2], x.shape[3]))
+    return _route_sparse((conv.weight, x.shape[2], x.shape[3]))
 
 
 def _applicable(x, conv):
@@ -118,7 +119,7 @@ class _ConvBiasActSparse(torch.autograd.Function):
             ws2 = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=dev)
             _ws2[key] = ws2
         _lib.check(L.odpl_sparse_conv3x3_backward(ctypes.byref(d), _lib.ptr(ws2), ws2.numel(), st), "odpl_sparse_conv3x3_backward")
-        rec = _density.setdefault(ctx.key, {"d": None, "pending": None, "dense_calls": 0})
+        rec = _density.setdefault(ctx.key[0], {}).setdefault(ctx.key[1:], {"d": None, "pending": None, "dense_calls": 0})
         if rec["pending"] is None and not torch.cuda.is_current_stream_capturing():       # one read-back in flight per layer, never waited for
             pinned = torch.empty(2, dtype=torch.int32, pin_memory=True)
             pinned.copy_(stats, non_blocking=True)
@@ -133,6 +134,12 @@ def forward_on_pixels(x, w, b, act, support, out=None, out_strides=None):
     `out` (default: a zeroed channels-last map) with element strides out_strides = (batch, pixel)."""
     N, Cin, H, W = x.shape
     C = w.shape[0]
+    lst, cnt = support
+    if not (lst.is_cuda and cnt.is_cuda and lst.dtype == torch.int32 and cnt.dtype == torch.int32 and lst.is_contiguous()
+            and lst.numel() >= N * H * W and cnt.numel() >= 1):
+        raise ValueError("support = (int32 device list with room for every pixel of the map, int32 device count)")
+    if not (x.is_contiguous(memory_format=torch.channels_last) and x.dtype == torch.float32 and w.dtype == torch.float32 and w.shape[1] == Cin):
+        raise ValueError("forward_on_pixels needs a dense channels-last fp32 input and fp32 weights [Cout, Cin, 3, 3]")
     if out is None:
         out = torch.zeros((N, H, W, C), dtype=torch.float32, device=x.device).permute(0, 3, 1, 2)        # channels-last [N, C, H, W]
         out_strides = (H * W * C, C)
@@ -150,4 +157,4 @@ def forward_on_pixels(x, w, b, act, support, out=None, out_strides=None):
 def conv_bias_act(x, conv, act="relu", support=None):
     """`act(conv(x))` with the sparse backward; callers check `applicable(x, conv)` first.  support = (pixel list, count): evaluate
     the forward on those pixels only (a loss-driven training step)."""
-    return _ConvBiasActSparse.apply(x, conv.weight, conv.bias, ACT[act], (id(conv.weight), x.shape[2], x.shape[3]), support)
+    return _ConvBiasActSparse.apply(x, conv.weight, conv.bias, ACT[act], (conv.weight, x.shape[2], x.shape[3]), support)
