@@ -37,6 +37,10 @@ def main():
                     help="A/B: training_step = forward + criterion on all 200 700 anchors (round 3 before the loss-driven step); default: the "
                          "assignment runs first and the heads are evaluated on the pixels RetinaNetLoss reads (model/RetinaNet.py:forward_and_loss)")
     ap.add_argument("--dense-tower-backward", action="store_true", help="A/B: the head towers' 3x3 convolutions keep MIOpen's backward on every level")
+    ap.add_argument("--gt-per-image", type=int, default=8)
+    ap.add_argument("--wh-range", type=float, nargs=2, default=(0.05, 0.5), metavar=("LO", "HI"),
+                    help="box width / height as a share of the image, uniform in [LO, HI] (SURVEY config 4: 0.05 0.5; smaller boxes put "
+                         "positives on the large FPN levels, where the loss-driven step has more pixels to evaluate)")
     ap.add_argument("--min-pixels", type=int, default=None, help="sparseconv.min_pixels: levels with fewer B*H*W pixels keep the library route")
     a = ap.parse_args()
     from objectdetectionpl_amd.LightningFunc.utils import sparseconv
@@ -56,9 +60,9 @@ def main():
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5, fused=True)
     g = torch.Generator().manual_seed(1)
     x = torch.rand(a.batch, 3, a.height, a.width, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
-    n = a.batch * 8
-    wh = torch.rand(n, 2, generator=g) * 0.45 + 0.05
-    y = torch.cat([torch.arange(a.batch).repeat_interleave(8).float()[:, None], torch.randint(0, 80, (n, 1), generator=g).float(),
+    n = a.batch * a.gt_per_image
+    wh = torch.rand(n, 2, generator=g) * (a.wh_range[1] - a.wh_range[0]) + a.wh_range[0]
+    y = torch.cat([torch.arange(a.batch).repeat_interleave(a.gt_per_image).float()[:, None], torch.randint(0, 80, (n, 1), generator=g).float(),
                    torch.rand(n, 2, generator=g) * 0.6 + 0.2, wh], 1).to(dev)
 
     model.iou_boxes, model.criterion = anchors, crit      # the 1333 x 800 table and its criterion (the ctor builds img_size^2 ones)
@@ -92,7 +96,7 @@ def main():
     assert anchors.shape[0] == 200700 or (a.height, a.width) != (800, 1333)
     print(json.dumps({"workload": f"RetinaNet-R50-FPN {a.height}x{a.width} bs={a.batch} training step, fp32, C=80, {anchors.shape[0]} anchors",
                       "img_per_s": round(a.batch / dt, 2), "ms_per_step": round(dt * 1e3, 2), "loss": round(float(d["loss"].detach()), 4),
-                      "num_pos": int(crit.last_counts[0]), "miopen_find": bool(a.miopen_find),
+                      "num_pos": int(crit.last_counts[0]), "gt_per_image": a.gt_per_image, "wh_range": list(a.wh_range), "miopen_find": bool(a.miopen_find),
                       "hosted_heads": not a.no_hosted_heads, "structured_head_backward": not (a.no_hosted_heads or a.dense_head_backward),
                       "sparse_tower_backward": not a.dense_tower_backward,
                       "loss_driven_forward": not (a.dense_forward or a.no_hosted_heads or a.dense_head_backward or a.dense_tower_backward), **kern}))
