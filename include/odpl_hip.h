@@ -29,7 +29,8 @@ extern "C" {
 
 #define ODPL_ABI_VERSION 5   /* 3: memory-format strides + compact (structured) gradients on the YOLO losses, head-conv backward from them;
                               * 4: odpl_retina_loss_desc_t grew pos_anchor / num_pos (ODPL_RETINA_ROWS_ONLY), odpl_retina_heads_backward
-                              * 5: odpl_sparse_conv3x3_t grew stats; ODPL_RETINA_ASSIGN_ONLY / _ASSIGNED, odpl_pixel_support, odpl_sparse_conv3x3_forward */
+                              * 5: odpl_sparse_conv3x3_t grew stats; ODPL_RETINA_ASSIGN_ONLY / _ASSIGNED, odpl_pixel_support, odpl_sparse_conv3x3_forward,
+                              *    ksize on both sparse-convolution descriptors, odpl_pixel_union_lists, odpl_sparse_upsample_add */
 #define ODPL_EINVAL (-1)
 #define ODPL_MAX_SCALES 4
 #define ODPL_MAX_ANCHORS 8
@@ -357,6 +358,7 @@ typedef struct {
     float* grad_x; float* grad_w;
     int64_t w_stride[4];                     /* element strides of w / grad_w along (o, i, ky, kx) */
     int32_t B, H, W, Cin, Cout;
+    int32_t ksize;                           /* 0 or 3: 3 x 3, pad 1 (the tower units, the FPN smoothing convolutions); 1: 1 x 1, pad 0 (the FPN laterals) */
     int32_t* stats;                          /* optional device int32 [2]: active pixels, pixels within one pixel of an active one -- what the host
                                               * reads LATER (asynchronously) to decide whether this route still pays; NULL = not wanted */
 } odpl_sparse_conv3x3_t;
@@ -396,8 +398,24 @@ typedef struct {
     const int32_t* count;                    /* device int32 [1]: how many */
     int32_t B, H, W, Cin, Cout;
     int32_t act;                             /* ODPL_ACT_LINEAR / _RELU / _LEAKY on conv + bias */
+    int32_t ksize;                           /* 0 or 3: 3 x 3, pad 1; 1: 1 x 1, pad 0 */
 } odpl_sparse_conv3x3_fwd_t;
 int odpl_sparse_conv3x3_forward(const odpl_sparse_conv3x3_fwd_t* desc, void* stream);
+
+/* The FPN's top-down path under the same restriction (model/backbone/RetinaNetbone.py:55-75: p4 = toplayer1(up(p5) + latlayer2(c4)),
+ * p3 = toplayer2(up(p4) + latlayer3(c3)); `F.upsample(..., mode='bilinear')`, align_corners = False).
+ * odpl_pixel_union_lists: the pixels of an H x W map that are in list_a (may be NULL) or are a bilinear source of a pixel in list_b
+ * (pixels of a finer Hf x Wf map; may be NULL) -> list_marked (ascending), list_near = those within one pixel of a marked one
+ * (ascending; what a 3 x 3 convolution evaluated on list_marked reads), counts2 = their sizes.  Lists: device int32 [B*H*W].
+ * odpl_sparse_upsample_add: out[q,:] = lateral[q,:] + bilinear(coarse)[q,:] on the listed pixels q of the fine map (channels-last fp32,
+ * C % 4 == 0; ATen's source-index arithmetic and operation order); nothing is written elsewhere. */
+size_t odpl_pixel_union_lists_workspace_bytes(int32_t B, int32_t H, int32_t W);
+int odpl_pixel_union_lists(const int32_t* list_a, const int32_t* count_a, const int32_t* list_b, const int32_t* count_b,
+                           int32_t B, int32_t H, int32_t W, int32_t Hf, int32_t Wf,
+                           int32_t* list_marked, int32_t* list_near, int32_t* counts2,
+                           void* workspace, size_t workspace_bytes, void* stream);
+int odpl_sparse_upsample_add(const float* coarse, const float* lateral, float* out, const int32_t* list, const int32_t* count,
+                             int32_t B, int32_t C, int32_t h, int32_t w, int32_t H, int32_t W, void* stream);
 
 /* ---- SSD loss: losses.py:159-315 ---------------------------------------------------------------- */
 

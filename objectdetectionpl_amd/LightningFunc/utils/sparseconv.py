@@ -55,10 +55,16 @@ def applicable(x, conv):
     return _route_sparse((conv.weight, x.shape[2], x.shape[3]))
 
 
+def conv_ok(conv):
+    """a convolution these kernels cover: 3 x 3 / pad 1 or 1 x 1 / pad 0, stride 1, biased, fp32, channel counts in whole 64s"""
+    return (conv.stride == (1, 1)
+            and ((conv.kernel_size == (3, 3) and conv.padding == (1, 1)) or (conv.kernel_size == (1, 1) and conv.padding == (0, 0)))
+            and conv.padding_mode == "zeros" and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is not None
+            and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0 and conv.weight.dtype == torch.float32)
+
+
 def _applicable(x, conv):
-    return (enabled and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
-            and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is not None
-            and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0 and conv.weight.dtype == torch.float32
+    return (enabled and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv_ok(conv) and x.shape[1] == conv.in_channels
             and x.shape[0] * x.shape[2] * x.shape[3] >= min_pixels and x.shape[2] > 1 and x.shape[3] > 1
             and x.is_contiguous(memory_format=torch.channels_last) and torch.is_grad_enabled())
 
@@ -72,7 +78,7 @@ class _ConvBiasActSparse(torch.autograd.Function):
             # backward below never reads a pixel off that list
             z = forward_on_pixels(x, w, b, act, support)
         else:
-            z = F.conv2d(x, w, None, 1, 1)
+            z = F.conv2d(x, w, None, 1, w.shape[2] // 2)
             N, C, H, W = z.shape
             ones, zeros = _ones_zeros(z.device, C)
             _lib.check(_lib.lib().odpl_bias_act_forward(_lib.ptr(z), N * H * W, C, _lib.ptr(b), _lib.ptr(ones), _lib.ptr(zeros), act, _lib.ptr(z),
@@ -107,7 +113,7 @@ class _ConvBiasActSparse(torch.autograd.Function):
         d.grad_w = gw.data_ptr() if gw is not None else None
         for k in range(4):
             d.w_stride[k] = w.stride(k)
-        d.B, d.H, d.W, d.Cin, d.Cout = N, H, W, x.shape[1], C
+        d.B, d.H, d.W, d.Cin, d.Cout, d.ksize = N, H, W, x.shape[1], C, w.shape[2]
         stats = torch.empty(2, dtype=torch.int32, device=dev)
         d.stats = stats.data_ptr()
         nbytes = L.odpl_sparse_conv3x3_backward_workspace_bytes(ctypes.byref(d))
@@ -138,8 +144,9 @@ def forward_on_pixels(x, w, b, act, support, out=None, out_strides=None):
     if not (lst.is_cuda and cnt.is_cuda and lst.dtype == torch.int32 and cnt.dtype == torch.int32 and lst.is_contiguous()
             and lst.numel() >= N * H * W and cnt.numel() >= 1):
         raise ValueError("support = (int32 device list with room for every pixel of the map, int32 device count)")
-    if not (x.is_contiguous(memory_format=torch.channels_last) and x.dtype == torch.float32 and w.dtype == torch.float32 and w.shape[1] == Cin):
-        raise ValueError("forward_on_pixels needs a dense channels-last fp32 input and fp32 weights [Cout, Cin, 3, 3]")
+    if not (x.is_contiguous(memory_format=torch.channels_last) and x.dtype == torch.float32 and w.dtype == torch.float32 and w.shape[1] == Cin
+            and w.shape[2] == w.shape[3] and w.shape[2] in (1, 3)):
+        raise ValueError("forward_on_pixels needs a dense channels-last fp32 input and fp32 weights [Cout, Cin, k, k], k = 3 (pad 1) or 1")
     if out is None:
         out = torch.zeros((N, H, W, C), dtype=torch.float32, device=x.device).permute(0, 3, 1, 2)        # channels-last [N, C, H, W]
         out_strides = (H * W * C, C)
@@ -149,7 +156,7 @@ def forward_on_pixels(x, w, b, act, support, out=None, out_strides=None):
         d.w_stride[k] = w.stride(k)
     d.y_batch_stride, d.y_pixel_stride = out_strides
     d.list, d.count = support[0].data_ptr(), support[1].data_ptr()
-    d.B, d.H, d.W, d.Cin, d.Cout, d.act = N, H, W, Cin, C, act
+    d.B, d.H, d.W, d.Cin, d.Cout, d.act, d.ksize = N, H, W, Cin, C, act, w.shape[2]
     _lib.check(_lib.lib().odpl_sparse_conv3x3_forward(ctypes.byref(d), _lib.current_stream(x.device)), "odpl_sparse_conv3x3_forward")
     return out
 
@@ -158,3 +165,60 @@ def conv_bias_act(x, conv, act="relu", support=None):
     """`act(conv(x))` with the sparse backward; callers check `applicable(x, conv)` first.  support = (pixel list, count): evaluate
     the forward on those pixels only (a loss-driven training step)."""
     return _ConvBiasActSparse.apply(x, conv.weight, conv.bias, ACT[act], (conv.weight, x.shape[2], x.shape[3]), support)
+
+
+class _UpAddOnPixels(torch.autograd.Function):
+    """`F.interpolate(coarse, size=lateral.shape[2:], mode="bilinear", align_corners=False) + lateral` on the listed pixels of the fine
+    map, zero elsewhere (the FPN's top-down merge in a loss-driven step).  backward: the gradient passes to `lateral` as it is and to
+    `coarse` through ATen's bilinear backward."""
+
+    @staticmethod
+    def forward(ctx, coarse, lateral, support):
+        N, C, H, W = lateral.shape
+        h, w = coarse.shape[2], coarse.shape[3]
+        lst, cnt = support
+        if not (coarse.is_contiguous(memory_format=torch.channels_last) and lateral.is_contiguous(memory_format=torch.channels_last)
+                and coarse.dtype == lateral.dtype == torch.float32 and coarse.shape[:2] == lateral.shape[:2] and C % 4 == 0
+                and lst.dtype == torch.int32 and lst.numel() >= N * H * W):
+            raise ValueError("up_add_on_pixels needs dense channels-last fp32 maps with equal batch and channels and an int32 pixel list")
+        out = torch.zeros((N, H, W, C), dtype=torch.float32, device=lateral.device).permute(0, 3, 1, 2)
+        _lib.check(_lib.lib().odpl_sparse_upsample_add(_lib.ptr(coarse), _lib.ptr(lateral), _lib.ptr(out), _lib.ptr(lst), _lib.ptr(cnt),
+                                                       N, C, h, w, H, W, _lib.current_stream(lateral.device)), "odpl_sparse_upsample_add")
+        ctx.sizes = ((H, W), tuple(coarse.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (H, W), cshape = ctx.sizes
+        gc = None
+        if ctx.needs_input_grad[0]:
+            gc = torch.ops.aten.upsample_bilinear2d_backward(g.contiguous(memory_format=torch.channels_last), [H, W], list(cshape), False, None, None)
+        return gc, (g if ctx.needs_input_grad[1] else None), None
+
+
+def up_add_on_pixels(coarse, lateral, support):
+    return _UpAddOnPixels.apply(coarse, lateral, support)
+
+
+def union_lists(B, H, W, own=None, finer=None, finer_hw=None):
+    """`odpl_pixel_union_lists`: (marked, near, counts) for an H x W map -- marked = pixels in `own` = (list, count) or bilinear sources
+    of the pixels in `finer` = (list, count) of a finer_hw map; near = within one pixel of a marked one.  -> ((marked, count),
+    (near, count)) as `forward_on_pixels` supports."""
+    L = _lib.lib()
+    if own is None and finer is None:
+        raise _lib.OdplError("union_lists needs a list of this map's pixels, of a finer map's pixels, or both")
+    dev = (own or finer)[0].device
+    P = B * H * W
+    marked = torch.empty(P, dtype=torch.int32, device=dev)
+    near = torch.empty(P, dtype=torch.int32, device=dev)
+    counts = torch.empty(2, dtype=torch.int32, device=dev)
+    n = L.odpl_pixel_union_lists_workspace_bytes(B, H, W)
+    if n == 0:
+        raise _lib.OdplError("odpl_pixel_union_lists_workspace_bytes rejected the map")
+    ws = torch.empty(n, dtype=torch.uint8, device=dev)
+    Hf, Wf = finer_hw if finer is not None else (H, W)
+    _lib.check(L.odpl_pixel_union_lists(own[0].data_ptr() if own else None, own[1].data_ptr() if own else None,
+                                        finer[0].data_ptr() if finer else None, finer[1].data_ptr() if finer else None,
+                                        B, H, W, Hf, Wf, _lib.ptr(marked), _lib.ptr(near), _lib.ptr(counts), _lib.ptr(ws), ws.numel(),
+                                        _lib.current_stream(dev)), "odpl_pixel_union_lists")
+    return (marked, counts[0:1]), (near, counts[1:2])

@@ -70,7 +70,7 @@ class SparseConv3x3(ctypes.Structure):
     """odpl_sparse_conv3x3_t"""
     _fields_ = [("x", c_void_p), ("gy", c_void_p), ("active", c_void_p), ("w", c_void_p), ("grad_x", c_void_p), ("grad_w", c_void_p),
                 ("w_stride", ctypes.c_int64 * 4), ("B", c_int32), ("H", c_int32), ("W", c_int32), ("Cin", c_int32), ("Cout", c_int32),
-                ("stats", c_void_p)]
+                ("ksize", c_int32), ("stats", c_void_p)]
 
 
 class PixelSupport(ctypes.Structure):
@@ -83,7 +83,7 @@ class SparseConv3x3Fwd(ctypes.Structure):
     """odpl_sparse_conv3x3_fwd_t"""
     _fields_ = [("x", c_void_p), ("w", c_void_p), ("bias", c_void_p), ("w_stride", ctypes.c_int64 * 4), ("y", c_void_p),
                 ("y_batch_stride", ctypes.c_int64), ("y_pixel_stride", ctypes.c_int64), ("list", c_void_p), ("count", c_void_p),
-                ("B", c_int32), ("H", c_int32), ("W", c_int32), ("Cin", c_int32), ("Cout", c_int32), ("act", c_int32)]
+                ("B", c_int32), ("H", c_int32), ("W", c_int32), ("Cin", c_int32), ("Cout", c_int32), ("act", c_int32), ("ksize", c_int32)]
 
 
 class YoloNmsDesc(ctypes.Structure):
@@ -197,6 +197,11 @@ SIGNATURES = {
     "odpl_pixel_support_workspace_bytes": (c_size_t, [c_void_p]),
     "odpl_pixel_support": (c_int32, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "odpl_sparse_conv3x3_forward": (c_int32, [c_void_p, c_void_p]),
+    "odpl_pixel_union_lists_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "odpl_pixel_union_lists": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "odpl_sparse_upsample_add": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                           c_void_p]),
     "odpl_upsample2x_nearest": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, ctypes.c_int64, ctypes.c_int64, c_int32, c_void_p]),
     "odpl_spp_forward": (c_int32, [c_void_p, POINTER(ctypes.c_int64), c_int32, c_int32, c_int32, c_int32, c_void_p, POINTER(ctypes.c_int64), c_void_p]),
     "odpl_spp_backward": (c_int32, [c_void_p, POINTER(ctypes.c_int64), c_int32, c_int32, c_int32, c_int32, c_void_p, POINTER(ctypes.c_int64), c_void_p, c_void_p]),

@@ -26,6 +26,7 @@ struct SP {
     const float* x; const float* gy; const unsigned char* act; const float* w; float* gx; float* gw;
     long long ws_o, ws_i, ws_ky, ws_kx;
     int B, H, W, Cin, Cout, P, ntile;    // P = B*H*W pixels; ntile = ceil(P / 256)
+    int ks, pad, taps;                   // 3 x 3 (pad 1) or 1 x 1 (pad 0): taps = ks * ks
     int* cnt_out; int* cnt_in;           // [ntile] active pixels / pixels within one pixel of an active one, per 256-pixel tile
     int* off_out; int* off_in;           // [ntile + 1] exclusive scans; [ntile] = totals
     int* list_out; int* list_in;         // [P] ascending pixel ids
@@ -40,6 +41,7 @@ __device__ __forceinline__ bool near_active(const SP& P, int p) {
     for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
         for (int dx = -1; dx <= 1; ++dx) {
+            if ((dy != 0 || dx != 0) && P.pad == 0) continue;             // a 1 x 1 convolution reaches no neighbour
             const int yy = y + dy, xx = x + dx;
             if (yy >= 0 && yy < P.H && xx >= 0 && xx < P.W) any |= P.act[(size_t)b * hw + yy * P.W + xx] != 0;
         }
@@ -128,11 +130,11 @@ __global__ __launch_bounds__(kT) void sc_data_kernel(const SP P) {
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         float4 ra[2], rb[2];
         auto load_tiles = [&](int kt) {
-            const int t = kt / kpt, co0 = (kt - t * kpt) * BK, ky = t / 3, kx = t - 3 * ky;
+            const int t = kt / kpt, co0 = (kt - t * kpt) * BK, ky = t / P.ks, kx = t - P.ks * ky;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int f = tid + kT * i, row = f >> 3, kq = f & 7;
-                const int yy = s_y[row] - (ky - 1), xx = s_x[row] - (kx - 1);                // dX[q] takes gY[q - d(tap)]
+                const int yy = s_y[row] - (ky - P.pad), xx = s_x[row] - (kx - P.pad);        // dX[q] takes gY[q - d(tap)]
                 const bool in = yy >= 0 && yy < P.H && xx >= 0 && xx < P.W;
                 const size_t src = ((size_t)s_b[row] * hw + (in ? yy * P.W + xx : 0)) * P.Cout + co0 + 4 * kq;
                 const float4 v = *reinterpret_cast<const float4*>(P.gy + src);
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(kT) void sc_data_kernel(const SP P) {
                 *reinterpret_cast<float4*>(Bs + kr * LDB + 4 * nq) = rb[i];
             }
         };
-        const int nk = 9 * kpt;
+        const int nk = P.taps * kpt;
         load_tiles(0);
         store_tiles();
         __syncthreads();
@@ -192,8 +194,8 @@ __global__ __launch_bounds__(kT) void sc_weight_kernel(const SP P) {
     int bid = blockIdx.x;
     const int tn = bid % tiles_n; bid /= tiles_n;
     const int tm = bid % tiles_m; bid /= tiles_m;
-    const int t = bid % 9, s = bid / 9;
-    const int ky = t / 3, kx = t - 3 * ky, hw = P.H * P.W;
+    const int t = bid % P.taps, s = bid / P.taps;
+    const int ky = t / P.ks, kx = t - P.ks * ky, hw = P.H * P.W;
     const int n_out = P.off_out[P.ntile];
     const int chunk = ((n_out + kSplits - 1) / kSplits + BK - 1) / BK * BK;
     const int r0 = s * chunk, r1 = r0 + chunk < n_out ? r0 + chunk : n_out;
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(kT) void sc_weight_kernel(const SP P) {
             const int p = P.list_out[live ? r : r0 < n_out ? r0 : 0];
             const float4 g = *reinterpret_cast<const float4*>(P.gy + (size_t)p * P.Cout + tm * BM + 4 * cq);
             ra[i] = live ? g : make_float4(0.f, 0.f, 0.f, 0.f);
-            const int b = p / hw, rem = p - b * hw, y = rem / P.W, x = rem - y * P.W, yy = y + ky - 1, xx = x + kx - 1;
+            const int b = p / hw, rem = p - b * hw, y = rem / P.W, x = rem - y * P.W, yy = y + ky - P.pad, xx = x + kx - P.pad;
             const bool in = live && yy >= 0 && yy < P.H && xx >= 0 && xx < P.W;
             const float4 v = *reinterpret_cast<const float4*>(P.x + ((size_t)b * hw + (in ? yy * P.W + xx : rem)) * P.Cin + tn * BN + 4 * cq);
             rb[i] = in ? v : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -239,18 +241,47 @@ __global__ __launch_bounds__(kT) void sc_weight_kernel(const SP P) {
             if (k0 + BK < r1) { store_tiles(); __syncthreads(); }
         }
     }
-    float* o = P.part + ((size_t)(s * 9 + t) * P.Cout + tm * BM) * P.Cin + tn * BN;
+    float* o = P.part + ((size_t)(s * P.taps + t) * P.Cout + tm * BM) * P.Cin + tn * BN;
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[(size_t)(wm + (r & 3) + 8 * (r >> 2) + 4 * lk) * P.Cin + wn + lr] = acc[r];
 }
 
 __global__ __launch_bounds__(kT) void sc_reduce_kernel(const SP P) {
-    const long long n = 9LL * P.Cout * P.Cin;
+    const long long n = (long long)P.taps * P.Cout * P.Cin;
     for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < n; i += (long long)gridDim.x * kT) {
         float v = P.part[i];
         for (int s = 1; s < kSplits; ++s) v += P.part[(long long)s * n + i];
         const int ci = (int)(i % P.Cin); const long long r = i / P.Cin; const int co = (int)(r % P.Cout), t = (int)(r / P.Cout);
-        P.gw[(long long)co * P.ws_o + (long long)ci * P.ws_i + (t / 3) * P.ws_ky + (t % 3) * P.ws_kx] = v;
+        P.gw[(long long)co * P.ws_o + (long long)ci * P.ws_i + (t / P.ks) * P.ws_ky + (t % P.ks) * P.ws_kx] = v;
+    }
+}
+
+// ---- pixel sets of a coarser FPN level: what a finer level's top-down merge will read of it ---------------------------------
+struct UnP {
+    unsigned char* flags;
+    const int* list_a; const int* count_a;       // pixels of THIS map, taken as they are (may be null)
+    const int* list_b; const int* count_b;       // pixels of a FINER map (Hf x Wf): their bilinear source pixels in this map (may be null)
+    int B, H, W, Hf, Wf;
+    float sy, sx;
+};
+
+__global__ __launch_bounds__(kT) void un_mark_kernel(const UnP P) {
+    const int stride = gridDim.x * kT, t0 = blockIdx.x * kT + threadIdx.x;
+    if (P.list_a) {
+        const int n = min(P.count_a[0], P.B * P.H * P.W);
+        for (int r = t0; r < n; r += stride) P.flags[P.list_a[r]] = 1;
+    }
+    if (P.list_b) {
+        const int n = min(P.count_b[0], P.B * P.Hf * P.Wf), hwf = P.Hf * P.Wf;
+        for (int r = t0; r < n; r += stride) {
+            const int q = P.list_b[r], b = q / hwf, rem = q - b * hwf, y = rem / P.Wf, x = rem - y * P.Wf;
+            float fy = P.sy * ((float)y + 0.5f) - 0.5f; if (fy < 0.f) fy = 0.f;      // the source index arithmetic of sf_upadd_kernel / ATen
+            float fx = P.sx * ((float)x + 0.5f) - 0.5f; if (fx < 0.f) fx = 0.f;
+            const int y0 = (int)fy, x0 = (int)fx;
+            const int y1 = y0 + (y0 < P.H - 1 ? 1 : 0), x1 = x0 + (x0 < P.W - 1 ? 1 : 0);
+            unsigned char* f = P.flags + (size_t)b * P.H * P.W;
+            f[y0 * P.W + x0] = 1; f[y0 * P.W + x1] = 1; f[y1 * P.W + x0] = 1; f[y1 * P.W + x1] = 1;
+        }
     }
 }
 
@@ -262,6 +293,7 @@ bool make_plan(const odpl_sparse_conv3x3_t* d, Plan* p) {
     const long long P = (long long)d->B * d->H * d->W;
     if (P * d->Cin > 0x7fffffffLL * 4 || P * d->Cout > 0x7fffffffLL * 4 || P > 0x7fffffffLL - 256) return false;
     if (!d->x || !d->gy || !d->active || !d->w) return false;
+    if (d->ksize != 0 && d->ksize != 1 && d->ksize != 3) return false;
     p->P = (int)P; p->ntile = (int)((P + kT - 1) / kT);
     size_t off = 0;
     p->cnt_out = off; off += align_up((size_t)p->ntile * 4, 256);
@@ -270,7 +302,7 @@ bool make_plan(const odpl_sparse_conv3x3_t* d, Plan* p) {
     p->off_in = off; off += align_up(((size_t)p->ntile + 1) * 4, 256);
     p->list_out = off; off += align_up((size_t)P * 4, 256);
     p->list_in = off; off += align_up((size_t)P * 4, 256);
-    p->part = off; off += align_up((size_t)kSplits * 9 * d->Cout * d->Cin * 4, 256);
+    p->part = off; off += align_up((size_t)kSplits * (d->ksize == 1 ? 1 : 9) * d->Cout * d->Cin * 4, 256);
     p->total = off;
     return true;
 }
@@ -285,13 +317,15 @@ extern "C" int odpl_sparse_conv3x3_backward(const odpl_sparse_conv3x3_t* d, void
     Plan pl;
     if (!make_plan(d, &pl) || !workspace || workspace_bytes < pl.total) return ODPL_EINVAL;
     if ((((uintptr_t)workspace | (uintptr_t)d->x | (uintptr_t)d->gy | (uintptr_t)d->grad_x) & 15)) return ODPL_EINVAL;
-    if (d->w_stride[1] == 1 && ((((uintptr_t)d->w) & 15) || (d->w_stride[0] & 3) || (d->w_stride[2] & 3) || (d->w_stride[3] & 3))) return ODPL_EINVAL;
+    if (d->w_stride[1] == 1 && ((((uintptr_t)d->w) & 15) || (d->w_stride[0] & 3) ||
+                                (d->ksize != 1 && ((d->w_stride[2] & 3) || (d->w_stride[3] & 3))))) return ODPL_EINVAL;   // (a 1 x 1 kernel never steps along ky / kx)
     hipStream_t stream = (hipStream_t)stream_;
     char* ws = (char*)workspace;
     SP P;
     P.x = d->x; P.gy = d->gy; P.act = d->active; P.w = d->w; P.gx = d->grad_x; P.gw = d->grad_w;
     P.ws_o = d->w_stride[0]; P.ws_i = d->w_stride[1]; P.ws_ky = d->w_stride[2]; P.ws_kx = d->w_stride[3];
     P.B = d->B; P.H = d->H; P.W = d->W; P.Cin = d->Cin; P.Cout = d->Cout; P.P = pl.P; P.ntile = pl.ntile;
+    P.ks = d->ksize == 1 ? 1 : 3; P.pad = P.ks / 2; P.taps = P.ks * P.ks;
     P.cnt_out = (int*)(ws + pl.cnt_out); P.cnt_in = (int*)(ws + pl.cnt_in); P.off_out = (int*)(ws + pl.off_out); P.off_in = (int*)(ws + pl.off_in);
     P.list_out = (int*)(ws + pl.list_out); P.list_in = (int*)(ws + pl.list_in); P.part = (float*)(ws + pl.part);
     P.stats = d->stats;
@@ -308,10 +342,61 @@ extern "C" int odpl_sparse_conv3x3_backward(const odpl_sparse_conv3x3_t* d, void
         ODPL_HIP_TRY(hipGetLastError());
     }
     if (d->grad_w) {
-        hipLaunchKernelGGL(sc_weight_kernel, dim3(kSplits * 9 * (d->Cout / 64) * (d->Cin / 64)), dim3(kT), 0, stream, P);
+        hipLaunchKernelGGL(sc_weight_kernel, dim3(kSplits * P.taps * (d->Cout / 64) * (d->Cin / 64)), dim3(kT), 0, stream, P);
         ODPL_HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(sc_reduce_kernel, dim3(1024), dim3(kT), 0, stream, P);
         ODPL_HIP_TRY(hipGetLastError());
     }
+    return 0;
+}
+
+// flags | 4 x (ntile [+ 1]) ints of counts / offsets; the two lists are the caller's
+static size_t union_plan(long long P, size_t* cnt_out, size_t* cnt_in, size_t* off_out, size_t* off_in) {
+    const size_t ntile = (size_t)((P + kT - 1) / kT);
+    size_t off = align_up((size_t)P, 256);
+    *cnt_out = off; off += align_up(ntile * 4, 256);
+    *cnt_in = off; off += align_up(ntile * 4, 256);
+    *off_out = off; off += align_up((ntile + 1) * 4, 256);
+    *off_in = off; off += align_up((ntile + 1) * 4, 256);
+    return off;
+}
+
+extern "C" size_t odpl_pixel_union_lists_workspace_bytes(int32_t B, int32_t H, int32_t W) {
+    if (B < 1 || H < 1 || W < 1 || (long long)B * H * W > 0x7fffffffLL - 256) return 0;
+    size_t a, b, c, d;
+    return union_plan((long long)B * H * W, &a, &b, &c, &d);
+}
+
+extern "C" int odpl_pixel_union_lists(const int32_t* list_a, const int32_t* count_a, const int32_t* list_b, const int32_t* count_b,
+                                      int32_t B, int32_t H, int32_t W, int32_t Hf, int32_t Wf,
+                                      int32_t* list_marked, int32_t* list_near, int32_t* counts2,
+                                      void* workspace, size_t workspace_bytes, void* stream_) {
+    const size_t need = odpl_pixel_union_lists_workspace_bytes(B, H, W);
+    if (!need || !workspace || workspace_bytes < need || !list_marked || !list_near || !counts2) return ODPL_EINVAL;
+    if ((list_a == nullptr) != (count_a == nullptr) || (list_b == nullptr) != (count_b == nullptr) || (!list_a && !list_b)) return ODPL_EINVAL;
+    if (list_b && (Hf < H || Wf < W || (long long)B * Hf * Wf > 0x7fffffffLL)) return ODPL_EINVAL;
+    hipStream_t stream = (hipStream_t)stream_;
+    char* ws = (char*)workspace;
+    const long long Pn = (long long)B * H * W;
+    size_t o_cnt_out, o_cnt_in, o_off_out, o_off_in;
+    union_plan(Pn, &o_cnt_out, &o_cnt_in, &o_off_out, &o_off_in);
+    UnP U;
+    U.flags = (unsigned char*)ws; U.list_a = list_a; U.count_a = count_a; U.list_b = list_b; U.count_b = count_b;
+    U.B = B; U.H = H; U.W = W; U.Hf = list_b ? Hf : 1; U.Wf = list_b ? Wf : 1;
+    U.sy = list_b ? (float)H / (float)Hf : 1.f; U.sx = list_b ? (float)W / (float)Wf : 1.f;
+    ODPL_HIP_TRY(odpl::fill_bytes(U.flags, 0, (size_t)Pn, stream));
+    hipLaunchKernelGGL(un_mark_kernel, dim3(256), dim3(kT), 0, stream, U);
+    ODPL_HIP_TRY(hipGetLastError());
+    SP P = {};
+    P.act = U.flags; P.B = B; P.H = H; P.W = W; P.P = (int)Pn; P.ntile = (int)((Pn + kT - 1) / kT);
+    P.ks = 3; P.pad = 1; P.taps = 9;
+    P.cnt_out = (int*)(ws + o_cnt_out); P.cnt_in = (int*)(ws + o_cnt_in); P.off_out = (int*)(ws + o_off_out); P.off_in = (int*)(ws + o_off_in);
+    P.list_out = list_marked; P.list_in = list_near; P.stats = counts2;
+    hipLaunchKernelGGL(sc_count_kernel, dim3(P.ntile), dim3(kT), 0, stream, P);
+    ODPL_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(sc_scan_kernel, dim3(1), dim3(1024), 0, stream, P);
+    ODPL_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(sc_list_kernel, dim3(P.ntile), dim3(kT), 0, stream, P);
+    ODPL_HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -92,6 +92,7 @@ struct FwdP {
     long long ws_o, ws_i, ws_ky, ws_kx, ybs, yps;
     const int* list; const int* count;
     int B, H, W, Cin, Cout, act;
+    int ks, pad, taps;                   // 3 x 3 (pad 1) or 1 x 1 (pad 0)
 };
 
 // y rows of the listed pixels: [n, 9 * Cin] (rows of x gathered one tap at a time) x [9 * Cin, Cout]
@@ -121,11 +122,11 @@ __global__ __launch_bounds__(kT) void sf_conv_kernel(const FwdP P) {
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         float4 ra[2], rb[2];
         auto load_tiles = [&](int kt) {
-            const int t = kt / kpt, ci0 = (kt - t * kpt) * BK, ky = t / 3, kx = t - 3 * ky;
+            const int t = kt / kpt, ci0 = (kt - t * kpt) * BK, ky = t / P.ks, kx = t - P.ks * ky;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int f = tid + kT * i, row = f >> 3, kq = f & 7;
-                const int yy = s_y[row] + (ky - 1), xx = s_x[row] + (kx - 1);                // y[p] takes x[p + d(tap)]
+                const int yy = s_y[row] + (ky - P.pad), xx = s_x[row] + (kx - P.pad);        // y[p] takes x[p + d(tap)]
                 const bool in = yy >= 0 && yy < P.H && xx >= 0 && xx < P.W;
                 const size_t src = ((size_t)s_b[row] * hw + (in ? yy * P.W + xx : 0)) * P.Cin + ci0 + 4 * kq;
                 const float4 v = *reinterpret_cast<const float4*>(P.x + src);
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(kT) void sf_conv_kernel(const FwdP P) {
                 e[0] = rb[i].x; e[1] = rb[i].y; e[2] = rb[i].z; e[3] = rb[i].w;
             }
         };
-        const int nk = 9 * kpt;
+        const int nk = P.taps * kpt;
         load_tiles(0);
         store_tiles();
         __syncthreads();
@@ -175,6 +176,45 @@ __global__ __launch_bounds__(kT) void sf_conv_kernel(const FwdP P) {
                 else if (P.act == ODPL_ACT_LEAKY) v = v > 0.f ? v : 0.1f * v;
                 P.y[(long long)s_b[row] * P.ybs + (long long)(s_y[row] * P.W + s_x[row]) * P.yps + co] = v;
             }
+        }
+    }
+}
+
+// m[q, :] = lat[q, :] + bilinear(coarse)[q, :] for the listed pixels q of the fine map (FPN top-down merge, RetinaNetbone.py:57
+// `F.upsample(x, size, mode='bilinear') + y`, align_corners = False): one wave per pixel, lanes across channel quads
+struct UpP {
+    const float* coarse; const float* lat; float* out;
+    const int* list; const int* count;
+    int B, h, w, H, W, C;
+    float sy, sx;                        // h / H, w / W (ATen's area_pixel_compute_scale)
+};
+
+__global__ __launch_bounds__(kT) void sf_upadd_kernel(const UpP P) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c4n = P.C >> 2;
+    int n = P.count[0];
+    const int cap = P.B * P.H * P.W;
+    if (n > cap) n = cap;
+    for (int r = blockIdx.x * (kT / 64) + wv; r < n; r += gridDim.x * (kT / 64)) {
+        const int q = P.list[r], HW = P.H * P.W, b = q / HW, rem = q - b * HW, y = rem / P.W, x = rem - y * P.W;
+        float fy = P.sy * ((float)y + 0.5f) - 0.5f; if (fy < 0.f) fy = 0.f;          // ATen: area_pixel_compute_source_index, cubic = false
+        float fx = P.sx * ((float)x + 0.5f) - 0.5f; if (fx < 0.f) fx = 0.f;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < P.h - 1 ? 1 : 0), x1 = x0 + (x0 < P.w - 1 ? 1 : 0);
+        const float ly1 = fy - (float)y0, ly0 = 1.f - ly1, lx1 = fx - (float)x0, lx0 = 1.f - lx1;
+        const float4* c00 = reinterpret_cast<const float4*>(P.coarse + ((size_t)(b * P.h + y0) * P.w + x0) * P.C);
+        const float4* c01 = reinterpret_cast<const float4*>(P.coarse + ((size_t)(b * P.h + y0) * P.w + x1) * P.C);
+        const float4* c10 = reinterpret_cast<const float4*>(P.coarse + ((size_t)(b * P.h + y1) * P.w + x0) * P.C);
+        const float4* c11 = reinterpret_cast<const float4*>(P.coarse + ((size_t)(b * P.h + y1) * P.w + x1) * P.C);
+        const float4* l = reinterpret_cast<const float4*>(P.lat + (size_t)q * P.C);
+        float4* o = reinterpret_cast<float4*>(P.out + (size_t)q * P.C);
+        for (int c = lane; c < c4n; c += 64) {
+            const float4 a = c00[c], bq = c01[c], cq = c10[c], dq = c11[c], lv = l[c];
+            float4 v;                                                    // ATen's order: h0 * (w0 * v00 + w1 * v01) + h1 * (w0 * v10 + w1 * v11)
+            v.x = ly0 * (lx0 * a.x + lx1 * bq.x) + ly1 * (lx0 * cq.x + lx1 * dq.x) + lv.x;
+            v.y = ly0 * (lx0 * a.y + lx1 * bq.y) + ly1 * (lx0 * cq.y + lx1 * dq.y) + lv.y;
+            v.z = ly0 * (lx0 * a.z + lx1 * bq.z) + ly1 * (lx0 * cq.z + lx1 * dq.z) + lv.z;
+            v.w = ly0 * (lx0 * a.w + lx1 * bq.w) + ly1 * (lx0 * cq.w + lx1 * dq.w) + lv.w;
+            o[c] = v;
         }
     }
 }
@@ -228,18 +268,36 @@ extern "C" int odpl_sparse_conv3x3_forward(const odpl_sparse_conv3x3_fwd_t* d, v
     if (!d || d->B < 1 || d->H < 1 || d->W < 1 || d->Cin < BK || (d->Cin % BK) || d->Cout < 1) return ODPL_EINVAL;
     if (!d->x || !d->w || !d->y || !d->list || !d->count) return ODPL_EINVAL;
     if (d->act != ODPL_ACT_LINEAR && d->act != ODPL_ACT_RELU && d->act != ODPL_ACT_LEAKY) return ODPL_EINVAL;
+    if (d->ksize != 0 && d->ksize != 1 && d->ksize != 3) return ODPL_EINVAL;
     const long long Pn = (long long)d->B * d->H * d->W;
     if (Pn * d->Cin > 0x7fffffffLL * 4 || Pn > 0x7fffffffLL - 256) return ODPL_EINVAL;
     if (((uintptr_t)d->x) & 15) return ODPL_EINVAL;
-    if (d->w_stride[1] == 1 && ((((uintptr_t)d->w) & 15) || (d->w_stride[0] & 3) || (d->w_stride[2] & 3) || (d->w_stride[3] & 3))) return ODPL_EINVAL;
+    if (d->w_stride[1] == 1 && ((((uintptr_t)d->w) & 15) || (d->w_stride[0] & 3) ||
+                                (d->ksize != 1 && ((d->w_stride[2] & 3) || (d->w_stride[3] & 3))))) return ODPL_EINVAL;   // (a 1 x 1 kernel never steps along ky / kx)
     FwdP P;
     P.x = d->x; P.w = d->w; P.bias = d->bias; P.y = d->y;
     P.ws_o = d->w_stride[0]; P.ws_i = d->w_stride[1]; P.ws_ky = d->w_stride[2]; P.ws_kx = d->w_stride[3];
     P.ybs = d->y_batch_stride; P.yps = d->y_pixel_stride;
     P.list = d->list; P.count = d->count;
     P.B = d->B; P.H = d->H; P.W = d->W; P.Cin = d->Cin; P.Cout = d->Cout; P.act = d->act;
+    P.ks = d->ksize == 1 ? 1 : 3; P.pad = P.ks / 2; P.taps = P.ks * P.ks;
     const long long worst = (Pn + 63) / 64 * ((d->Cout + 63) / 64);
     hipLaunchKernelGGL(sf_conv_kernel, dim3((unsigned)(worst < 2048 ? worst : 2048)), dim3(kT), 0, (hipStream_t)stream_, P);
+    ODPL_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int odpl_sparse_upsample_add(const float* coarse, const float* lateral, float* out, const int32_t* list, const int32_t* count,
+                                        int32_t B, int32_t C, int32_t h, int32_t w, int32_t H, int32_t W, void* stream_) {
+    if (!coarse || !lateral || !out || !list || !count || B < 1 || C < 4 || (C & 3) || h < 1 || w < 1 || H < 1 || W < 1) return ODPL_EINVAL;
+    if ((((uintptr_t)coarse | (uintptr_t)lateral | (uintptr_t)out) & 15) || (long long)B * H * W > 0x7fffffffLL) return ODPL_EINVAL;
+    UpP P;
+    P.coarse = coarse; P.lat = lateral; P.out = out; P.list = list; P.count = count;
+    P.B = B; P.h = h; P.w = w; P.H = H; P.W = W; P.C = C;
+    P.sy = (float)h / (float)H; P.sx = (float)w / (float)W;
+    const long long waves = (long long)B * H * W;
+    const long long blocks = (waves + kT / 64 - 1) / (kT / 64);
+    hipLaunchKernelGGL(sf_upadd_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(kT), 0, (hipStream_t)stream_, P);
     ODPL_HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -82,15 +82,45 @@ class FPN(nn.Module):
     def _up_add(x, y):
         return F.interpolate(x, size=y.shape[2:], mode="bilinear", align_corners=False) + y     # F.upsample(bilinear), :57
 
-    def forward(self, x):
+    def forward(self, x, support=None, reach=0):
+        """support (utils/retinahead.PixelSupport) + reach: a loss-driven training step -- the heads will read p3 / p4 within `reach`
+        pixels of a positive anchor only (on the levels the support lists), so the top-down path is evaluated there only: p_l on
+        N_l = reach(l) united with what the finer level's merge interpolates from, the merged map one pixel further out (the
+        smoothing convolution's reads), the lateral 1 x 1 convolution where the merge is."""
         c1 = F.max_pool2d(_bn(self.conv1(x), self.bn1, "relu"), 3, 2, 1)
         c2 = self.layer1(c1); c3 = self.layer2(c2); c4 = self.layer3(c3); c5 = self.layer4(c4)
         p6 = self.conv6(c5)
         p7 = self.conv7(F.relu(p6))
         p5 = self.latlayer1(c5)
+        if support is not None and support.has(0) and self._topdown_on_pixels_ok(c3, c4, p5):
+            return self._topdown_on_pixels(c3, c4, p5, support, reach) + (p5, p6, p7)
         p4 = self._smooth(self.toplayer1, self._up_add(p5, self.latlayer2(c4)))
         p3 = self._smooth(self.toplayer2, self._up_add(p4, self.latlayer3(c3)))
         return p3, p4, p5, p6, p7
+
+    def _topdown_on_pixels_ok(self, c3, c4, p5):
+        return (_sc._applicable(c3, self.latlayer3) and _sc.conv_ok(self.toplayer2) and self.toplayer2.in_channels == self.latlayer3.out_channels
+                and p5.dtype == torch.float32 and p5.is_contiguous(memory_format=torch.channels_last) and p5.shape[1] == self.latlayer3.out_channels)
+
+    def _topdown_on_pixels(self, c3, c4, p5, sup, reach):
+        B = c3.shape[0]
+        (H3, W3), (H4, W4) = c3.shape[2:], c4.shape[2:]
+        # P3: p3 where the heads read it, the merged map one pixel further out
+        need_p3 = sup.pair(0, reach)
+        need_m3 = sup.pair(0, reach + 1)
+        # P4: what P3's merge interpolates from, plus (if P4's heads run on lists too) what they read; else every pixel (dense P4)
+        if (sup.has(1) and _sc._applicable(c4, self.latlayer2) and _sc.conv_ok(self.toplayer1)
+                and self.toplayer1.in_channels == self.latlayer2.out_channels == p5.shape[1]):
+            need_p4, need_m4 = _sc.union_lists(B, H4, W4, own=sup.pair(1, reach), finer=need_m3, finer_hw=(H3, W3))
+            l4 = _sc.conv_bias_act(c4, self.latlayer2, "linear", need_m4)
+            m4 = _sc.up_add_on_pixels(p5, l4, need_m4)
+            p4 = _sc.conv_bias_act(m4, self.toplayer1, "linear", need_p4)
+        else:
+            p4 = self._smooth(self.toplayer1, self._up_add(p5, self.latlayer2(c4)))
+        l3 = _sc.conv_bias_act(c3, self.latlayer3, "linear", need_m3)
+        m3 = _sc.up_add_on_pixels(p4, l3, need_m3)
+        p3 = _sc.conv_bias_act(m3, self.toplayer2, "linear", need_p3)
+        return p3, p4
 
     @staticmethod
     def _smooth(conv, x):
@@ -185,6 +215,7 @@ class RetinaNet(_Base):
             cls.append(self._run_head(self.cls_head, fm).permute(0, 2, 3, 1).contiguous().view(x.size(0), -1, self.num_classes))
         return torch.cat(loc, 1), torch.cat(cls, 1)
 
+    topdown_on_pixels = True       # class switch: the FPN's top-down path under the same restriction (A/B: --dense-topdown)
     loss_driven_step = True        # class switch (tools/bench_retina_step.py --dense-forward): False = training_step is forward + criterion
 
     def loss_driven_mask(self, x, y):
@@ -227,17 +258,18 @@ class RetinaNet(_Base):
             return None
         if self.iou_boxes is None or self.iou_boxes.device != x.device:
             self._build_anchors(x.device)
-        feats = self.fpn(x)
         crit = self.criterion
+        n_units = (len(self.loc_head) - 1) // 2
+        pos, npos, token = crit.assign(y, x.shape[0])                       # needs anchors and boxes only
+        sup = _rh.PixelSupport(pos, npos, x.shape[0], self._level_shapes(x), n_units + 3, mask)      # reach 0 .. n_units + 2
+        feats = self.fpn(x, sup, n_units + 1) if self.topdown_on_pixels else self.fpn(x)
         ok = [(f.shape[2], f.shape[3]) for f in feats] == self._level_shapes(x) and feats[0].dtype == torch.float32
         for l, f in enumerate(feats):
             if (mask >> l) & 1 and not (_sc._applicable(f, self.loc_head[0]) and _sc._applicable(f, self.cls_head[0])):
                 ok = False
-        if not ok:                                   # (an FPN that does not produce what the shapes promised: dense heads on what it did)
-            return crit(self._heads(x, feats), y)
-        pos, npos, token = crit.assign(y, x.shape[0])
-        n_units = (len(self.loc_head) - 1) // 2
-        sup = _rh.PixelSupport(pos, npos, x.shape[0], [(f.shape[2], f.shape[3]) for f in feats], n_units + 1, mask)
+        if not ok:                                   # (an FPN that does not produce what the shapes promised)
+            crit._assignment = None
+            return crit(self._heads(x, self.fpn(x)), y)
         xl = [self._run_tower(self.loc_head, fm, sup, l) for l, fm in enumerate(feats)]
         xc = [self._run_tower(self.cls_head, fm, sup, l) for l, fm in enumerate(feats)]
         out = _rh.final_convs(self.loc_head[-1], self.cls_head[-1], xl, xc, support=sup, assignment=token)

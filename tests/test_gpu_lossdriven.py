@@ -278,9 +278,9 @@ def test_heads_on_the_loss_pixels_against_the_library_heads(size, B, mask):
     _close(dr["out"][0].reshape(-1, 4)[rows], dn["out"][0].reshape(-1, 4)[rows], 1e-4, 1e-5)
     _close(dr["out"][1].reshape(-1, C)[rows], dn["out"][1].reshape(-1, C)[rows], 1e-4, 1e-5)
     for k in dn["gp"]:
-        assert _rel_l2(dr["gp"][k], dn["gp"][k]) < 1e-2, (k, _rel_l2(dr["gp"][k], dn["gp"][k]))
+        assert _rel_l2(dr["gp"][k], dn["gp"][k]) < 5e-2, (k, _rel_l2(dr["gp"][k], dn["gp"][k]))
     for a, b in zip(dr["gf"], dn["gf"]):
-        assert _rel_l2(a, b) < 1e-2 or float(b.abs().max()) == 0.0
+        assert _rel_l2(a, b) < 5e-2 or float(b.abs().max()) == 0.0
 
 
 def test_training_step_takes_the_loss_driven_route():
@@ -309,7 +309,7 @@ def test_training_step_takes_the_loss_driven_route():
             finally:
                 sc.forward_on_pixels = orig
             d["loss"].backward()
-            assert len(calls) == (20 if driven else 0)                            # 2 levels x 2 heads x (4 tower units + the final convolution)
+            assert len(calls) == (24 if driven else 0)      # 2 levels x (2 heads x (4 tower units + the final convolution) + FPN lateral + smoothing)
             assert all(p.grad is not None for p in model.parameters())
             res.append(({k: float(v.detach()) for k, v in d.items()}, torch.cat([p.grad.flatten().double() for p in model.parameters()]),
                         int(model.criterion.last_counts[0])))
@@ -420,3 +420,179 @@ def test_config4_size_restriction_changes_no_bit():
         assert abs(float(full["loss"][k]) - float(drv["loss"][k])) <= 1e-6 * abs(float(full["loss"][k]))
     for k in full["gp"]:
         assert _rel_l2(drv["gp"][k], full["gp"][k]) < 1e-3, k                             # (sums over all five levels)
+
+
+# ---- the FPN's top-down path under the same restriction ----------------------------------------------------------------------
+
+@pytest.mark.parametrize("B,H,W,Hf,Wf,na,nb", [(2, 13, 17, 25, 34, 9, 30), (1, 50, 84, 100, 167, 0, 400), (3, 8, 8, 16, 16, 20, 0), (2, 5, 6, 10, 11, 0, 0)])
+def test_union_lists_mark_own_pixels_and_bilinear_sources(B, H, W, Hf, Wf, na, nb):
+    from objectdetectionpl_amd.LightningFunc.utils import sparseconv as sc
+    rng = np.random.default_rng(4)
+    own = np.sort(rng.choice(B * H * W, size=na, replace=False)).astype(np.int32)
+    fin = np.sort(rng.choice(B * Hf * Wf, size=nb, replace=False)).astype(np.int32)
+
+    def dev_list(a, n):
+        t = torch.zeros(n, dtype=torch.int32, device=DEV)
+        t[:len(a)] = torch.from_numpy(a).to(DEV)
+        return t, torch.tensor([len(a)], dtype=torch.int32, device=DEV)
+    if na == 0 and nb == 0:
+        with pytest.raises(_lib.OdplError):
+            sc.union_lists(B, H, W)                                            # nothing to build from
+        return
+    (marked, cm), (near, cn) = sc.union_lists(B, H, W, own=dev_list(own, B * H * W) if na else None,
+                                             finer=dev_list(fin, B * Hf * Wf) if nb else None, finer_hw=(Hf, Wf))
+    m = np.zeros((B, H, W), dtype=bool)
+    m.reshape(-1)[own] = True
+    for q in fin:
+        b, rem = divmod(int(q), Hf * Wf)
+        y, x = divmod(rem, Wf)
+        fy = max(np.float32(H / Hf) * np.float32(y + 0.5) - np.float32(0.5), np.float32(0))
+        fx = max(np.float32(W / Wf) * np.float32(x + 0.5) - np.float32(0.5), np.float32(0))
+        y0, x0 = int(fy), int(fx)
+        y1, x1 = y0 + (1 if y0 < H - 1 else 0), x0 + (1 if x0 < W - 1 else 0)
+        for yy in (y0, y1):
+            for xx in (x0, x1):
+                m[b, yy, xx] = True
+    n = np.zeros_like(m)
+    for dy in (-1, 0, 1):
+        for dx in (-1, 0, 1):
+            sh = np.zeros_like(m)
+            sh[:, max(-dy, 0):H + min(-dy, 0), max(-dx, 0):W + min(-dx, 0)] = m[:, max(dy, 0):H + min(dy, 0), max(dx, 0):W + min(dx, 0)]
+            n |= sh
+    assert np.array_equal(marked[:int(cm)].cpu().numpy(), np.flatnonzero(m.reshape(-1)))          # ascending
+    assert np.array_equal(near[:int(cn)].cpu().numpy(), np.flatnonzero(n.reshape(-1)))
+
+
+@pytest.mark.parametrize("B,C,h,w,H,W", [(2, 64, 13, 17, 25, 34), (1, 256, 50, 84, 100, 167), (2, 32, 4, 4, 8, 8), (1, 16, 3, 5, 3, 5)])
+def test_up_add_on_pixels_is_interpolate_plus_lateral_there(B, C, h, w, H, W):
+    from objectdetectionpl_amd.LightningFunc.utils import sparseconv as sc
+    g = torch.Generator().manual_seed(8)
+    coarse = torch.randn(B, h, w, C, generator=g).to(DEV).permute(0, 3, 1, 2).requires_grad_()
+    lat = torch.randn(B, H, W, C, generator=g).to(DEV).permute(0, 3, 1, 2).requires_grad_()
+    P = B * H * W
+    sel = torch.randperm(P, generator=g)[:max(1, P // 3)].to(torch.int32)
+    lst = torch.zeros(P, dtype=torch.int32, device=DEV)
+    lst[:sel.numel()] = sel.to(DEV)
+    cnt = torch.tensor([sel.numel()], dtype=torch.int32, device=DEV)
+    on = torch.zeros(P, dtype=torch.bool, device=DEV)
+    on[sel.long().to(DEV)] = True
+    onm = on.view(B, 1, H, W)
+    got = sc.up_add_on_pixels(coarse, lat, (lst, cnt))
+    want = F.interpolate(coarse, size=(H, W), mode="bilinear", align_corners=False) + lat
+    _close(got, want * onm, 1e-5, 1e-6)
+    assert torch.count_nonzero(got * (~onm)) == 0
+    gy = torch.randn(B, H, W, C, generator=g).to(DEV).permute(0, 3, 1, 2) * onm
+    gc, gl = torch.autograd.grad(got, [coarse, lat], gy)
+    wc, wl = torch.autograd.grad(want, [coarse, lat], gy)
+    _close(gc, wc, 1e-4, 1e-6)
+    assert torch.equal(gl, wl)
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,weights_cl,dens", [(2, 20, 24, 512, 256, True, 0.05), (1, 9, 7, 128, 64, False, 0.3), (2, 16, 16, 64, 64, True, 1.0)])
+def test_one_by_one_convolution_on_pixels_forward_and_backward(B, H, W, cin, cout, weights_cl, dens):
+    """the FPN laterals (1 x 1, pad 0) through the same kernels: forward on a list == F.conv2d there; backward from a sparse gradient ==
+    aten::convolution_backward"""
+    from objectdetectionpl_amd.LightningFunc.utils import sparseconv as sc
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(B, H, W, cin, generator=g).to(DEV).permute(0, 3, 1, 2).requires_grad_()
+    conv = nn.Conv2d(cin, cout, 1).to(DEV)
+    if weights_cl:
+        conv = conv.to(memory_format=torch.channels_last)
+    P = B * H * W
+    sel = torch.nonzero(torch.rand(P, generator=g) < dens).flatten().to(torch.int32)
+    lst = torch.zeros(P, dtype=torch.int32, device=DEV)
+    lst[:sel.numel()] = sel.to(DEV)
+    cnt = torch.tensor([sel.numel()], dtype=torch.int32, device=DEV)
+    on = torch.zeros(P, dtype=torch.bool, device=DEV)
+    on[sel.long().to(DEV)] = True
+    onm = on.view(B, 1, H, W)
+    old = sc.min_pixels
+    sc.min_pixels = 1
+    try:
+        assert sc._applicable(x, conv)
+        got = sc.conv_bias_act(x, conv, "linear", (lst, cnt))
+        want = conv(x)
+        _close(got, want.detach() * onm, 1e-4, 2e-6)
+        gy = torch.randn(B, H, W, cout, generator=g).to(DEV).permute(0, 3, 1, 2) * onm
+        ga = torch.autograd.grad(got, [x, conv.weight, conv.bias], gy)
+        gb = torch.autograd.grad(want, [x, conv.weight, conv.bias], gy)
+    finally:
+        sc.min_pixels = old
+    for a, b in zip(ga, gb):
+        _close(a, b, 1e-4, 2e-6)
+
+
+def _topdown_run(model, c3, c4, p5, rest, y, B, mode, mask):
+    """FPN top-down (laterals, merges, smoothing) + both heads + criterion on fixed backbone features"""
+    from objectdetectionpl_amd.LightningFunc.utils import retinahead as rh
+    leaves = [t.clone().requires_grad_() for t in (c3, c4, p5)]
+    model.zero_grad(set_to_none=True)
+    crit = model.criterion
+    fpn = model.fpn
+    shapes = [(t.shape[2], t.shape[3]) for t in (c3, c4, p5)] + [(t.shape[2], t.shape[3]) for t in rest]
+    if mode == "library":
+        p4 = fpn._smooth(fpn.toplayer1, fpn._up_add(leaves[2], fpn.latlayer2(leaves[1])))
+        p3 = fpn._smooth(fpn.toplayer2, fpn._up_add(p4, fpn.latlayer3(leaves[0])))
+        feats = [p3, p4, leaves[2]] + list(rest)
+        out = rh.final_convs(model.loc_head[-1], model.cls_head[-1], [model._run_tower(model.loc_head, fm) for fm in feats],
+                             [model._run_tower(model.cls_head, fm) for fm in feats])
+    else:
+        pos, npos, token = crit.assign(y, B)
+        sup = rh.PixelSupport(pos, npos, B, shapes, 7, mask) if mode == "driven" else _EveryPixel(B, shapes, mask)
+        p3, p4 = fpn._topdown_on_pixels(leaves[0], leaves[1], leaves[2], sup, 5)
+        feats = [p3, p4, leaves[2]] + list(rest)
+        xl = [model._run_tower(model.loc_head, fm, sup, l) for l, fm in enumerate(feats)]
+        xc = [model._run_tower(model.cls_head, fm, sup, l) for l, fm in enumerate(feats)]
+        out = rh.final_convs(model.loc_head[-1], model.cls_head[-1], xl, xc, support=sup, assignment=token)
+    d = crit(out, y)
+    d["loss"].backward()
+    return dict(loss={k: v.detach().clone() for k, v in d.items()}, gl=[t.grad.clone() for t in leaves],
+                gp={k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}, n=int(crit.last_counts[0]))
+
+
+@pytest.mark.parametrize("size,B,mask", [(256, 2, 0b00011), (320, 1, 0b00001), (384, 2, 0b00011)])
+def test_topdown_on_the_loss_pixels_changes_no_bit_and_matches_the_library(size, B, mask):
+    """Fixed backbone features (c3, c4, p5, p6, p7): laterals + merges + smoothing + heads + criterion with the pixel lists, with EVERY
+    pixel through the same kernels (bit for bit: loss, d loss / d (c3, c4, p5), every FPN top-down and head parameter), and through
+    the library (loss 1e-5, gradients 5e-2 in relative L2: a handful of flipped ReLUs among few positives)."""
+    from objectdetectionpl_amd.LightningFunc.utils import sparseconv as sc
+    torch.manual_seed(0)
+    C = 5
+    model = _model(C, size)
+    g = torch.Generator().manual_seed(14)
+    x = torch.rand(B, 3, size, size, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    y = _targets(g, B, 3, C).to(DEV)
+    fpn = model.fpn
+    with torch.no_grad():
+        c1 = F.max_pool2d(torch.relu(fpn.bn1(fpn.conv1(x))), 3, 2, 1)
+        c3 = fpn.layer2(fpn.layer1(c1)); c4 = fpn.layer3(c3); c5 = fpn.layer4(c4)
+        p6 = fpn.conv6(c5); p7 = fpn.conv7(F.relu(p6)); p5 = fpn.latlayer1(c5)
+        c3, c4, p5, p6, p7 = (t.contiguous(memory_format=torch.channels_last).clone() for t in (c3, c4, p5, p6, p7))
+    old = sc.min_pixels, sc.max_density
+    sc.min_pixels, sc.max_density = 1, 2.0
+    try:
+        lib = _topdown_run(model, c3, c4, p5, (p6, p7), y, B, "library", mask)
+        full = _topdown_run(model, c3, c4, p5, (p6, p7), y, B, "everywhere", mask)
+        drv = _topdown_run(model, c3, c4, p5, (p6, p7), y, B, "driven", mask)
+    finally:
+        sc.min_pixels, sc.max_density = old
+    assert lib["n"] == full["n"] == drv["n"] > 10
+    topdown = ("fpn.latlayer2", "fpn.latlayer3", "fpn.toplayer1", "fpn.toplayer2")
+    for k in full["loss"]:
+        assert abs(float(full["loss"][k]) - float(drv["loss"][k])) <= 1e-6 * abs(float(full["loss"][k])), k
+        assert abs(float(lib["loss"][k]) - float(drv["loss"][k])) <= 1e-5 * abs(float(lib["loss"][k])), k
+    listed = [l for l in (0, 1) if (mask >> l) & 1]                              # a level off the mask runs the library: not reproducible
+    for i in (0, 1):                                                            # d loss / d c3, c4
+        if i in listed:
+            assert torch.equal(full["gl"][i], drv["gl"][i]), i
+        assert _rel_l2(drv["gl"][i], lib["gl"][i]) < 5e-2 and _rel_l2(drv["gl"][i], full["gl"][i]) < 5e-2
+    assert _rel_l2(drv["gl"][2], full["gl"][2]) < 5e-2 and _rel_l2(drv["gl"][2], lib["gl"][2]) < 5e-2   # p5 also feeds its own (library) heads
+    exact = ("fpn.latlayer3", "fpn.toplayer2") + (("fpn.latlayer2", "fpn.toplayer1") if 1 in listed else ())
+    seen = 0
+    for k in full["gp"]:
+        if k.startswith(exact):
+            assert torch.equal(full["gp"][k], drv["gp"][k]), k
+        if k.startswith(topdown):
+            seen += 1
+        assert _rel_l2(drv["gp"][k], lib["gp"][k]) < 5e-2, (k, _rel_l2(drv["gp"][k], lib["gp"][k]))
+    assert seen == 8

@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--dense-forward", action="store_true",
                     help="A/B: training_step = forward + criterion on all 200 700 anchors (round 3 before the loss-driven step); default: the "
                          "assignment runs first and the heads are evaluated on the pixels RetinaNetLoss reads (model/RetinaNet.py:forward_and_loss)")
+    ap.add_argument("--dense-topdown", action="store_true", help="A/B: the FPN's top-down path (laterals, merges, smoothing) on every pixel")
     ap.add_argument("--dense-tower-backward", action="store_true", help="A/B: the head towers' 3x3 convolutions keep MIOpen's backward on every level")
     ap.add_argument("--gt-per-image", type=int, default=8)
     ap.add_argument("--wh-range", type=float, nargs=2, default=(0.05, 0.5), metavar=("LO", "HI"),
@@ -51,6 +52,7 @@ def main():
     retinahead.enabled = not a.no_hosted_heads
     RetinaNetLoss.fuse_head_backward = not a.dense_head_backward
     RetinaNet.loss_driven_step = not a.dense_forward
+    RetinaNet.topdown_on_pixels = not a.dense_topdown
     dev = torch.device("cuda:0")
     torch.backends.cudnn.benchmark = bool(a.miopen_find)
     torch.manual_seed(0)
@@ -85,6 +87,7 @@ def main():
     t1 = time.perf_counter()
     for _ in range(a.steps):
         d = step()
+    t_enq = (time.perf_counter() - t1) / a.steps                                  # host time to enqueue a step (== the step when host-bound)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t1) / a.steps
     kern = {}
@@ -95,11 +98,13 @@ def main():
             kern[k + "_us"] = round(1e3 * sum(ms) / len(ms), 2)
     assert anchors.shape[0] == 200700 or (a.height, a.width) != (800, 1333)
     print(json.dumps({"workload": f"RetinaNet-R50-FPN {a.height}x{a.width} bs={a.batch} training step, fp32, C=80, {anchors.shape[0]} anchors",
-                      "img_per_s": round(a.batch / dt, 2), "ms_per_step": round(dt * 1e3, 2), "loss": round(float(d["loss"].detach()), 4),
+                      "img_per_s": round(a.batch / dt, 2), "ms_per_step": round(dt * 1e3, 2), "host_enqueue_ms_per_step": round(t_enq * 1e3, 2), "loss": round(float(d["loss"].detach()), 4),
                       "num_pos": int(crit.last_counts[0]), "gt_per_image": a.gt_per_image, "wh_range": list(a.wh_range), "miopen_find": bool(a.miopen_find),
                       "hosted_heads": not a.no_hosted_heads, "structured_head_backward": not (a.no_hosted_heads or a.dense_head_backward),
                       "sparse_tower_backward": not a.dense_tower_backward,
-                      "loss_driven_forward": not (a.dense_forward or a.no_hosted_heads or a.dense_head_backward or a.dense_tower_backward), **kern}))
+                      "loss_driven_forward": not (a.dense_forward or a.no_hosted_heads or a.dense_head_backward or a.dense_tower_backward),
+                      "topdown_on_pixels": not (a.dense_topdown or a.dense_forward or a.no_hosted_heads or a.dense_head_backward or a.dense_tower_backward),
+                      **kern}))
 
 
 if __name__ == "__main__":
