@@ -400,7 +400,10 @@ typedef struct {
     int32_t act;                             /* ODPL_ACT_LINEAR / _RELU / _LEAKY on conv + bias */
     int32_t ksize;                           /* 0 or 3: 3 x 3, pad 1; 1: 1 x 1, pad 0 */
 } odpl_sparse_conv3x3_fwd_t;
-int odpl_sparse_conv3x3_forward(const odpl_sparse_conv3x3_fwd_t* desc, void* stream);
+/* K is always summed as 8 consecutive ranges added left to right.  workspace (optional, >= 1 MiB, 16-byte aligned; NULL = none): a launch whose
+ * list is short (<= 128 output tiles) gives each range its own workgroup and adds the partials in the same order in a second launch --
+ * same bits either way; 32 MiB covers every such case at Cout <= 1024 */
+int odpl_sparse_conv3x3_forward(const odpl_sparse_conv3x3_fwd_t* desc, void* workspace, size_t workspace_bytes, void* stream);
 
 /* The FPN's top-down path under the same restriction (model/backbone/RetinaNetbone.py:55-75: p4 = toplayer1(up(p5) + latlayer2(c4)),
  * p3 = toplayer2(up(p4) + latlayer3(c3)); `F.upsample(..., mode='bilinear')`, align_corners = False).

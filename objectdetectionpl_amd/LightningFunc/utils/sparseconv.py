@@ -157,7 +157,12 @@ def forward_on_pixels(x, w, b, act, support, out=None, out_strides=None):
     d.y_batch_stride, d.y_pixel_stride = out_strides
     d.list, d.count = support[0].data_ptr(), support[1].data_ptr()
     d.B, d.H, d.W, d.Cin, d.Cout, d.act, d.ksize = N, H, W, Cin, C, act, w.shape[2]
-    _lib.check(_lib.lib().odpl_sparse_conv3x3_forward(ctypes.byref(d), _lib.current_stream(x.device)), "odpl_sparse_conv3x3_forward")
+    ws = _ws2.get((x.device, "fwd"))
+    if ws is None:
+        ws = torch.empty(32 << 20, dtype=torch.uint8, device=x.device)           # split-K partials of short lists (stream-ordered reuse)
+        _ws2[(x.device, "fwd")] = ws
+    _lib.check(_lib.lib().odpl_sparse_conv3x3_forward(ctypes.byref(d), _lib.ptr(ws), ws.numel(), _lib.current_stream(x.device)),
+               "odpl_sparse_conv3x3_forward")
     return out
 
 

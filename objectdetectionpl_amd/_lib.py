@@ -196,7 +196,7 @@ SIGNATURES = {
     "odpl_sparse_conv3x3_backward": (c_int32, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "odpl_pixel_support_workspace_bytes": (c_size_t, [c_void_p]),
     "odpl_pixel_support": (c_int32, [c_void_p, c_void_p, c_size_t, c_void_p]),
-    "odpl_sparse_conv3x3_forward": (c_int32, [c_void_p, c_void_p]),
+    "odpl_sparse_conv3x3_forward": (c_int32, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "odpl_pixel_union_lists_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "odpl_pixel_union_lists": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -31,6 +31,7 @@ struct SP {
     int* off_out; int* off_in;           // [ntile + 1] exclusive scans; [ntile] = totals
     int* list_out; int* list_in;         // [P] ascending pixel ids
     float* part;                         // [kSplits][9][Cout][Cin]
+    float* part_x; long long part_x_floats;   // split-K partials of the data GEMM on short lists: [R][tiles_m * 64][Cin]
     int* stats;                          // optional [2]: active pixels, pixels within one pixel of an active one (for the caller's route choice)
 };
 
@@ -105,7 +106,16 @@ __global__ __launch_bounds__(kT) void sc_list_kernel(const SP P) {
     if (i) P.list_in[b1 + __popcll(mi & below)] = p;
 }
 
-// dX rows of the pixels in list_in: [n_in, 9 * Cout] (gathered rows of gY, one tap at a time) x [9 * Cout, Cin]
+// K (= taps * Cout / 32 tiles) is ALWAYS summed as R = 8 consecutive ranges whose sums are added left to right; a short list (a few dozen
+// output tiles, each a serial walk over all of K at the matrix pipe's pace) gives every range its own workgroup and sc_data_finish_kernel
+// adds the partials in the same order: same bits whichever way a launch went (csrc/odpl_sparsefwd.hip does the same going forward).
+__device__ __forceinline__ int k_ranges(int nk) { return nk < 8 ? nk : 8; }
+__device__ __forceinline__ int k_bound(int r, int nk, int R) { return (int)((long long)r * nk / R); }
+__device__ __forceinline__ bool split_ranges(int ntiles, int tiles_m, int cin, int R, const float* part, long long part_floats) {
+    return part && R > 1 && ntiles * R <= 1024 && (long long)tiles_m * 64 * cin * R <= part_floats;
+}
+
+// dX rows of the pixels in list_in: [n_in, taps * Cout] (gathered rows of gY, one tap at a time) x [taps * Cout, Cin]
 __global__ __launch_bounds__(kT) void sc_data_kernel(const SP P) {
     constexpr int BM = 64, BN = 64, LDA = BK + 1, LDB = BN + 4;
     __shared__ float As[BM * LDA];
@@ -116,7 +126,11 @@ __global__ __launch_bounds__(kT) void sc_data_kernel(const SP P) {
     const int n_in = P.off_in[P.ntile];
     const int tiles_n = P.Cin / BN, tiles_m = (n_in + BM - 1) / BM, ntiles = tiles_m * tiles_n;
     const int hw = P.H * P.W, kpt = P.Cout / BK;                         // K steps per tap
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int nk_all = P.taps * kpt, R = k_ranges(nk_all);
+    const int S = split_ranges(ntiles, tiles_m, P.Cin, R, P.part_x, P.part_x_floats) ? R : 1;
+    for (int work = blockIdx.x; work < ntiles * S; work += gridDim.x) {
+        const int tile = work / S, sp = work - tile * S;
+        const int k_begin = S == 1 ? 0 : k_bound(sp, nk_all, R), k_end = S == 1 ? nk_all : k_bound(sp + 1, nk_all, R);
         const int tm = tile / tiles_n, tn = tile - tm * tiles_n, bn = tn * BN;
         __syncthreads();
         if (tid < BM) {
@@ -125,9 +139,10 @@ __global__ __launch_bounds__(kT) void sc_data_kernel(const SP P) {
             s_q[tid] = q; s_b[tid] = b; s_y[tid] = y; s_x[tid] = rem - y * P.W;
         }
         __syncthreads();
-        f32x16 acc;
+        f32x16 acc, total;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int r = 0; r < 16; ++r) { acc[r] = 0.f; total[r] = 0.f; }
+        int cur = 0, next_bound = S == 1 ? k_bound(1, nk_all, R) : k_end;
         float4 ra[2], rb[2];
         auto load_tiles = [&](int kt) {
             const int t = kt / kpt, co0 = (kt - t * kpt) * BK, ky = t / P.ks, kx = t - P.ks * ky;
@@ -161,25 +176,55 @@ __global__ __launch_bounds__(kT) void sc_data_kernel(const SP P) {
                 *reinterpret_cast<float4*>(Bs + kr * LDB + 4 * nq) = rb[i];
             }
         };
-        const int nk = P.taps * kpt;
-        load_tiles(0);
+        load_tiles(k_begin);
         store_tiles();
         __syncthreads();
-        for (int kt = 0; kt < nk; ++kt) {
-            if (kt + 1 < nk) load_tiles(kt + 1);
+        for (int kt = k_begin; kt < k_end; ++kt) {
+            if (kt + 1 < k_end) load_tiles(kt + 1);
 #pragma unroll
             for (int kk = 0; kk < BK; kk += 2) {
                 const float a = As[(wm + lr) * LDA + kk + lk], b = Bs[(kk + lk) * LDB + wn + lr];
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
             }
+            if (S == 1 && kt + 1 == next_bound) {                        // unsplit: fold the range sums in order as they complete
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { total[r] += acc[r]; acc[r] = 0.f; }
+                ++cur; next_bound = k_bound(cur + 1, nk_all, R);
+            }
             __syncthreads();
-            if (kt + 1 < nk) { store_tiles(); __syncthreads(); }
+            if (kt + 1 < k_end) { store_tiles(); __syncthreads(); }
+        }
+        if (S > 1) {
+            float* o = P.part_x + ((size_t)sp * tiles_m * BM + (size_t)tm * BM) * P.Cin + bn + wn + lr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[(size_t)(wm + (r & 3) + 8 * (r >> 2) + 4 * lk) * P.Cin] = acc[r];
+            continue;
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = wm + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            if (tm * BM + row < n_in) P.gx[(size_t)s_q[row] * P.Cin + bn + wn + lr] = acc[r];
+            if (tm * BM + row < n_in) P.gx[(size_t)s_q[row] * P.Cin + bn + wn + lr] = total[r];
         }
+    }
+}
+
+// the split launches' second half: dX[q, ci] = sum over the R ranges in range order; returns at once when the launch was not split
+__global__ __launch_bounds__(kT) void sc_data_finish_kernel(const SP P) {
+    const int n_in = P.off_in[P.ntile];
+    const int tiles_n = P.Cin / 64, tiles_m = (n_in + 63) / 64, kpt = P.Cout / BK;
+    const int R = k_ranges(P.taps * kpt);
+    if (!split_ranges(tiles_m * tiles_n, tiles_m, P.Cin, R, P.part_x, P.part_x_floats)) return;
+    const size_t plane = (size_t)tiles_m * 64 * P.Cin;
+    const int c4n = P.Cin >> 2;
+    const long long total = (long long)n_in * c4n;
+    for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < total; i += (long long)gridDim.x * kT) {
+        const int r = (int)(i / c4n), c = (int)(i - (long long)r * c4n);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                      // 0 + r0 + r1 + ...: the order of the unsplit launch
+        for (int s2 = 0; s2 < R; ++s2) {
+            const float4 p = *reinterpret_cast<const float4*>(P.part_x + s2 * plane + (size_t)r * P.Cin + 4 * c);
+            v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+        }
+        *reinterpret_cast<float4*>(P.gx + (size_t)P.list_in[r] * P.Cin + 4 * c) = v;
     }
 }
 
@@ -286,7 +331,8 @@ __global__ __launch_bounds__(kT) void un_mark_kernel(const UnP P) {
 }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-struct Plan { size_t cnt_out, cnt_in, off_out, off_in, list_out, list_in, part, total; int P, ntile; };
+struct Plan { size_t cnt_out, cnt_in, off_out, off_in, list_out, list_in, part, part_x, total; int P, ntile; };
+constexpr size_t kPartXBytes = 32u << 20;      // split-K partials of the data GEMM (short lists only)
 
 bool make_plan(const odpl_sparse_conv3x3_t* d, Plan* p) {
     if (!d || d->B < 1 || d->H < 1 || d->W < 1 || d->Cin < 64 || (d->Cin % 64) || d->Cout < 64 || (d->Cout % 64)) return false;
@@ -303,6 +349,7 @@ bool make_plan(const odpl_sparse_conv3x3_t* d, Plan* p) {
     p->list_out = off; off += align_up((size_t)P * 4, 256);
     p->list_in = off; off += align_up((size_t)P * 4, 256);
     p->part = off; off += align_up((size_t)kSplits * (d->ksize == 1 ? 1 : 9) * d->Cout * d->Cin * 4, 256);
+    p->part_x = off; off += kPartXBytes;
     p->total = off;
     return true;
 }
@@ -329,6 +376,7 @@ extern "C" int odpl_sparse_conv3x3_backward(const odpl_sparse_conv3x3_t* d, void
     P.cnt_out = (int*)(ws + pl.cnt_out); P.cnt_in = (int*)(ws + pl.cnt_in); P.off_out = (int*)(ws + pl.off_out); P.off_in = (int*)(ws + pl.off_in);
     P.list_out = (int*)(ws + pl.list_out); P.list_in = (int*)(ws + pl.list_in); P.part = (float*)(ws + pl.part);
     P.stats = d->stats;
+    P.part_x = (float*)(ws + pl.part_x); P.part_x_floats = (long long)(kPartXBytes / sizeof(float));
     hipLaunchKernelGGL(sc_count_kernel, dim3(pl.ntile), dim3(kT), 0, stream, P);
     ODPL_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(sc_scan_kernel, dim3(1), dim3(1024), 0, stream, P);
@@ -339,6 +387,8 @@ extern "C" int odpl_sparse_conv3x3_backward(const odpl_sparse_conv3x3_t* d, void
         ODPL_HIP_TRY(odpl::fill_bytes(d->grad_x, 0, (size_t)pl.P * d->Cin * sizeof(float), stream));
         long long worst = ((long long)pl.P + 63) / 64 * (d->Cin / 64);
         hipLaunchKernelGGL(sc_data_kernel, dim3((unsigned)(worst < 2048 ? worst : 2048)), dim3(kT), 0, stream, P);
+        ODPL_HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(sc_data_finish_kernel, dim3(512), dim3(kT), 0, stream, P);
         ODPL_HIP_TRY(hipGetLastError());
     }
     if (d->grad_w) {

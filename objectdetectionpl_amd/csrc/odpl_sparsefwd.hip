@@ -93,13 +93,26 @@ struct FwdP {
     const int* list; const int* count;
     int B, H, W, Cin, Cout, act;
     int ks, pad, taps;                   // 3 x 3 (pad 1) or 1 x 1 (pad 0)
+    float* part; long long part_floats;  // split-K partials [S][tiles_m * 64][tiles_n * 64] (null: never split)
 };
+
+// A short list makes a grid of a few dozen workgroups, each walking all 9 * Cin / 32 K tiles at the matrix pipe's own pace (16 MFMAs of
+// 64 cycles per tile and wave): the launch takes as long as ONE tile's K loop however idle the chip is.  K is therefore ALWAYS summed as
+// R = 8 consecutive ranges (range sums added left to right), and a short list gives each range to its own workgroup; a second launch
+// adds the R partials in the same order and applies the epilogue.  The result does not depend on which way a launch went -- bit for bit.
+__device__ __forceinline__ int k_ranges(int nk) { return nk < 8 ? nk : 8; }
+__device__ __forceinline__ int k_bound(int r, int nk, int R) { return (int)((long long)r * nk / R); }
+__device__ __forceinline__ bool split_ranges(int ntiles, int tiles_m, int tiles_n, int R, const float* part, long long part_floats) {
+    return part && R > 1 && ntiles * R <= 1024 && (long long)tiles_m * 64 * tiles_n * 64 * R <= part_floats;
+}
 
 // y rows of the listed pixels: [n, 9 * Cin] (rows of x gathered one tap at a time) x [9 * Cin, Cout]
 __global__ __launch_bounds__(kT) void sf_conv_kernel(const FwdP P) {
     constexpr int BM = 64, BN = 64, LD = BK + 1;
-    __shared__ float As[BM * LD];
-    __shared__ float Bs[BN * LD];
+    constexpr int D = 4;                                                 // K tiles in flight per workgroup: these grids are a few dozen
+                                                                         // workgroups walking 72 K tiles each -- latency, not bandwidth
+    __shared__ float As[2][BM * LD];
+    __shared__ float Bs[2][BN * LD];
     __shared__ int s_b[BM], s_y[BM], s_x[BM];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wm = (wv >> 1) * 32, wn = (wv & 1) * 32, lr = lane & 31, lk = lane >> 5;
@@ -108,7 +121,11 @@ __global__ __launch_bounds__(kT) void sf_conv_kernel(const FwdP P) {
     if (n > cap) n = cap;
     const int tiles_n = (P.Cout + BN - 1) / BN, tiles_m = (n + BM - 1) / BM, ntiles = tiles_m * tiles_n;
     const int hw = P.H * P.W, kpt = P.Cin / BK;                          // K steps per tap
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int nk_all = P.taps * kpt, R = k_ranges(nk_all);
+    const int S = split_ranges(ntiles, tiles_m, tiles_n, R, P.part, P.part_floats) ? R : 1;
+    for (int work = blockIdx.x; work < ntiles * S; work += gridDim.x) {
+        const int tile = work / S, sp = work - tile * S;
+        const int k_begin = S == 1 ? 0 : k_bound(sp, nk_all, R), nk = S == 1 ? nk_all : k_bound(sp + 1, nk_all, R) - k_begin;
         const int tm = tile / tiles_n, tn = tile - tm * tiles_n, bn = tn * BN;
         __syncthreads();
         if (tid < BM) {
@@ -117,11 +134,13 @@ __global__ __launch_bounds__(kT) void sf_conv_kernel(const FwdP P) {
             s_b[tid] = b; s_y[tid] = y; s_x[tid] = rem - y * P.W;
         }
         __syncthreads();
-        f32x16 acc;
+        f32x16 acc, total;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        float4 ra[2], rb[2];
-        auto load_tiles = [&](int kt) {
+        for (int r = 0; r < 16; ++r) { acc[r] = 0.f; total[r] = 0.f; }
+        int cur = 0, next_bound = S == 1 ? k_bound(1, nk_all, R) : nk;       // unsplit: fold the range sums in order as they complete
+        float4 ra[D][2], rb[D][2];
+        auto load_tiles = [&](int kl, float4 (&xa)[2], float4 (&xb)[2]) {          // kl: K tile within this range
+            const int kt = k_begin + kl;
             const int t = kt / kpt, ci0 = (kt - t * kpt) * BK, ky = t / P.ks, kx = t - P.ks * ky;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -130,42 +149,64 @@ __global__ __launch_bounds__(kT) void sf_conv_kernel(const FwdP P) {
                 const bool in = yy >= 0 && yy < P.H && xx >= 0 && xx < P.W;
                 const size_t src = ((size_t)s_b[row] * hw + (in ? yy * P.W + xx : 0)) * P.Cin + ci0 + 4 * kq;
                 const float4 v = *reinterpret_cast<const float4*>(P.x + src);
-                ra[i] = in ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+                xa[i] = in ? v : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int f = tid + kT * i, nr = f >> 3, kq = f & 7;                         // W[bn + nr][ci0 + 4 kq ..][ky][kx]
                 int co = bn + nr; if (co > P.Cout - 1) co = P.Cout - 1;                      // surplus columns: computed, not stored
                 const long long off = (long long)co * P.ws_o + ky * P.ws_ky + kx * P.ws_kx + (long long)(ci0 + 4 * kq) * P.ws_i;
-                rb[i] = P.ws_i == 1 ? *reinterpret_cast<const float4*>(P.w + off)
+                xb[i] = P.ws_i == 1 ? *reinterpret_cast<const float4*>(P.w + off)
                                     : make_float4(P.w[off], P.w[off + P.ws_i], P.w[off + 2 * P.ws_i], P.w[off + 3 * P.ws_i]);
             }
         };
-        auto store_tiles = [&]() {
+        auto store_tiles = [&](int buf, const float4 (&xa)[2], const float4 (&xb)[2]) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int f = tid + kT * i, row = f >> 3, kq = f & 7;
-                float* d = As + row * LD + 4 * kq;
-                d[0] = ra[i].x; d[1] = ra[i].y; d[2] = ra[i].z; d[3] = ra[i].w;
-                float* e = Bs + row * LD + 4 * kq;
-                e[0] = rb[i].x; e[1] = rb[i].y; e[2] = rb[i].z; e[3] = rb[i].w;
+                float* d = As[buf] + row * LD + 4 * kq;
+                d[0] = xa[i].x; d[1] = xa[i].y; d[2] = xa[i].z; d[3] = xa[i].w;
+                float* e = Bs[buf] + row * LD + 4 * kq;
+                e[0] = xb[i].x; e[1] = xb[i].y; e[2] = xb[i].z; e[3] = xb[i].w;
             }
         };
-        const int nk = P.taps * kpt;
-        load_tiles(0);
-        store_tiles();
-        __syncthreads();
-        for (int kt = 0; kt < nk; ++kt) {
-            if (kt + 1 < nk) load_tiles(kt + 1);
+        // K tile t travels: global -> register set t % D (requested D - 1 iterations before it is needed) -> LDS image (t & 1) -> MFMA
 #pragma unroll
-            for (int kk = 0; kk < BK; kk += 2) {
-                const float a = As[(wm + lr) * LD + kk + lk], b = Bs[(wn + lr) * LD + kk + lk];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        for (int j = 0; j < D; ++j)
+            if (j < nk) load_tiles(j, ra[j], rb[j]);
+        store_tiles(0, ra[0], rb[0]);
+        __syncthreads();
+        for (int kt0 = 0; kt0 < nk; kt0 += D) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const int kt = kt0 + j;
+                if (kt < nk) {
+                    if (kt + 1 < nk) store_tiles((j + 1) & 1, ra[(j + 1) % D], rb[(j + 1) % D]);   // (kt0 is a multiple of D, D even)
+                    if (kt + D < nk) load_tiles(kt + D, ra[j], rb[j]);                             // set j was stored one iteration ago
+                    const float* A = As[j & 1];
+                    const float* Bm = Bs[j & 1];
+#pragma unroll
+                    for (int kk = 0; kk < BK; kk += 2) {
+                        const float a = A[(wm + lr) * LD + kk + lk], b = Bm[(wn + lr) * LD + kk + lk];
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+                    }
+                    if (S == 1 && kt + 1 == next_bound) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) { total[r] += acc[r]; acc[r] = 0.f; }
+                        ++cur; next_bound = k_bound(cur + 1, nk_all, R);
+                    }
+                    __syncthreads();
+                }
             }
-            __syncthreads();
-            if (kt + 1 < nk) { store_tiles(); __syncthreads(); }
         }
+        if (S == 1) acc = total;
         const int co = bn + wn + lr;
+        if (S > 1) {                                                     // partial sums of this K range; sf_finish_kernel does the rest
+            float* o = P.part + ((size_t)sp * tiles_m * BM + (size_t)tm * BM) * ((size_t)tiles_n * BN) + bn + wn + lr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[(size_t)(wm + (r & 3) + 8 * (r >> 2) + 4 * lk) * ((size_t)tiles_n * BN)] = acc[r];
+            continue;
+        }
         const float bv = (P.bias && co < P.Cout) ? P.bias[co] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -177,6 +218,30 @@ __global__ __launch_bounds__(kT) void sf_conv_kernel(const FwdP P) {
                 P.y[(long long)s_b[row] * P.ybs + (long long)(s_y[row] * P.W + s_x[row]) * P.yps + co] = v;
             }
         }
+    }
+}
+
+// the split launches' second half: y[q, co] = act(bias + sum over the S ranges, in range order); returns at once when S = 1
+__global__ __launch_bounds__(kT) void sf_finish_kernel(const FwdP P) {
+    int n = P.count[0];
+    const int cap = P.B * P.H * P.W;
+    if (n > cap) n = cap;
+    const int tiles_n = (P.Cout + 63) / 64, tiles_m = (n + 63) / 64, kpt = P.Cin / BK;
+    const int R = k_ranges(P.taps * kpt);
+    if (!split_ranges(tiles_m * tiles_n, tiles_m, tiles_n, R, P.part, P.part_floats)) return;
+    const int S = R;
+    const int hw = P.H * P.W, ld = tiles_n * 64;
+    const size_t plane = (size_t)tiles_m * 64 * ld;
+    const long long total = (long long)n * P.Cout;
+    for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < total; i += (long long)gridDim.x * kT) {
+        const int r = (int)(i / P.Cout), co = (int)(i - (long long)r * P.Cout);
+        float v = 0.f;                                                   // 0 + r0 + r1 + ...: the order of the unsplit launch
+        for (int s2 = 0; s2 < S; ++s2) v += P.part[s2 * plane + (size_t)r * ld + co];
+        if (P.bias) v += P.bias[co];
+        if (P.act == ODPL_ACT_RELU) v = v > 0.f ? v : 0.f;
+        else if (P.act == ODPL_ACT_LEAKY) v = v > 0.f ? v : 0.1f * v;
+        const int q = P.list[r], b = q / hw, rem = q - b * hw;
+        P.y[(long long)b * P.ybs + (long long)rem * P.yps + co] = v;
     }
 }
 
@@ -264,7 +329,7 @@ extern "C" int odpl_pixel_support(const odpl_pixel_support_t* d, void* workspace
     return 0;
 }
 
-extern "C" int odpl_sparse_conv3x3_forward(const odpl_sparse_conv3x3_fwd_t* d, void* stream_) {
+extern "C" int odpl_sparse_conv3x3_forward(const odpl_sparse_conv3x3_fwd_t* d, void* workspace, size_t workspace_bytes, void* stream_) {
     if (!d || d->B < 1 || d->H < 1 || d->W < 1 || d->Cin < BK || (d->Cin % BK) || d->Cout < 1) return ODPL_EINVAL;
     if (!d->x || !d->w || !d->y || !d->list || !d->count) return ODPL_EINVAL;
     if (d->act != ODPL_ACT_LINEAR && d->act != ODPL_ACT_RELU && d->act != ODPL_ACT_LEAKY) return ODPL_EINVAL;
@@ -281,9 +346,15 @@ extern "C" int odpl_sparse_conv3x3_forward(const odpl_sparse_conv3x3_fwd_t* d, v
     P.list = d->list; P.count = d->count;
     P.B = d->B; P.H = d->H; P.W = d->W; P.Cin = d->Cin; P.Cout = d->Cout; P.act = d->act;
     P.ks = d->ksize == 1 ? 1 : 3; P.pad = P.ks / 2; P.taps = P.ks * P.ks;
+    const bool split = workspace && workspace_bytes >= (1u << 20) && !(((uintptr_t)workspace) & 15);   // optional: short lists cut K over workgroups
+    P.part = split ? (float*)workspace : nullptr; P.part_floats = split ? (long long)(workspace_bytes / sizeof(float)) : 0;
     const long long worst = (Pn + 63) / 64 * ((d->Cout + 63) / 64);
     hipLaunchKernelGGL(sf_conv_kernel, dim3((unsigned)(worst < 2048 ? worst : 2048)), dim3(kT), 0, (hipStream_t)stream_, P);
     ODPL_HIP_TRY(hipGetLastError());
+    if (split) {
+        hipLaunchKernelGGL(sf_finish_kernel, dim3(512), dim3(kT), 0, (hipStream_t)stream_, P);
+        ODPL_HIP_TRY(hipGetLastError());
+    }
     return 0;
 }
 
