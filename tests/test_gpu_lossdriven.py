@@ -596,3 +596,47 @@ def test_topdown_on_the_loss_pixels_changes_no_bit_and_matches_the_library(size,
             seen += 1
         assert _rel_l2(drv["gp"][k], lib["gp"][k]) < 5e-2, (k, _rel_l2(drv["gp"][k], lib["gp"][k]))
     assert seen == 8
+
+
+@pytest.mark.parametrize("case", ["no_positive_anchor", "image_without_boxes", "label_out_of_range"])
+def test_edge_cases_follow_the_dense_step(case):
+    """What RetinaNetLoss does at the edges (losses.py:431 raises on an image without boxes -- here: NaN + status bit; no positive anchor:
+    zero loss over max(1, 0); a label >= C: status bit) is the same on the loss-driven route, and every parameter still gets a gradient."""
+    from objectdetectionpl_amd.LightningFunc.utils import sparseconv as sc
+    from objectdetectionpl_amd.model.RetinaNet import RetinaNet
+    torch.manual_seed(0)
+    C, size, B = 4, 320, 2
+    model = _model(C, size)
+    g = torch.Generator().manual_seed(15)
+    x = torch.rand(B, 3, size, size, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    if case == "no_positive_anchor":          # boxes far smaller than the smallest anchor: IoU < 0.4 everywhere
+        y = torch.tensor([[0, 1, 0.5, 0.5, 0.004, 0.004], [1, 2, 0.3, 0.6, 0.003, 0.005]], device=DEV)
+    elif case == "image_without_boxes":
+        y = torch.tensor([[0, 1, 0.5, 0.5, 0.3, 0.3], [0, 2, 0.3, 0.6, 0.2, 0.4]], device=DEV)
+    else:
+        y = torch.tensor([[0, 1, 0.5, 0.5, 0.3, 0.3], [1, 9, 0.3, 0.6, 0.2, 0.4]], device=DEV)
+    old = sc.min_pixels
+    sc.min_pixels = 1000
+    res = []
+    try:
+        for driven in (True, False):
+            RetinaNet.loss_driven_step = driven
+            model.zero_grad(set_to_none=True)
+            assert (model.loss_driven_mask(x, y) != 0) == driven
+            d = model.training_step((x, y), 0)
+            d["loss"].backward()
+            counts = model.criterion.last_counts.cpu().tolist()
+            res.append(({k: float(v.detach()) for k, v in d.items()}, counts, [p.grad is not None for p in model.parameters()]))
+    finally:
+        RetinaNet.loss_driven_step = True
+        sc.min_pixels = old
+    (la, ca, ga), (lb, cb, gb) = res
+    assert ca == cb and ga == gb and all(ga)
+    for k in lb:
+        assert (math.isnan(la[k]) and math.isnan(lb[k])) or abs(la[k] - lb[k]) <= 2e-5 * abs(lb[k]) + 1e-12, (k, la, lb)
+    if case == "no_positive_anchor":
+        assert ca[0] == 0 and la["loss"] == 0.0
+    elif case == "image_without_boxes":
+        assert ca[1] & 1 and math.isnan(la["loss"])
+    else:
+        assert ca[1] & 2
