@@ -239,7 +239,40 @@ class RetinaNet(_Base):
         for l, (h, w) in enumerate(shapes):
             if x.shape[0] * h * w >= _sc.min_pixels and h > 1 and w > 1:
                 mask |= 1 << l
-        return mask
+        return mask & ~self._crowded_levels()
+
+    dense_share = 0.5              # a level whose heads would be evaluated on more than this share of its pixels goes back to the library
+    reprobe_every = 200            # ... and is tried again after this many steps
+
+    def _crowded_levels(self):
+        """Levels the last looks found too crowded for lists to pay (tools/bench_sparse_gemm.py: the gathered GEMM breaks even with the
+        library at about half of the pixels).  The pixel counts are read back WITHOUT a sync: `forward_and_loss` starts a pinned copy
+        of PixelSupport's counters, this looks at it on a later step."""
+        st = self.__dict__.setdefault("_support_stats", {"pending": None, "crowded": 0, "since": 0})
+        if st["pending"] is not None:
+            pinned, ev, pixels, reach, depth = st["pending"]
+            if ev.query():
+                st["pending"] = None
+                crowded = 0
+                for l, n in enumerate(pixels):
+                    if n and int(pinned[l * depth + reach]) > self.dense_share * n:
+                        crowded |= 1 << l
+                if crowded != st["crowded"]:
+                    st["crowded"], st["since"] = crowded, 0
+        if st["crowded"]:
+            st["since"] += 1
+            if st["since"] >= self.reprobe_every:
+                st["crowded"], st["since"] = 0, 0
+        return st["crowded"]
+
+    def _watch_support(self, sup, reach):
+        st = self.__dict__.setdefault("_support_stats", {"pending": None, "crowded": 0, "since": 0})
+        if st["pending"] is None and not torch.cuda.is_current_stream_capturing():
+            pinned = torch.empty(sup.counts.numel(), dtype=torch.int32, pin_memory=True)
+            pinned.copy_(sup.counts, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            st["pending"] = (pinned, ev, [p if sup.has(l) else 0 for l, p in enumerate(sup.pix)], reach, sup.depth)
 
     @staticmethod
     def _level_shapes(x):
@@ -262,6 +295,7 @@ class RetinaNet(_Base):
         n_units = (len(self.loc_head) - 1) // 2
         pos, npos, token = crit.assign(y, x.shape[0])                       # needs anchors and boxes only
         sup = _rh.PixelSupport(pos, npos, x.shape[0], self._level_shapes(x), n_units + 3, mask)      # reach 0 .. n_units + 2
+        self._watch_support(sup, n_units)
         feats = self.fpn(x, sup, n_units + 1) if self.topdown_on_pixels else self.fpn(x)
         ok = [(f.shape[2], f.shape[3]) for f in feats] == self._level_shapes(x) and feats[0].dtype == torch.float32
         for l, f in enumerate(feats):

@@ -640,3 +640,33 @@ def test_edge_cases_follow_the_dense_step(case):
         assert ca[1] & 1 and math.isnan(la["loss"])
     else:
         assert ca[1] & 2
+
+
+def test_a_crowded_level_goes_back_to_the_library_route():
+    """Boxes on every part of the image put most of a level's pixels within reach of a positive anchor: the counters are read back
+    without a sync and the level leaves the mask on a later step (and comes back after `reprobe_every` steps)."""
+    import time
+    from objectdetectionpl_amd.LightningFunc.utils import sparseconv as sc
+    from objectdetectionpl_amd.model.RetinaNet import RetinaNet
+    torch.manual_seed(0)
+    C, size, B = 3, 256, 2
+    model = _model(C, size)
+    g = torch.Generator().manual_seed(16)
+    x = torch.rand(B, 3, size, size, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    n = 40
+    cxy = torch.rand(B * n, 2, generator=g) * 0.8 + 0.1
+    y = torch.cat([torch.arange(B).repeat_interleave(n).float()[:, None], torch.randint(0, C, (B * n, 1), generator=g).float(), cxy,
+                   torch.full((B * n, 2), 0.2)], 1).to(DEV)                       # 51-pixel boxes: P3 / P4 anchors, all over the image
+    old = sc.min_pixels, RetinaNet.reprobe_every
+    sc.min_pixels, RetinaNet.reprobe_every = 500, 3
+    try:
+        assert model.loss_driven_mask(x, y) == 0b00011
+        d = model.training_step((x, y), 0)
+        d["loss"].backward()
+        torch.cuda.synchronize(); time.sleep(0.05)
+        m = model.loss_driven_mask(x, y)
+        assert m != 0b00011 and (m & ~0b00011) == 0                              # at least one of the two levels was found crowded
+        masks = [model.loss_driven_mask(x, y) for _ in range(3)]
+        assert masks[-1] == 0b00011                                              # tried again after reprobe_every looks
+    finally:
+        sc.min_pixels, RetinaNet.reprobe_every = old
