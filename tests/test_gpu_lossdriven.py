@@ -670,3 +670,35 @@ def test_a_crowded_level_goes_back_to_the_library_route():
         assert masks[-1] == 0b00011                                              # tried again after reprobe_every looks
     finally:
         sc.min_pixels, RetinaNet.reprobe_every = old
+
+
+@pytest.mark.parametrize("driven", [True, False])
+def test_overfitting_one_batch_brings_the_loss_down_on_either_route(driven):
+    """system-level sanity: 40 Adam steps on one batch through `training_step` -- the loss has to fall by more than half whichever way the
+    step is computed (and on the loss-driven route the step has to have taken it)"""
+    from objectdetectionpl_amd.LightningFunc.utils import sparseconv as sc
+    from objectdetectionpl_amd.model.RetinaNet import RetinaNet
+    torch.manual_seed(0)
+    C, size, B = 4, 256, 2
+    model = _model(C, size)
+    g = torch.Generator().manual_seed(17)
+    x = torch.rand(B, 3, size, size, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    y = _targets(g, B, 3, C).to(DEV)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    old = sc.min_pixels
+    sc.min_pixels = 500
+    RetinaNet.loss_driven_step = driven
+    try:
+        assert (model.loss_driven_mask(x, y) != 0) == driven
+        losses = []
+        for _ in range(40):
+            opt.zero_grad(set_to_none=True)
+            d = model.training_step((x, y), 0)
+            d["loss"].backward()
+            opt.step()
+            losses.append(float(d["loss"].detach()))
+    finally:
+        RetinaNet.loss_driven_step = True
+        sc.min_pixels = old
+    assert all(math.isfinite(v) for v in losses)
+    assert min(losses[-5:]) < 0.5 * losses[0], (losses[0], losses[-5:])
