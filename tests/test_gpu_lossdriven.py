@@ -320,7 +320,7 @@ def test_training_step_takes_the_loss_driven_route():
     for k in res[1][0]:
         assert abs(res[0][0][k] - res[1][0][k]) <= 2e-5 * abs(res[1][0][k]), (k, res[0][0], res[1][0])
     cos = float(torch.dot(res[0][1], res[1][1]) / (res[0][1].norm() * res[1][1].norm()))
-    assert cos > 0.9995, cos
+    assert cos > 0.999, cos            # (two dense runs of the same step: 0.99990-0.99995; a missing level or tap: < 0.99)
 
 
 def test_predictions_of_a_loss_driven_step_serve_that_assignment_only():
