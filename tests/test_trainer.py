@@ -227,3 +227,17 @@ def test_forward_via_offers_a_folded_step_to_the_bucketed_wrapper_only():
     class Plain:
         pass
     assert _ForwardVia(Plain(), host).forward_and_loss is None
+
+
+def test_benchmark_flag_turns_the_solver_search_on():
+    """PL's Trainer(benchmark=True) == torch.backends.cudnn.benchmark (MIOpen's solver search on ROCm); the default leaves it alone"""
+    import torch
+    from objectdetectionpl_amd.trainer import Trainer
+    old = torch.backends.cudnn.benchmark
+    try:
+        torch.backends.cudnn.benchmark = False
+        Trainer(max_epochs=1, device="cpu")
+        assert torch.backends.cudnn.benchmark is False
+        assert Trainer(max_epochs=1, device="cpu", benchmark=True).benchmark and torch.backends.cudnn.benchmark is True
+    finally:
+        torch.backends.cudnn.benchmark = old
