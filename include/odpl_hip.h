@@ -644,6 +644,14 @@ int odpl_bn_add_act_forward(const float* x, const float* residual, int64_t R, in
                             float* running_mean, float* running_var, int32_t training, float momentum, float eps,
                             int32_t act, float* save_mean, float* save_invstd, float* y, void* workspace,
                             size_t workspace_bytes, int64_t* num_batches_tracked, void* stream);
+/* ... and its backward: the derivative of the activation is taken from the saved OUTPUT y (relu / leaky: sign of y == sign of the
+ * pre-activation; linear: none); grad_residual = grad_y * act'(y) is d loss / d residual (written by the reduce pass, which sums it in the
+ * same sweep); then finalize and the dx pass -- `aten::threshold_backward` + the BN backward of the reference's autograd graph in three
+ * launches instead of four, seven passes over the map instead of eight.  fp32, channels-last [R, C]; workspace: odpl_bn_act_workspace_bytes. */
+int odpl_bn_add_act_backward(const float* x, const float* y, const float* grad_y, int64_t R, int32_t C, const float* gamma,
+                             const float* beta, const float* save_mean, const float* save_invstd, int32_t training, int32_t act,
+                             float* grad_x, float* grad_residual, float* grad_gamma, float* grad_beta,
+                             void* workspace, size_t workspace_bytes, void* stream);
 int odpl_bn_act_backward(const float* x, const float* grad_y, int64_t R, int32_t C, const float* gamma, const float* beta,
                          const float* save_mean, const float* save_invstd, int32_t training, int32_t act,
                          float* grad_x, float* grad_gamma, float* grad_beta, void* workspace, size_t workspace_bytes,

@@ -145,22 +145,17 @@ class _BnAddActFn(torch.autograd.Function):
         R = N * H * W
         dev = x.device
         L = _lib.lib()
-        if ctx.act == ACT["relu"]:
-            gu = torch.ops.aten.threshold_backward(gy, y, 0)
-        elif ctx.act == ACT["linear"]:
-            gu = gy
-        else:
-            gu = torch.where(y > 0, gy, 0.1 * gy)                  # leaky: the sign of y is the sign of the pre-activation
-        if not gu.is_contiguous(memory_format=torch.channels_last) or gu.dtype != torch.float32:
-            gu = gu.float().contiguous(memory_format=torch.channels_last)
+        if gy.dtype != torch.float32 or not gy.is_contiguous(memory_format=torch.channels_last):
+            gy = gy.float().contiguous(memory_format=torch.channels_last)
+        gu = torch.empty_like(x)                                   # d loss / d s = gy * act'(y): written by the reduce pass, read by the dx pass
         gx = torch.empty_like(x)
         dg = torch.empty(C, dtype=torch.float32, device=dev)
         db = torch.empty(C, dtype=torch.float32, device=dev)
         need = L.odpl_bn_act_workspace_bytes(R, C)
         ws = _workspace(dev, need)
-        _lib.check(L.odpl_bn_act_backward(_lib.ptr(x), _lib.ptr(gu), R, C, _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(mean), _lib.ptr(invstd),
-                                          1 if ctx.training else 0, ACT["linear"], _lib.ptr(gx), _lib.ptr(dg), _lib.ptr(db), _lib.ptr(ws),
-                                          ws.numel(), _lib.current_stream(dev)), "odpl_bn_act_backward")
+        _lib.check(L.odpl_bn_add_act_backward(_lib.ptr(x), _lib.ptr(y), _lib.ptr(gy), R, C, _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(mean),
+                                              _lib.ptr(invstd), 1 if ctx.training else 0, ctx.act, _lib.ptr(gx), _lib.ptr(gu), _lib.ptr(dg),
+                                              _lib.ptr(db), _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)), "odpl_bn_add_act_backward")
         return gx, gu, dg, db, None, None, None, None, None, None, None
 
 

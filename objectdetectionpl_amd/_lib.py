@@ -214,6 +214,8 @@ SIGNATURES = {
                                                c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "odpl_bn_add_act_forward": (c_int32, [c_void_p, c_void_p, ctypes.c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_float, c_float,
                                           c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "odpl_bn_add_act_backward": (c_int32, [c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
+                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "odpl_bn_act_forward_strided": (c_int32, [c_void_p, c_void_p, c_int32, ctypes.c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_float, c_float,
                                               c_int32, c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_void_p, c_size_t, c_void_p, c_void_p]),
     "odpl_bn_act_backward_strided": (c_int32, [c_void_p, c_void_p, ctypes.c_int64, c_int32, ctypes.c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,

@@ -59,6 +59,7 @@ struct BnParams {
     unsigned* sync;                              // one-launch path: [nslices][2] arrival / departure counters (library-owned, zero at rest)
     unsigned timeout_ticks;                      // one-launch path: bound of the wait for the slice's other workgroups, 100 MHz ticks
     unsigned long long* stamp;                   // diagnostic (odpl_bn_fused_debug_stamps): 8 readings of the 100 MHz clock per workgroup, or null
+    void* gu;                                    // bn_add_act backward: grad_y masked by the activation's derivative AT THE SAVED OUTPUT y (written by the reduce pass)
     unsigned char* flags;                        // bias_act_bwd: [R] bytes, set to 1 where the row of grad_x has a non-zero (pre-zeroed), or null
 };
 

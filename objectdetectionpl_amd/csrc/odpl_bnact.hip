@@ -32,7 +32,10 @@ namespace {
 // K rows per lane are requested before any is consumed (forward: 8 x 16 B, backward: 4 x (x, gy)); the loads are unconditional
 // -- rows past the end of the tile are clamped to its last row and ignored by the arithmetic -- so a ragged tile costs no extra
 // trip to memory (a tile of 43 rows over 4 row lanes used to take 2 trips of four rows and 3 of one).
-template <bool BWD, bool BF, int ACT>
+// MASKY (backward of act(bn(x) + s), fp32): the activation's derivative is taken from the SAVED OUTPUT y (relu / leaky: the sign of y is
+// the sign of the pre-activation), the masked gradient gu = grad_y * act'(y) is WRITTEN here (it is d loss / d s, and what the dx pass
+// reads) and the sums are those of a linear epilogue on gu -- the separate threshold_backward pass and its launch are gone.
+template <bool BWD, bool BF, int ACT, bool MASKY = false>
 __global__ __launch_bounds__(kT) void bn_reduce_kernel(const BnParams P) {
     constexpr int K = BWD ? 4 : 8;
     constexpr unsigned QB = BF ? 8u : 16u;
@@ -50,6 +53,8 @@ __global__ __launch_bounds__(kT) void bn_reduce_kernel(const BnParams P) {
     const int lane_rows = (nrows + rows_par - 1) / rows_par;
     const char* bx = reinterpret_cast<const char*>(P.x) + (size_t)r0 * c4n * QB;
     const char* bg = BWD ? reinterpret_cast<const char*>(P.gy) + (size_t)r0 * (size_t)P.gy_rs4 * QB : nullptr;
+    const char* by = MASKY ? reinterpret_cast<const char*>(P.y) + (size_t)r0 * c4n * QB : nullptr;
+    char* bu = MASKY ? reinterpret_cast<char*>(P.gu) + (size_t)r0 * c4n * QB : nullptr;
     const unsigned xs = (unsigned)c4n * QB, gs = (unsigned)P.gy_rs4 * QB;      // row strides in bytes (a tile spans < 2^31 bytes: plan())
     for (int q0 = sq0; q0 < sq1; q0 += tpr) {               // slices wider than the workgroup (C > 1024 unsliced): several channel passes
         const int q = q0 + tc;
@@ -67,23 +72,32 @@ __global__ __launch_bounds__(kT) void bn_reduce_kernel(const BnParams P) {
                 b[0] = fma((double)v.x, (double)v.x, b[0]); b[1] = fma((double)v.y, (double)v.y, b[1]); b[2] = fma((double)v.z, (double)v.z, b[2]); b[3] = fma((double)v.w, (double)v.w, b[3]);
             } else {
                 const float xh0 = (v.x - mu.x) * is.x, xh1 = (v.y - mu.y) * is.y, xh2 = (v.z - mu.z) * is.z, xh3 = (v.w - mu.w) * is.w;
-                const float g0 = g.x * act_grad<ACT>(ga.x * xh0 + be.x), g1 = g.y * act_grad<ACT>(ga.y * xh1 + be.y);
-                const float g2 = g.z * act_grad<ACT>(ga.z * xh2 + be.z), g3 = g.w * act_grad<ACT>(ga.w * xh3 + be.w);
+                const float g0 = MASKY ? g.x : g.x * act_grad<ACT>(ga.x * xh0 + be.x), g1 = MASKY ? g.y : g.y * act_grad<ACT>(ga.y * xh1 + be.y);
+                const float g2 = MASKY ? g.z : g.z * act_grad<ACT>(ga.z * xh2 + be.z), g3 = MASKY ? g.w : g.w * act_grad<ACT>(ga.w * xh3 + be.w);
                 a[0] += g0; a[1] += g1; a[2] += g2; a[3] += g3;
                 b[0] = fma((double)g0, (double)xh0, b[0]); b[1] = fma((double)g1, (double)xh1, b[1]); b[2] = fma((double)g2, (double)xh2, b[2]); b[3] = fma((double)g3, (double)xh3, b[3]);
             }
         };
         for (int k0 = 0; k0 < lane_rows; k0 += K) {         // rows trc + k * rows_par, k ascending: the same order as ever
-            float4 v[K], g[K];
+            float4 v[K], g[K], yv[MASKY ? K : 1];
 #pragma unroll
             for (int u = 0; u < K; ++u) {
                 int r = trc + (k0 + u) * rows_par; if (r > nrows - 1) r = nrows - 1;
                 v[u] = ld_quad_at<BF>(bx, (unsigned)r * xs + (unsigned)qc * QB);
                 if (BWD) g[u] = ld_quad_at<BF>(bg, (unsigned)r * gs + (unsigned)qc * QB); else g[u] = v[u];
+                if (MASKY) yv[u] = ld_quad_at<BF>(by, (unsigned)r * xs + (unsigned)qc * QB);
             }
 #pragma unroll
             for (int u = 0; u < K; ++u)
-                if (mine && trc + (k0 + u) * rows_par < nrows) body(v[u], g[u]);
+                if (mine && trc + (k0 + u) * rows_par < nrows) {
+                    if (MASKY) {
+                        const float neg = ACT == ODPL_ACT_LEAKY ? 0.1f : 0.0f;           // (ACT names the activation of y here; the sums are linear in gu)
+                        g[u].x = yv[u].x > 0.f ? g[u].x : neg * g[u].x; g[u].y = yv[u].y > 0.f ? g[u].y : neg * g[u].y;
+                        g[u].z = yv[u].z > 0.f ? g[u].z : neg * g[u].z; g[u].w = yv[u].w > 0.f ? g[u].w : neg * g[u].w;
+                        *reinterpret_cast<float4*>(bu + (size_t)(unsigned)(trc + (k0 + u) * rows_par) * xs + (unsigned)q * QB) = g[u];
+                    }
+                    body(v[u], g[u]);
+                }
         }
         // combine the rows_par row-lanes through LDS (fixed order), write the workgroup partial
         __syncthreads();
@@ -530,6 +544,45 @@ extern "C" int odpl_bn_act_backward_strided(const void* x, const void* grad_y, i
     { const long long cap = odpl::g_bn_stream_max_blocks > 0 ? odpl::g_bn_stream_max_blocks : (n4 >= (8LL << 20) ? 16384 : 4096); if (blocks > cap) blocks = cap; }
     if (bf16) { ODPL_BN_LAUNCH(bn_bwd_dx_kernel, true, dim3((unsigned)blocks), 0, stream, P) }
     else { ODPL_BN_LAUNCH(bn_bwd_dx_kernel, false, dim3((unsigned)blocks), 0, stream, P) }
+    ODPL_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// Backward of y = act(bn(x) + s) (odpl_bn_add_act_forward; ResNet's bottleneck tail, model/backbone/RetinaNetbone.py:27-30): the reduce
+// pass masks grad_y by act'(y) from the saved output, writes that as d loss / d s and sums it; finalize; the dx pass of a linear epilogue.
+extern "C" int odpl_bn_add_act_backward(const float* x, const float* y, const float* grad_y, int64_t R, int32_t C, const float* gamma,
+                                        const float* beta, const float* save_mean, const float* save_invstd, int32_t training, int32_t act,
+                                        float* grad_x, float* grad_residual, float* grad_gamma, float* grad_beta,
+                                        void* workspace, size_t workspace_bytes, void* stream_) {
+    RPlan pl;
+    if (!x || !y || !grad_y || !grad_x || !grad_residual || !gamma || !beta || !save_mean || !save_invstd || !grad_gamma || !grad_beta ||
+        !plan(R, C, &pl)) return ODPL_EINVAL;
+    if (act != ODPL_ACT_RELU && act != ODPL_ACT_LEAKY && act != ODPL_ACT_LINEAR) return ODPL_EINVAL;   // (mish: its derivative is no function of y)
+    if (!workspace || workspace_bytes < odpl_bn_act_workspace_bytes(R, C)) return ODPL_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)grad_y | (uintptr_t)grad_x | (uintptr_t)grad_residual | (uintptr_t)grad_gamma |
+         (uintptr_t)grad_beta | (uintptr_t)workspace) & 15) return ODPL_EINVAL;
+    if (act == ODPL_ACT_LINEAR) {                                                // nothing to mask: d loss / d s IS grad_y
+        ODPL_HIP_TRY(hipMemcpyAsync(grad_residual, grad_y, (size_t)R * C * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream_));
+        return odpl_bn_act_backward_strided(x, grad_y, C, 0, R, C, gamma, beta, save_mean, save_invstd, training, ODPL_ACT_LINEAR, grad_x,
+                                            grad_gamma, grad_beta, workspace, workspace_bytes, stream_);
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    BnParams P = {};
+    P.x = x; P.gy = grad_y; P.y = (void*)y; P.gu = grad_residual; P.gx = grad_x; P.gamma = gamma; P.beta = beta;
+    P.mean = (float*)save_mean; P.invstd = (float*)save_invstd;
+    P.R = R; P.C = C; P.act = ODPL_ACT_LINEAR; P.nblk = pl.nblk; P.rows_per_blk = pl.rows_per_blk; P.slice_q = pl.slice_q; P.training = training;
+    P.part = (double*)workspace; P.y_rs4 = C >> 2; P.gy_rs4 = C >> 2;
+    P.dgamma = grad_gamma; P.dbeta = grad_beta;
+    if (act == ODPL_ACT_RELU) hipLaunchKernelGGL((bn_reduce_kernel<true, false, ODPL_ACT_RELU, true>), dim3(pl.nblk, pl.nslices), dim3(kT), pl.lds, stream, P);
+    else hipLaunchKernelGGL((bn_reduce_kernel<true, false, ODPL_ACT_LEAKY, true>), dim3(pl.nblk, pl.nslices), dim3(kT), pl.lds, stream, P);
+    ODPL_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(kT), 0, stream, P);
+    ODPL_HIP_TRY(hipGetLastError());
+    P.gy = grad_residual;                                                        // the dx pass reads the masked gradient
+    const long long n4 = R * (C >> 2);
+    long long blocks = (n4 + kT - 1) / kT;
+    { const long long cap = odpl::g_bn_stream_max_blocks > 0 ? odpl::g_bn_stream_max_blocks : (n4 >= (8LL << 20) ? 16384 : 4096); if (blocks > cap) blocks = cap; }
+    hipLaunchKernelGGL((bn_bwd_dx_kernel<false, ODPL_ACT_LINEAR>), dim3((unsigned)blocks), dim3(kT), 0, stream, P);
     ODPL_HIP_TRY(hipGetLastError());
     return 0;
 }

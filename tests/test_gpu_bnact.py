@@ -345,3 +345,33 @@ def test_bn_act_of_cat_single_module(training, dtype):
     st = dict(rtol=1e-5, atol=1e-6) if dtype == torch.float32 else dict(rtol=1e-2, atol=1e-2)
     assert torch.allclose(m1.running_mean, m2.running_mean, **st) and torch.allclose(m1.running_var, m2.running_var, **st)
     assert int(m1.num_batches_tracked) == int(m2.num_batches_tracked)
+
+
+@pytest.mark.parametrize("act", ["relu", "leaky", "linear"])
+@pytest.mark.parametrize("shape", [(2, 64, 9, 7), (3, 256, 12, 12), (2, 1024, 5, 6), (1, 2048, 3, 3)])
+def test_bn_add_act_backward_masks_in_the_reduce_pass(shape, act):
+    """`odpl_bn_add_act_backward`: act'(y) from the saved output inside the reduce pass (no separate threshold launch) -- every activation
+    it serves, unsliced and channel-sliced reduce grids, against torch's graph; the two gradients are exactly consistent with each other
+    (d loss / d s is what the dx pass read)."""
+    from objectdetectionpl_amd.LightningFunc.utils.bnact import bn_add_act
+    DEV = "cuda:0"
+    g = torch.Generator().manual_seed(3)
+    N, C, H, W = shape
+    x = torch.randn(N, H, W, C, generator=g).to(DEV).permute(0, 3, 1, 2)
+    s = torch.randn(N, H, W, C, generator=g).to(DEV).permute(0, 3, 1, 2)
+    gy = torch.randn(N, H, W, C, generator=g).to(DEV).permute(0, 3, 1, 2)
+    b0, b1 = nn.BatchNorm2d(C).to(DEV), nn.BatchNorm2d(C).to(DEV)
+    with torch.no_grad():
+        b0.weight.copy_(torch.rand(C, generator=g) + 0.5); b0.bias.copy_(torch.randn(C, generator=g) * 0.2)
+    b1.load_state_dict(b0.state_dict())
+    fn = {"relu": torch.relu, "leaky": lambda t: F.leaky_relu(t, 0.1), "linear": lambda t: t}[act]
+    x0, s0 = x.clone().requires_grad_(), s.clone().requires_grad_()
+    x1, s1 = x.clone().requires_grad_(), s.clone().requires_grad_()
+    y0 = fn(b0(x0) + s0)
+    y1 = bn_add_act(x1, b1, s1, act)
+    assert torch.allclose(y0, y1, rtol=1e-5, atol=1e-5)
+    y0.backward(gy); y1.backward(gy)
+    assert torch.allclose(s0.grad, s1.grad, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(x0.grad, x1.grad, rtol=2e-4, atol=2e-5 * float(x0.grad.abs().max()))
+    assert torch.allclose(b0.weight.grad, b1.weight.grad, rtol=2e-4, atol=1e-4 * float(b0.weight.grad.abs().max()))
+    assert torch.allclose(b0.bias.grad, b1.bias.grad, rtol=2e-4, atol=1e-4 * float(b0.bias.grad.abs().max()))
