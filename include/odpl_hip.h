@@ -27,10 +27,12 @@
 extern "C" {
 #endif
 
-#define ODPL_ABI_VERSION 5   /* 3: memory-format strides + compact (structured) gradients on the YOLO losses, head-conv backward from them;
+#define ODPL_ABI_VERSION 6   /* 3: memory-format strides + compact (structured) gradients on the YOLO losses, head-conv backward from them;
                               * 4: odpl_retina_loss_desc_t grew pos_anchor / num_pos (ODPL_RETINA_ROWS_ONLY), odpl_retina_heads_backward
                               * 5: odpl_sparse_conv3x3_t grew stats; ODPL_RETINA_ASSIGN_ONLY / _ASSIGNED, odpl_pixel_support, odpl_sparse_conv3x3_forward,
-                              *    ksize on both sparse-convolution descriptors, odpl_pixel_union_lists, odpl_sparse_upsample_add */
+                              *    ksize on both sparse-convolution descriptors, odpl_pixel_union_lists, odpl_sparse_upsample_add
+                              * 6: the two probes left the library (tools/probes/: odpl_conv1x1_*, odpl_bn_fused_*, ODPL_TUNE_BN_FUSED*);
+                              */
 #define ODPL_EINVAL (-1)
 #define ODPL_MAX_SCALES 4
 #define ODPL_MAX_ANCHORS 8
@@ -672,12 +674,6 @@ int odpl_bn_act_backward_strided(const void* x, const void* grad_y, int64_t gy_r
                                  int32_t training, int32_t act, void* grad_x, float* grad_gamma, float* grad_beta,
                                  void* workspace, size_t workspace_bytes, void* stream);
 
-/* ---- PROBE (not used by the models: ties MIOpen, see csrc/odpl_gemm1x1.hip): 1x1 stride-1 convolutions on channels-last fp32 tensors as
- * GEMMs on the fp32 matrix cores.  The Conv2d(Cin, Cout, 1) layers of the caller networks (utils/YoloV4Utils.py:208-236 Conv_Bn_Activation with kernel_size 1): x [M = N*H*W, Cin],
- * w [Cout, Cin] (a 1x1 weight in either memory format), y [M, Cout].  tile: 0 = by shape, 64 or 128. */
-int odpl_conv1x1_forward(const float* x, const float* w, float* y, int64_t M, int32_t Cin, int32_t Cout, int32_t tile, void* stream);
-int odpl_conv1x1_backward_data(const float* dy, const float* w, float* dx, int64_t M, int32_t Cin, int32_t Cout, int32_t tile, void* stream);
-
 /* launch-geometry knobs (process-wide; defaults are the tuned values) */
 #define ODPL_TUNE_YOLO_FILL_F4_PER_BLOCK 0
 #define ODPL_TUNE_YOLO_FILL_NT 1
@@ -686,20 +682,7 @@ int odpl_conv1x1_backward_data(const float* dy, const float* w, float* dx, int64
 #define ODPL_TUNE_BN_STREAM_MAX_BLOCKS 4  /* grid cap of the BN apply / dx streams (0 = by size: 4096 / 16384) */
 #define ODPL_TUNE_BN_MAX_ROWS_PER_TILE 5  /* rows per reduce tile at most (default 2048) */
 #define ODPL_TUNE_BN_SLICE_FROM_C 6       /* BN reduce passes cut rows into 16-quad channel slices from this C on (default 256) */
-#define ODPL_TUNE_BN_FUSED 7             /* 1: BatchNorm(train) + activation in ONE launch per direction for the maps the chip holds in registers
-                                           * (odpl_bnfused.hip); 0 (default: the one-launch form measured slower, see that file): always statistics /
-                                           * finalize / apply as three launches */
-#define ODPL_TUNE_BN_FUSED_TIMEOUT_US 8  /* bound of the in-launch wait for a channel slice's other workgroups (default 20000); a workgroup
-                                           * whose peers are late computes the slice's statistics itself (same bits); 0 = never wait (tests) */
 int odpl_tune_set(int32_t key, int32_t value);
-/* diagnostic (synchronises): out[0] = launches of the one-launch BatchNorm path since the library was loaded, out[1] = workgroups among
- * them that did not wait for their peers (self-service) */
-int odpl_bn_fused_stats(int32_t* out2);
-/* diagnostic: on != 0 makes later one-launch BatchNorm launches record 8 readings of the 100 MHz clock per workgroup (start, sums done,
- * partials drained, peers seen, acquired, statistics done, stores issued, unused); out (HOST, n_wg * 8 uint64, may be NULL) receives the
- * last launch's readings (synchronises) */
-int odpl_bn_fused_debug_stamps(int32_t on, uint64_t* out, int32_t n_wg);
-
 /* diagnostic: when non-NULL, every workgroup w of yolo_expand_kernel stores its start / end reading of the
  * constant 100 MHz counter into dev_u64[2w], dev_u64[2w+1] (buffer >= 2 * grid entries); NULL disables it. */
 int odpl_debug_set_stamp_buffer(void* dev_u64);

@@ -119,7 +119,7 @@ class _ConvBiasActSparse(torch.autograd.Function):
         nbytes = L.odpl_sparse_conv3x3_backward_workspace_bytes(ctypes.byref(d))
         if nbytes == 0:
             raise _lib.OdplError("odpl_sparse_conv3x3_backward_workspace_bytes rejected the descriptor")
-        key = (dev, "sc")
+        key = (dev, st.value, "sc")         # per stream: partials written by one launch are read by the next on the SAME stream
         ws2 = _ws2.get(key)
         if ws2 is None or ws2.numel() < nbytes:
             ws2 = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=dev)
@@ -157,12 +157,12 @@ def forward_on_pixels(x, w, b, act, support, out=None, out_strides=None):
     d.y_batch_stride, d.y_pixel_stride = out_strides
     d.list, d.count = support[0].data_ptr(), support[1].data_ptr()
     d.B, d.H, d.W, d.Cin, d.Cout, d.act, d.ksize = N, H, W, Cin, C, act, w.shape[2]
-    ws = _ws2.get((x.device, "fwd"))
+    st = _lib.current_stream(x.device)
+    ws = _ws2.get((x.device, st.value, "fwd"))
     if ws is None:
-        ws = torch.empty(32 << 20, dtype=torch.uint8, device=x.device)           # split-K partials of short lists (stream-ordered reuse)
-        _ws2[(x.device, "fwd")] = ws
-    _lib.check(_lib.lib().odpl_sparse_conv3x3_forward(ctypes.byref(d), _lib.ptr(ws), ws.numel(), _lib.current_stream(x.device)),
-               "odpl_sparse_conv3x3_forward")
+        ws = torch.empty(32 << 20, dtype=torch.uint8, device=x.device)           # split-K partials of short lists (stream-ordered reuse:
+        _ws2[(x.device, st.value, "fwd")] = ws                                         # one buffer per stream, two streams never share one)
+    _lib.check(_lib.lib().odpl_sparse_conv3x3_forward(ctypes.byref(d), _lib.ptr(ws), ws.numel(), st), "odpl_sparse_conv3x3_forward")
     return out
 
 

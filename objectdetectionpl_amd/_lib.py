@@ -6,7 +6,7 @@ from ctypes import POINTER, c_float, c_int32, c_size_t, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libodpl_hip.so")
 
-ABI_VERSION = 5            # include/odpl_hip.h: ODPL_ABI_VERSION
+ABI_VERSION = 6            # include/odpl_hip.h: ODPL_ABI_VERSION
 LAYOUT_PLANAR, LAYOUT_INTERLEAVED = 0, 1
 MAX_SCALES = 4
 MAX_ANCHORS = 8
@@ -223,10 +223,6 @@ SIGNATURES = {
     "odpl_bn_act_backward": (c_int32, [c_void_p, c_void_p, ctypes.c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "odpl_tune_set": (c_int32, [c_int32, c_int32]),
-    "odpl_conv1x1_forward": (c_int32, [c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_int32, c_int32, c_int32, c_void_p]),
-    "odpl_conv1x1_backward_data": (c_int32, [c_void_p, c_void_p, c_void_p, ctypes.c_int64, c_int32, c_int32, c_int32, c_void_p]),
-    "odpl_bn_fused_stats": (c_int32, [POINTER(c_int32)]),
-    "odpl_bn_fused_debug_stamps": (c_int32, [c_int32, c_void_p, c_int32]),
     "odpl_scale_inplace_if_not_one_bf16": (c_int32, [c_void_p, c_size_t, c_void_p, c_void_p]),
     "odpl_profile_enable": (c_int32, [c_int32, c_int32]),
     "odpl_profile_collect": (c_int32, [c_int32, POINTER(c_float), POINTER(c_float), c_int32]),
@@ -287,8 +283,7 @@ RETINA_ASSIGN_ONLY = 4
 RETINA_ASSIGNED = 8
 YOLOV5_STATE_CLEAN = 1
 IOU_MODES = {"iou": 0, "giou": 1, "diou": 2, "ciou": 3}
-TUNE_KEYS = {"yolo_fill_f4_per_block": 0, "yolo_fill_nt": 1, "retina_fill_nt": 2, "bn_target_blocks": 3, "bn_stream_max_blocks": 4, "bn_max_rows_per_tile": 5, "bn_slice_from_c": 6, "bn_fused": 7,
-             "bn_fused_timeout_us": 8}
+TUNE_KEYS = {"yolo_fill_f4_per_block": 0, "yolo_fill_nt": 1, "retina_fill_nt": 2, "bn_target_blocks": 3, "bn_stream_max_blocks": 4, "bn_max_rows_per_tile": 5, "bn_slice_from_c": 6}
 
 
 def tune_set(name, value):
@@ -297,13 +292,6 @@ def tune_set(name, value):
 
 PROF_IDS = {"yolo_expand": 0, "yolo_assign": 1, "yolo_loss": 2, "yolo_finalize": 3, "retina_assign": 4, "retina_main": 5,
             "yolo_nms_prep": 6, "yolo_nms_image": 7, "greedy_nms_prep": 8, "greedy_nms_image": 9, "yolo_decode": 10, "yolov5_dense": 11, "headgrad_stream": 12, "headgrad_finish": 13, "yolo_patch": 14, "yolov5_obj": 15}
-
-
-def bn_fused_stats():
-    """(launches of the one-launch BatchNorm path, workgroups that took its self-service path) since the library was loaded"""
-    out = (c_int32 * 2)()
-    check(lib().odpl_bn_fused_stats(out), "odpl_bn_fused_stats")
-    return int(out[0]), int(out[1])
 
 
 def profile_enable(name, on=True):

@@ -1,5 +1,4 @@
-// Device pieces shared by the BatchNorm + activation epilogues: odpl_bnact.hip (three launches per direction) and
-// odpl_bnfused.hip (one launch per direction for the maps the chip can hold in registers).
+// Device pieces of the BatchNorm + activation epilogues (odpl_bnact.hip).
 #pragma once
 #include "odpl_common.hpp"
 #include "../../include/odpl_hip.h"
@@ -56,9 +55,6 @@ struct BnParams {
     int slice_q;                                 // channel quads per workgroup of the reduce passes (grid.y slices of the row), or C/4
     long long y_rs4, gy_rs4;                     // row strides of y / grad_y in float4 units (== C/4 when dense)
     float eps, momentum;
-    unsigned* sync;                              // one-launch path: [nslices][2] arrival / departure counters (library-owned, zero at rest)
-    unsigned timeout_ticks;                      // one-launch path: bound of the wait for the slice's other workgroups, 100 MHz ticks
-    unsigned long long* stamp;                   // diagnostic (odpl_bn_fused_debug_stamps): 8 readings of the 100 MHz clock per workgroup, or null
     void* gu;                                    // bn_add_act backward: grad_y masked by the activation's derivative AT THE SAVED OUTPUT y (written by the reduce pass)
     unsigned char* flags;                        // bias_act_bwd: [R] bytes, set to 1 where the row of grad_x has a non-zero (pre-zeroed), or null
 };
@@ -71,15 +67,5 @@ __device__ __forceinline__ float4 ld_quad_at(const char* base, unsigned byte_off
     const uint2 u = *reinterpret_cast<const uint2*>(base + byte_off);
     return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
 }
-
-// ---- one-launch path (odpl_bnfused.hip) ------------------------------------------------------------------------------------
-struct BnFusedPlan { int s, kr, T, nslices, rpb; size_t lds; };
-// false: the map does not qualify (too large to hold on chip, too few channels, ...) -> the three-launch path
-bool bn_fused_plan(long long R, int C, bool bf16, bool bwd, BnFusedPlan* p);
-size_t bn_fused_workspace_bytes(long long R, int C);
-// 0 = launched; 1 = declined (grid larger than what is resident at once on this device) -> the caller takes the three-launch path
-int bn_fused_launch(const BnParams& P, const BnFusedPlan& pl, bool bwd, bool bf16, hipStream_t stream);
-extern int g_bn_fused;                  // odpl_tune_set(ODPL_TUNE_BN_FUSED): 0 = always three launches
-extern int g_bn_fused_timeout_us;       // bounded wait for the other workgroups of a channel slice (then: self-service)
 
 }  // namespace odpl

@@ -489,7 +489,12 @@ extern "C" int odpl_retina_heads_backward(const odpl_retina_heads_desc_t* d, int
     hipLaunchKernelGGL(rh_map_kernel, dim3(256), dim3(kT), 0, stream, P);
     ODPL_HIP_TRY(hipGetLastError());
     if (want_x) {
-        static size_t lds_allowed = 64 * 1024;
+        static size_t lds_allowed_dev[16] = {};              // hipFuncSetAttribute is per device
+        int dev_id = 0;
+        ODPL_HIP_TRY(hipGetDevice(&dev_id));
+        if (dev_id < 0 || dev_id >= 16) return ODPL_EINVAL;
+        size_t& lds_allowed = lds_allowed_dev[dev_id];
+        if (lds_allowed == 0) lds_allowed = 64 * 1024;
         for (int i = 0; i < n; ++i) {
             if (!P.h[i].gx[0]) continue;
             const int slab = P.h[i].no < kSlabRows ? P.h[i].no : kSlabRows;

@@ -87,8 +87,17 @@ class FPN(nn.Module):
         pixels of a positive anchor only (on the levels the support lists), so the top-down path is evaluated there only: p_l on
         N_l = reach(l) united with what the finer level's merge interpolates from, the merged map one pixel further out (the
         smoothing convolution's reads), the lateral 1 x 1 convolution where the merge is."""
+        return self.top_down(*self.bottom_up(x), support=support, reach=reach)
+
+    def bottom_up(self, x):
+        """The ResNet stages (every BatchNorm of the network lives here): c3, c4, c5."""
         c1 = F.max_pool2d(_bn(self.conv1(x), self.bn1, "relu"), 3, 2, 1)
         c2 = self.layer1(c1); c3 = self.layer2(c2); c4 = self.layer3(c3); c5 = self.layer4(c4)
+        return c3, c4, c5
+
+    def top_down(self, c3, c4, c5, support=None, reach=0):
+        """p3 .. p7 from the stage outputs (RetinaNetbone.py:55-75); no BatchNorm, so evaluating it twice on the same stage outputs
+        changes no buffer."""
         p6 = self.conv6(c5)
         p7 = self.conv7(F.relu(p6))
         p5 = self.latlayer1(c5)
@@ -280,13 +289,15 @@ class RetinaNet(_Base):
         H, W = x.shape[2], x.shape[3]
         return [(-(-H // 2 ** (3 + l)), -(-W // 2 ** (3 + l))) for l in range(5)]
 
-    def forward_and_loss(self, x, y):
+    def forward_and_loss(self, x, y, mask=None):
         """`criterion(forward(x), y)` (step.py:17-18) for a training step, or None when the step has to be forward + criterion
-        (`loss_driven_mask`; nothing has run then).  RetinaNetLoss reads the positive anchor rows of the predictions and nothing else
+        (`loss_driven_mask`; nothing has run then; once the route is taken the backbone runs exactly once, whatever the FPN then
+        turns out to deliver).  RetinaNetLoss reads the positive anchor rows of the predictions and nothing else
         (losses.py:336-339, 458-461), and which rows those are depends on anchors and boxes only: the assignment runs first and the
         heads are evaluated where the loss will look (csrc/odpl_sparsefwd.hip) -- same loss, same gradients, the predictions of the
         other rows are never formed."""
-        mask = self.loss_driven_mask(x, y)
+        if mask is None:                             # (a data-parallel caller decides once per step and passes its decision: trainer._ForwardVia)
+            mask = self.loss_driven_mask(x, y)
         if not mask:
             return None
         if self.iou_boxes is None or self.iou_boxes.device != x.device:
@@ -296,14 +307,15 @@ class RetinaNet(_Base):
         pos, npos, token = crit.assign(y, x.shape[0])                       # needs anchors and boxes only
         sup = _rh.PixelSupport(pos, npos, x.shape[0], self._level_shapes(x), n_units + 3, mask)      # reach 0 .. n_units + 2
         self._watch_support(sup, n_units)
-        feats = self.fpn(x, sup, n_units + 1) if self.topdown_on_pixels else self.fpn(x)
+        stages = self.fpn.bottom_up(x)
+        feats = self.fpn.top_down(*stages, support=sup, reach=n_units + 1) if self.topdown_on_pixels else self.fpn.top_down(*stages)
         ok = [(f.shape[2], f.shape[3]) for f in feats] == self._level_shapes(x) and feats[0].dtype == torch.float32
         for l, f in enumerate(feats):
             if (mask >> l) & 1 and not (_sc._applicable(f, self.loc_head[0]) and _sc._applicable(f, self.cls_head[0])):
                 ok = False
-        if not ok:                                   # (an FPN that does not produce what the shapes promised)
-            crit._assignment = None
-            return crit(self._heads(x, self.fpn(x)), y)
+        if not ok:                                   # (an FPN that does not produce what the shapes promised): the dense heads on the SAME
+            crit._assignment = None                  # stage outputs -- the ResNet (and with it every BatchNorm buffer update) runs once per step
+            return crit(self._heads(x, self.fpn.top_down(*stages)), y)
         xl = [self._run_tower(self.loc_head, fm, sup, l) for l, fm in enumerate(feats)]
         xc = [self._run_tower(self.cls_head, fm, sup, l) for l, fm in enumerate(feats)]
         out = _rh.final_convs(self.loc_head[-1], self.cls_head[-1], xl, xc, support=sup, assignment=token)

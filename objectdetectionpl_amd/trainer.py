@@ -56,11 +56,18 @@ class _ForwardVia:
             return None
 
         def run(x, y):
+            # The route is decided ONCE per step and handed down: `loss_driven_mask` is not pure (it polls an asynchronous read-back
+            # and counts steps), and a second look could disagree with the first -- this rank would then broadcast its buffers twice
+            # (here and in self.forward) while its peers do it once, and the next collective would pair a broadcast with an all-reduce.
             taken = getattr(self._m, "loss_driven_mask", None)
-            if taken is not None and not taken(x, y):
+            mask = taken(x, y) if taken is not None else None
+            if taken is not None and not mask:
                 return None                              # declined: training_step goes through self.forward (which syncs the buffers)
             self._n.sync_buffers()
-            return fl(x, y)
+            out = fl(x, y) if mask is None else fl(x, y, mask=mask)
+            if out is None:
+                raise RuntimeError("forward_and_loss declined after its route was taken (buffers already synchronised for this step)")
+            return out
         return run
 
     def __getattr__(self, k):
@@ -170,7 +177,7 @@ class Trainer:
         while not self._watch_done:
             for r, p in enumerate(self._children, start=1):
                 rc = p.poll()
-                if rc not in (None, 0):
+                if rc not in (None, 0) and not self._watch_done:       # (_reap may be stopping the children itself by now)
                     print(f"[trainer] rank {r} exited with code {rc}; stopping the other ranks", file=sys.stderr, flush=True)
                     self._watch_done = True
                     self._stop_children(10.0)
@@ -184,6 +191,9 @@ class Trainer:
         """atexit of rank 0: after a clean run the children are finishing too (shared deadline of two minutes); after a crash
         they are stuck in a collective: stop them at once.  A child that failed makes this process exit non-zero."""
         self._watch_done = True
+        w = getattr(self, "_watcher", None)
+        if w is not None and w is not threading.current_thread():
+            w.join(timeout=2.0)                 # the watcher must not meet a child that THIS function terminates (rc -15) and end a clean run with 1
         if self._crashed:
             self._stop_children(10.0)
         else:
@@ -345,6 +355,15 @@ class Trainer:
 
     # -- fit ----------------------------------------------------------------------------------------------------------------
     def fit(self, model, datamodule=None, train_dataloader=None, val_dataloaders=None):
+        try:
+            return self._fit(model, datamodule, train_dataloader, val_dataloaders)
+        except BaseException:
+            # anything that leaves fit() early on rank 0 -- an exception, but also sys.exit(n) / KeyboardInterrupt, which never reach
+            # sys.excepthook -- leaves the other ranks inside a collective: _reap must stop them at once, not wait out its deadline
+            self._crashed = True
+            raise
+
+    def _fit(self, model, datamodule=None, train_dataloader=None, val_dataloaders=None):
         if datamodule is None:
             datamodule = train_dataloader
         if self.requested_world > 1 and "RANK" not in os.environ:

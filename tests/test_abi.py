@@ -21,7 +21,7 @@ def test_header_symbols_exported_and_bound():
     for n in names:
         assert hasattr(raw, n), f"{n} declared in odpl_hip.h but not exported"
     assert sorted(_lib.SIGNATURES) == names, (set(names) ^ set(_lib.SIGNATURES))
-    assert _lib.lib().odpl_abi_version() == _lib.ABI_VERSION == 5
+    assert _lib.lib().odpl_abi_version() == _lib.ABI_VERSION == 6
 
 
 def test_struct_layout_matches_header():

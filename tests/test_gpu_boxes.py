@@ -37,30 +37,3 @@ def test_ssd_priors_bit_exact(golden):
     g = golden("anchors")
     t = get_dboxes().cpu().numpy()
     assert t.shape == (8732, 4) and np.array_equal(t, g["ssd_dboxes"])
-
-
-@pytest.mark.parametrize("cin,cout,h", [(64, 64, 26), (256, 128, 13), (128, 256, 9), (32, 64, 20)])
-def test_conv1x1_as_fp32_mfma_gemm_vs_conv2d(cin, cout, h):
-    """csrc/odpl_gemm1x1.hip (a probe, not used by the models: it ties MIOpen on the network's 1x1 layers): a 1x1
-    convolution on channels-last tensors as a GEMM on v_mfma_f32_32x32x2_f32 -- forward and backward-data against F.conv2d, both tiles,
-    a row count that is not a multiple of the tile."""
-    import torch.nn.functional as F
-    from objectdetectionpl_amd import _lib
-    L = _lib.lib()
-    g = torch.Generator().manual_seed(cin + cout)
-    B = 3
-    x = torch.randn(B, cin, h, h, generator=g).cuda().contiguous(memory_format=torch.channels_last)
-    w = (torch.randn(cout, cin, 1, 1, generator=g) * 0.1).cuda().contiguous(memory_format=torch.channels_last)
-    y_ref = F.conv2d(x, w)
-    gy = torch.randn(y_ref.shape, generator=g).cuda().contiguous(memory_format=torch.channels_last)
-    gx_ref = torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [True, False, False])[0]
-    M, st = B * h * h, _lib.current_stream(x.device)
-    for tile in (64, 128):
-        if cout % tile == 0:
-            y = torch.empty_like(y_ref)
-            _lib.check(L.odpl_conv1x1_forward(_lib.ptr(x), _lib.ptr(w), _lib.ptr(y), M, cin, cout, tile, st), "fwd")
-            assert torch.allclose(y, y_ref, rtol=1e-4, atol=1e-5 * float(y_ref.abs().max()))
-        if cin % tile == 0:
-            gx = torch.empty_like(x)
-            _lib.check(L.odpl_conv1x1_backward_data(_lib.ptr(gy), _lib.ptr(w), _lib.ptr(gx), M, cin, cout, tile, st), "bwd")
-            assert torch.allclose(gx, gx_ref, rtol=1e-4, atol=1e-5 * float(gx_ref.abs().max()))

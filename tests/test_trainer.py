@@ -210,18 +210,37 @@ def test_forward_via_offers_a_folded_step_to_the_bucketed_wrapper_only():
         def loss_driven_mask(self, x, y):
             return 1 if self.take else 0
 
-        def forward_and_loss(self, x, y):
-            calls.append("fold")
+        def forward_and_loss(self, x, y, mask=None):
+            calls.append(("fold", mask))
             return {"loss": x + y}
 
     host = object.__new__(parallel.DataParallelHost)
     host.sync_buffers = lambda: calls.append("sync")
     m = M()
     via = _ForwardVia(m, host)
-    assert via.forward_and_loss(1, 2) == {"loss": 3} and calls == ["sync", "fold"]
+    assert via.forward_and_loss(1, 2) == {"loss": 3} and calls == ["sync", ("fold", 1)]      # the decision is handed down, not re-made
     m.take = False
     del calls[:]
     assert via.forward_and_loss(1, 2) is None and calls == []
+
+    # the route decision is not pure (model/RetinaNet.py:_crowded_levels polls an asynchronous read-back): a second look inside the
+    # fold could disagree with the first and make this rank broadcast its buffers twice in one step.  One look per step:
+    class Flipping(M):
+        looks = 0
+
+        def loss_driven_mask(self, x, y):
+            self.looks += 1
+            return 3 if self.looks == 1 else 0            # every later look would decline
+
+        def forward_and_loss(self, x, y, mask=None):
+            if mask is None:
+                mask = self.loss_driven_mask(x, y)
+            calls.append(("fold", mask))
+            return {"loss": x + y} if mask else None
+    f = Flipping()
+    del calls[:]
+    assert _ForwardVia(f, host).forward_and_loss(1, 2) == {"loss": 3}
+    assert calls == ["sync", ("fold", 3)] and f.looks == 1                                   # exactly one sync_buffers, one look
     assert _ForwardVia(m, object()).forward_and_loss is None                 # any other wrapper (torch DDP)
 
     class Plain:

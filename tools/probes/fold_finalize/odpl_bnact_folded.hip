@@ -14,6 +14,7 @@
 // concatenated tensor (row strides: the CSP merges write in place of torch.cat), bf16 activations (template BF: 8-byte
 // quads, fp32 arithmetic, one rounding), inference (statistics derived from the running buffers inside apply), and the
 // per-channel bias gradient of the linear head convs.
+#include <atomic>
 #include "odpl_bn_dev.hpp"
 
 namespace {
@@ -25,8 +26,95 @@ int g_bn_target_blocks = 1024;          // row tiles of the two reduce passes (o
 int g_bn_stream_max_blocks = 0;         // grid cap of the apply / dx streams; 0 = by size (4096, or 16384 from 8 M quads on)
 int g_bn_max_rows_per_tile = 2048;
 int g_bn_slice_from_c = 256;            // reduce passes cut the row into 16-quad channel slices from this many channels on
+int g_bn_fold_finalize = 1;             // channel-sliced maps: the last row tile of a slice finalizes it inside the reduce launch (0: finalize launch)
 }
 namespace {
+
+// ---- [r4] the finalize launch folded into the reduce launch (channel-sliced maps) ------------------------------------------------
+// A channel slice (16 quads) is reduced by nblk row tiles = nblk workgroups; each leaves its partial write-through (agent scope:
+// every XCD has its own L2), waits for the stores to land and takes a ticket; the holder of the slice's LAST ticket sums the nblk
+// partials in a fixed order (thread (tr, tc): rows tr, tr + 16, ... of quad tc; then the 16 row lanes in order) and writes what the
+// one-workgroup-per-channel finalize kernels used to.  The order of the sum is fixed, which workgroup runs it is not: bitwise
+// reproducible.  Nobody waits for anybody (no spinning), so progress never depends on co-residency.  Counters: a library-owned
+// device array, zero at rest (the last workgroup resets its slice's counter); consecutive calls rotate through kTicketSlots rows, so
+// calls in flight on different streams do not share one.
+// Every counter sits on a line of its own (kTicketPitch words apart): agent-scope atomics on one line are served one at a time
+// (~12 ns each, MI355X_MICROARCH.md "fanin") -- with the slices' counters side by side the ~1000 arrivals of a launch queued on ONE
+// line (+10 us per launch, measured); apart, a slice's 20-250 arrivals queue on its own.
+constexpr int kTicketSlots = 64, kTicketSlices = 64, kTicketPitch = 64;
+__device__ unsigned g_bn_ticket[kTicketSlots * kTicketSlices * kTicketPitch];
+
+// 16-byte write-through stores / L1-bypassing loads (`sc1`) through a buffer descriptor over the partial array: an 8-byte `sc1`
+// store is one fabric write each and costs 2.7x the time per byte (MI355X_MICROARCH.md, stores of each flavour)
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t part_rsrc(const BnParams& P) {
+    return __builtin_amdgcn_make_buffer_rsrc(P.part, 0, (int)((size_t)P.nblk * P.C * 2 * sizeof(double)), 0x00020000);
+}
+__device__ __forceinline__ void st2_f64_agent(__amdgpu_buffer_rsrc_t r, unsigned byte_off, double a, double b) {
+    union { v4u u; double d[2]; } x;
+    x.d[0] = a; x.d[1] = b;
+    __builtin_amdgcn_raw_buffer_store_b128(x.u, r, byte_off, 0, 16);
+}
+__device__ __forceinline__ void ld2_f64_agent(__amdgpu_buffer_rsrc_t r, unsigned byte_off, double& a, double& b) {
+    union { v4u u; double d[2]; } x;
+    x.u = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16);
+    a = x.d[0]; b = x.d[1];
+}
+
+// called by every thread of a sliced reduce workgroup after its partial (8 doubles per quad, written by the tr == 0 threads of
+// wave 0 with st2_f64_agent) has been issued.  MODE 0: batch statistics (mean / invstd / running buffers); 1: dgamma / dbeta.
+template <int MODE>
+__device__ __forceinline__ void slice_tail(const BnParams& P, int sq0, int tr, int tc, double* s_red) {
+    __shared__ int s_last;
+    if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the partial (stored by lanes of this wave) has landed
+        unsigned* t = P.ticket + (size_t)blockIdx.y * kTicketPitch;
+        const unsigned old = __hip_atomic_fetch_add(t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = old == gridDim.x - 1;
+        if (s_last) __hip_atomic_store(t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const int C = P.C, q = sq0 + tc;                                       // sliced maps: tpr == 16 threads per row, 16 row lanes
+    double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+    const __amdgpu_buffer_rsrc_t rs = part_rsrc(P);
+    for (int t = tr; t < P.nblk; t += 16) {
+        const unsigned o = (unsigned)(((size_t)t * C + 4 * q) * 2 * sizeof(double));
+        double va[4], vb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ld2_f64_agent(rs, o + 16u * i, va[i], vb[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a[i] += va[i]; b[i] += vb[i]; }
+    }
+    double* d = s_red + ((size_t)tr * 16 + tc) * 8;
+    for (int i = 0; i < 4; ++i) { d[i] = a[i]; d[4 + i] = b[i]; }
+    __syncthreads();
+    if (tr != 0) return;
+    double sa[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
+    for (int t = 0; t < 16; ++t) {
+        const double* e = s_red + ((size_t)t * 16 + tc) * 8;
+        for (int i = 0; i < 4; ++i) { sa[i] += e[i]; sb[i] += e[4 + i]; }
+    }
+#pragma unroll 1
+    for (int i = 0; i < 4; ++i) {                                          // (not unrolled: four copies of the double-precision division and
+        const int c = 4 * q + i;                                           // square root would cost the streaming loop above its occupancy)
+        if (MODE == 0) {
+            const double n = (double)P.R, mean = sa[i] / n;
+            double var = sb[i] / n - mean * mean; if (var < 0) var = 0;          // biased (normalisation)
+            P.mean[c] = (float)mean;
+            P.invstd[c] = (float)(1.0 / sqrt(var + (double)P.eps));
+            if (c == 0 && P.num_batches_tracked) P.num_batches_tracked[0] += 1;
+            if (P.running_mean) {                                                 // nn.BatchNorm2d: unbiased var into the running buffer
+                const double unb = n > 1 ? var * n / (n - 1) : var;
+                P.running_mean[c] = (float)((1.0 - P.momentum) * P.running_mean[c] + P.momentum * mean);
+                P.running_var[c] = (float)((1.0 - P.momentum) * P.running_var[c] + P.momentum * unb);
+            }
+        } else {
+            P.dbeta[c] = (float)sa[i];
+            P.dgamma[c] = (float)sb[i];
+        }
+    }
+}
 
 // one pass over a row tile: per-channel sums of (a, b) where (a, b) = f(row, channel-quad).
 // K rows per lane are requested before any is consumed (forward: 8 x 16 B, backward: 4 x (x, gy)); the loads are unconditional
@@ -113,9 +201,15 @@ __global__ __launch_bounds__(kT) void bn_reduce_kernel(const BnParams P) {
                 for (int i = 0; i < 4; ++i) { sa[i] += d[i]; sb[i] += d[4 + i]; }
             }
             double* o = P.part + ((size_t)blockIdx.x * C + 4 * q) * 2;
-            for (int i = 0; i < 4; ++i) { o[2 * i] = sa[i]; o[2 * i + 1] = sb[i]; }
+            if (P.ticket) {
+                const __amdgpu_buffer_rsrc_t rs = part_rsrc(P);
+                const unsigned ob = (unsigned)(((size_t)blockIdx.x * C + 4 * q) * 2 * sizeof(double));
+                for (int i = 0; i < 4; ++i) st2_f64_agent(rs, ob + 16u * i, sa[i], sb[i]);
+            }
+            else { for (int i = 0; i < 4; ++i) { o[2 * i] = sa[i]; o[2 * i + 1] = sb[i]; } }
         }
     }
+    if (P.ticket) slice_tail<BWD ? 1 : 0>(P, sq0, tr, tc, s_red);         // sliced maps: one channel pass, tpr == 16
 }
 
 // one workgroup per channel: lanes stride over the row-tile partials, fixed shuffle tree + fixed wave order
@@ -333,9 +427,15 @@ __global__ __launch_bounds__(kT) void bias_act_bwd_kernel(const BnParams P) {
                 for (int i = 0; i < 4; ++i) sa[i] += d[i];
             }
             double* o = P.part + ((size_t)blockIdx.x * C + 4 * q) * 2;
-            for (int i = 0; i < 4; ++i) { o[2 * i] = sa[i]; o[2 * i + 1] = 0.0; }
+            if (P.ticket) {
+                const __amdgpu_buffer_rsrc_t rs = part_rsrc(P);
+                const unsigned ob = (unsigned)(((size_t)blockIdx.x * C + 4 * q) * 2 * sizeof(double));
+                for (int i = 0; i < 4; ++i) st2_f64_agent(rs, ob + 16u * i, sa[i], 0.0);
+            }
+            else { for (int i = 0; i < 4; ++i) { o[2 * i] = sa[i]; o[2 * i + 1] = 0.0; } }
         }
     }
+    if (P.ticket) slice_tail<1>(P, sq0, tr, tc, s_red);
 }
 
 // Bias gradient of a conv whose output gradient is NCHW-dense (the three linear head convs: the region loss hands
@@ -404,6 +504,20 @@ bool plan(long long R, int C, RPlan* p) {
     const int tpr = p->slice_q < kT ? p->slice_q : kT, rows_par = kT / tpr;
     p->lds = (size_t)rows_par * tpr * 8 * sizeof(double);
     return true;
+}
+
+// counters of the folded finalize for this call, or NULL (unsliced map / switched off): a finalize launch follows then
+std::atomic<unsigned> g_ticket_slot{0};
+unsigned* g_ticket_base[16] = {};
+int ticket_row(const RPlan& pl, unsigned** out) {
+    *out = nullptr;
+    if (!odpl::g_bn_fold_finalize || pl.nslices < 2 || pl.nslices > kTicketSlices || pl.slice_q != 16) return 0;
+    int dev = 0;
+    ODPL_HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16) return 0;
+    if (!g_ticket_base[dev]) ODPL_HIP_TRY(hipGetSymbolAddress((void**)&g_ticket_base[dev], HIP_SYMBOL(g_bn_ticket)));
+    *out = g_ticket_base[dev] + (size_t)(g_ticket_slot.fetch_add(1) % kTicketSlots) * kTicketSlices * kTicketPitch;
+    return 0;
 }
 }  // namespace
 
@@ -477,11 +591,15 @@ static int bn_forward_impl(const void* x, const void* residual, int32_t res_pre,
     P.num_batches_tracked = (long long*)num_batches_tracked;
     if (training) {
         if (!workspace || workspace_bytes < odpl_bn_act_workspace_bytes(R, C) || ((uintptr_t)workspace & 15)) return ODPL_EINVAL;
+        { const int rc = ticket_row(pl, &P.ticket); if (rc) return rc; }
         if (bf16) hipLaunchKernelGGL((bn_reduce_kernel<false, true, 0>), dim3(nblk, pl.nslices), dim3(kT), lds, stream, P);      // statistics: no activation involved
         else hipLaunchKernelGGL((bn_reduce_kernel<false, false, 0>), dim3(nblk, pl.nslices), dim3(kT), lds, stream, P);
         ODPL_HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), dim3(kT), 0, stream, P);
-        ODPL_HIP_TRY(hipGetLastError());
+        if (!P.ticket) {
+            hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), dim3(kT), 0, stream, P);
+            ODPL_HIP_TRY(hipGetLastError());
+        }
+        P.ticket = nullptr;
     }   // eval: the caller filled save_mean / save_invstd from the running statistics
     const long long n4 = R * (C >> 2);
     long long blocks = (n4 + kT - 1) / kT;
@@ -518,11 +636,14 @@ extern "C" int odpl_bn_act_backward_strided(const void* x, const void* grad_y, i
     P.R = R; P.C = C; P.act = act; P.nblk = nblk; P.rows_per_blk = rpb; P.slice_q = pl.slice_q; P.training = training; P.part = (double*)workspace;
     P.y_rs4 = C >> 2; P.gy_rs4 = gy_row_stride >> 2;
     P.dgamma = grad_gamma; P.dbeta = grad_beta;
+    { const int rc = ticket_row(pl, &P.ticket); if (rc) return rc; }
     if (bf16) { ODPL_BN_LAUNCH(bn_reduce_kernel, true ODPL_COMMA true, dim3(nblk, pl.nslices), lds, stream, P) }
     else { ODPL_BN_LAUNCH(bn_reduce_kernel, true ODPL_COMMA false, dim3(nblk, pl.nslices), lds, stream, P) }
     ODPL_HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(kT), 0, stream, P);
-    ODPL_HIP_TRY(hipGetLastError());
+    if (!P.ticket) {
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(kT), 0, stream, P);
+        ODPL_HIP_TRY(hipGetLastError());
+    }
     const long long n4 = R * (C >> 2);
     long long blocks = (n4 + kT - 1) / kT;
     { const long long cap = odpl::g_bn_stream_max_blocks > 0 ? odpl::g_bn_stream_max_blocks : (n4 >= (8LL << 20) ? 16384 : 4096); if (blocks > cap) blocks = cap; }
@@ -557,11 +678,14 @@ extern "C" int odpl_bn_add_act_backward(const float* x, const float* y, const fl
     P.R = R; P.C = C; P.act = ODPL_ACT_LINEAR; P.nblk = pl.nblk; P.rows_per_blk = pl.rows_per_blk; P.slice_q = pl.slice_q; P.training = training;
     P.part = (double*)workspace; P.y_rs4 = C >> 2; P.gy_rs4 = C >> 2;
     P.dgamma = grad_gamma; P.dbeta = grad_beta;
+    { const int rc = ticket_row(pl, &P.ticket); if (rc) return rc; }
     if (act == ODPL_ACT_RELU) hipLaunchKernelGGL((bn_reduce_kernel<true, false, ODPL_ACT_RELU, true>), dim3(pl.nblk, pl.nslices), dim3(kT), pl.lds, stream, P);
     else hipLaunchKernelGGL((bn_reduce_kernel<true, false, ODPL_ACT_LEAKY, true>), dim3(pl.nblk, pl.nslices), dim3(kT), pl.lds, stream, P);
     ODPL_HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(kT), 0, stream, P);
-    ODPL_HIP_TRY(hipGetLastError());
+    if (!P.ticket) {
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(kT), 0, stream, P);
+        ODPL_HIP_TRY(hipGetLastError());
+    }
     P.gy = grad_residual;                                                        // the dx pass reads the masked gradient
     const long long n4 = R * (C >> 2);
     long long blocks = (n4 + kT - 1) / kT;
@@ -610,12 +734,15 @@ extern "C" int odpl_bias_act_backward_flags(const float* y, const float* grad_y,
     P.flags = active;
     if (active) ODPL_HIP_TRY(odpl::fill_bytes(active, 0, (size_t)R, stream));
     const dim3 grid(pl.nblk, pl.nslices);
+    { const int rc = ticket_row(pl, &P.ticket); if (rc) return rc; }
     if (act == ODPL_ACT_RELU) hipLaunchKernelGGL(bias_act_bwd_kernel<ODPL_ACT_RELU>, grid, dim3(kT), pl.lds, stream, P);
     else if (act == ODPL_ACT_LEAKY) hipLaunchKernelGGL(bias_act_bwd_kernel<ODPL_ACT_LEAKY>, grid, dim3(kT), pl.lds, stream, P);
     else hipLaunchKernelGGL(bias_act_bwd_kernel<ODPL_ACT_LINEAR>, grid, dim3(kT), pl.lds, stream, P);
     ODPL_HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(kT), 0, stream, P);
-    ODPL_HIP_TRY(hipGetLastError());
+    if (!P.ticket) {
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(kT), 0, stream, P);
+        ODPL_HIP_TRY(hipGetLastError());
+    }
     return 0;
 }
 

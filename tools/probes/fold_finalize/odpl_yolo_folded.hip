@@ -15,7 +15,10 @@
 //   loss     (one launch)            "conf" blocks: confidence logit + state of every cell -> BCE(obj / noobj x100) partial
 //                                    sums, gconf[cell] = d loss/d logit, state reset; "obj" blocks (1 / target / scale):
 //                                    the 5+C logits of an obj cell -> x,y,w,h,cls terms, gobj[t][5+C], "Size" metric
-//   finalize (1 workgroup)           fixed-order reduction -> the reference's 7 scalars per scale and total
+//                                    the LAST workgroup to arrive (one integer ticket per call) then runs the fixed-order
+//                                    double-precision reduction -> the reference's 7 scalars per scale and total: the order of
+//                                    the sum is fixed, who runs it is not, so the result is bitwise reproducible ([r4]: this was a
+//                                    third launch of one workgroup)
 // backward consumes the compact gradient:
 //   expand + patch                   the dense tensor autograd hands to a generic producer: zeros streamed with 16-B
 //                                    non-temporal stores and gconf in the confidence slots (HBM-write bound; the kernel the
@@ -213,6 +216,17 @@ __device__ __forceinline__ void conf_cell(float z, int st, float w_obj, float w_
     }                                               // st == 0: ignored (anchor IoU > thres)
 }
 
+// Partial sums cross workgroups INSIDE the loss launch (the last arrival reduces them): they are stored write-through and read
+// back at agent scope (8-byte relaxed atomics: every XCD has its own L2), the ticket orders them -- see yolo_loss_kernel.
+__device__ __forceinline__ void st2_agent(float* p, float a, float b) {
+    const unsigned long long v = (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32);
+    __hip_atomic_store((unsigned long long*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float2 ld2_agent(const float* p) {
+    const unsigned long long v = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float2(__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32)));
+}
+
 // diagnostic stamps: first-start / last-end of the grid on the constant 100 MHz counter (never read by the kernel)
 __device__ __forceinline__ void stamp_begin(const Params& P) {
     if (P.stamp && threadIdx.x == 0) P.stamp[2 * blockIdx.x] = (unsigned long long)wall_clock64();
@@ -265,7 +279,7 @@ __device__ __forceinline__ void conf_block(const Params& P, const Scale& S, int 
         }
     }
     block_sum<2>(acc, sh);
-    if (tid == 0) { S.conf_part[local * 2] = acc[0]; S.conf_part[local * 2 + 1] = acc[1]; }
+    if (tid == 0) st2_agent(S.conf_part + local * 2, acc[0], acc[1]);
 }
 
 __device__ __forceinline__ void obj_block(const Params& P, const Scale& S, int t, float* sh, float* sh_bc) {
@@ -274,7 +288,7 @@ __device__ __forceinline__ void obj_block(const Params& P, const Scale& S, int t
     const bool act = tid < kObjThreads;
     float* part = S.obj_part + (size_t)t * 8;
     const int cell = S.tcell[t];
-    if (cell < 0 || cell >= S.cells) { if (tid < 8) part[tid] = 0.f; return; }       // uniform per block
+    if (cell < 0 || cell >= S.cells) { if (tid < 3) st2_agent(part + 2 * tid, 0.f, 0.f); return; }       // uniform per block
     size_t base, cs;
     int a;
     if (S.layout == ODPL_LAYOUT_PLANAR) {
@@ -351,46 +365,26 @@ __device__ __forceinline__ void obj_block(const Params& P, const Scale& S, int t
         }
     }
     block_sum<6>(acc, sh);
-    if (tid == 0) {
-        for (int i = 0; i < 6; ++i) part[i] = acc[i];
-        part[6] = part[7] = 0.f;
-    }
+    if (tid == 0) { st2_agent(part, acc[0], acc[1]); st2_agent(part + 2, acc[2], acc[3]); st2_agent(part + 4, acc[4], acc[5]); }
 }
 
-__global__ __launch_bounds__(kConfThreads) void yolo_loss_kernel(const Params P) {
-    __shared__ float sh[8 * (kConfThreads / 64)];
-    __shared__ float sh_bc[2];
-    const int bid = blockIdx.x;
-    int si = 0;
-    bool is_conf = true;
-    for (int i = 0; i < P.nscales; ++i) {
-        const Scale& T = P.s[i];
-        if (bid >= T.conf_blk0 && bid < T.conf_blk0 + T.conf_nblk) { si = i; is_conf = true; }
-        if (bid >= T.obj_blk0 && bid < T.obj_blk0 + P.nT) { si = i; is_conf = false; }
-    }
-    const Scale& S = P.s[si];
-    if (is_conf) conf_block(P, S, bid - S.conf_blk0, sh);
-    else obj_block(P, S, bid - S.obj_blk0, sh, sh_bc);
-}
-
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64 * ODPL_MAX_SCALES) void yolo_finalize_kernel(const Params P) {
-    // wave w reduces scale w (fixed lane-strided order + fixed shuffle tree => reproducible);
-    // then lanes 0..6 of wave 0 add the scales in order (losses.py:606-612)
-    __shared__ float res[ODPL_MAX_SCALES][8];
+// The reference's 7 scalars per scale and their total from the partial sums; run by ONE workgroup of kConfThreads threads.
+// Wave w reduces scale w (fixed lane-strided order + fixed shuffle tree => reproducible), then lanes 0..6 of wave 0 add the
+// scales in order (losses.py:606-612).
+__device__ __forceinline__ void finalize_block(const Params& P, float (*res)[8]) {
     const int tid = threadIdx.x, lane = tid & 63, si = tid >> 6;
     if (si < P.nscales) {
         const Scale& S = P.s[si];
         const int nObj = S.counts[0], nNoobj = S.counts[1];
         double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};          // lx ly lw lh lcls size conf_obj conf_noobj
         for (int t = lane; t < P.nT; t += 64) {
-            const float4* p = reinterpret_cast<const float4*>(S.obj_part + (size_t)t * 8);
-            const float4 u = p[0], v = p[1];
-            a[0] += (double)u.x; a[1] += (double)u.y; a[2] += (double)u.z; a[3] += (double)u.w;
-            a[4] += (double)v.x; a[5] += (double)v.y;
+            const float* p = S.obj_part + (size_t)t * 8;
+            const float2 u = ld2_agent(p), v = ld2_agent(p + 2), w = ld2_agent(p + 4);
+            a[0] += (double)u.x; a[1] += (double)u.y; a[2] += (double)v.x; a[3] += (double)v.y;
+            a[4] += (double)w.x; a[5] += (double)w.y;
         }
         for (int b = lane; b < S.conf_nblk; b += 64) {
-            const float2 c = reinterpret_cast<const float2*>(S.conf_part)[b];
+            const float2 c = ld2_agent(S.conf_part + 2 * b);
             a[6] += (double)c.x; a[7] += (double)c.y;
         }
 #pragma unroll
@@ -414,7 +408,7 @@ __global__ __launch_bounds__(64 * ODPL_MAX_SCALES) void yolo_finalize_kernel(con
             r[0] = lx + ly + lw + lh + lconf + lcls;                                  // losses.py:566
             r[1] = lx + ly; r[2] = size; r[3] = lconf; r[4] = lcls; r[5] = lobj; r[6] = lnoobj;
             for (int i = 0; i < 7; ++i) { res[si][i] = r[i]; if (P.out_scales) P.out_scales[si * 7 + i] = r[i]; }
-            if (P.out_counts) for (int i = 0; i < 8; ++i) P.out_counts[si * 8 + i] = S.counts[i];
+            if (P.out_counts) for (int i = 0; i < 8; ++i) P.out_counts[si * 8 + i] = i < 5 ? S.counts[i] : 0;
         }
     }
     __syncthreads();
@@ -423,6 +417,37 @@ __global__ __launch_bounds__(64 * ODPL_MAX_SCALES) void yolo_finalize_kernel(con
         for (int i = 0; i < P.nscales; ++i) acc += res[i][tid];                       // losses.py:606-612
         P.out7[tid] = P.average ? acc / (float)P.nscales : acc;                       // losses.py:616-623
     }
+}
+
+// Grid: the obj workgroups first (two dependent trips to memory each: the cell index, then the cell's logits), then the
+// confidence workgroups.  Every workgroup leaves its partial sums write-through, waits for them to land and takes a ticket;
+// the holder of the last ticket sees every partial (agent-scope loads) and finishes the call.
+__global__ __launch_bounds__(kConfThreads) void yolo_loss_kernel(const Params P) {
+    __shared__ float sh[8 * (kConfThreads / 64)];
+    __shared__ float sh_bc[2];
+    __shared__ float res[ODPL_MAX_SCALES][8];
+    __shared__ int s_last;
+    const int bid = blockIdx.x;
+    int si = 0;
+    bool is_conf = true;
+    for (int i = 0; i < P.nscales; ++i) {
+        const Scale& T = P.s[i];
+        if (bid >= T.conf_blk0 && bid < T.conf_blk0 + T.conf_nblk) { si = i; is_conf = true; }
+        if (bid >= T.obj_blk0 && bid < T.obj_blk0 + P.nT) { si = i; is_conf = false; }
+    }
+    const Scale& S = P.s[si];
+    if (is_conf) conf_block(P, S, bid - S.conf_blk0, sh);
+    else obj_block(P, S, bid - S.obj_blk0, sh, sh_bc);
+    if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                              // this workgroup's partials have landed (they were
+                                                                                      // stored by lanes of this wave)
+        int* ticket = P.s[0].counts + 5;                                              // zeroed by the assign launch
+        const int old = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = old == (int)gridDim.x - 1;
+        if (s_last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (s_last) finalize_block(P, res);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -662,8 +687,8 @@ int run_forward(const odpl_yolo_loss_desc_t* d, const Plan& pl, void* workspace,
     if (rc) return rc;
     P.out7 = out7; P.out_scales = out_scales; P.out_counts = out_counts;
     int nblk = 0;
-    for (int i = 0; i < d->nscales; ++i) { P.s[i].conf_blk0 = nblk; nblk += P.s[i].conf_nblk; }     // confidence blocks first
-    for (int i = 0; i < d->nscales; ++i) { P.s[i].obj_blk0 = nblk; nblk += d->nT; }
+    for (int i = 0; i < d->nscales; ++i) { P.s[i].obj_blk0 = nblk; nblk += d->nT; }                 // obj blocks first (the longer chain)
+    for (int i = 0; i < d->nscales; ++i) { P.s[i].conf_blk0 = nblk; nblk += P.s[i].conf_nblk; }
     if (!(d->flags & ODPL_YOLO_STATE_CLEAN)) ODPL_HIP_TRY(odpl::fill_bytes(workspace, 0xFF, pl.state_bytes_total, stream));
     prof_begin(ODPL_PROF_YOLO_ASSIGN, stream);
     hipLaunchKernelGGL(yolo_assign_kernel, dim3(d->nscales), dim3(kAssignThreads), 0, stream, P);
@@ -672,10 +697,6 @@ int run_forward(const odpl_yolo_loss_desc_t* d, const Plan& pl, void* workspace,
     prof_begin(ODPL_PROF_YOLO_LOSS, stream);
     hipLaunchKernelGGL(yolo_loss_kernel, dim3(nblk), dim3(kConfThreads), 0, stream, P);
     prof_end(ODPL_PROF_YOLO_LOSS, stream);
-    ODPL_HIP_TRY(hipGetLastError());
-    prof_begin(ODPL_PROF_YOLO_FINALIZE, stream);
-    hipLaunchKernelGGL(yolo_finalize_kernel, dim3(1), dim3(64 * ODPL_MAX_SCALES), 0, stream, P);
-    prof_end(ODPL_PROF_YOLO_FINALIZE, stream);
     ODPL_HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -766,7 +787,7 @@ extern "C" int odpl_yolo_compact_view(const odpl_yolo_loss_desc_t* d, const void
     return 0;
 }
 
-namespace odpl { extern int g_retina_fill_nt; extern int g_bn_target_blocks; extern int g_bn_stream_max_blocks; extern int g_bn_max_rows_per_tile; extern int g_bn_slice_from_c; }
+namespace odpl { extern int g_retina_fill_nt; extern int g_bn_target_blocks; extern int g_bn_stream_max_blocks; extern int g_bn_max_rows_per_tile; extern int g_bn_slice_from_c; extern int g_bn_fold_finalize; }
 
 extern "C" int odpl_debug_set_stamp_buffer(void* dev_u64x2) { g_stamp = (unsigned long long*)dev_u64x2; return 0; }
 
@@ -779,6 +800,7 @@ extern "C" int odpl_tune_set(int32_t key, int32_t value) {
         case ODPL_TUNE_BN_STREAM_MAX_BLOCKS: if (value != 0 && (value < 64 || value > (1 << 20))) return ODPL_EINVAL; odpl::g_bn_stream_max_blocks = value; return 0;
         case ODPL_TUNE_BN_MAX_ROWS_PER_TILE: if (value < 16 || value > (1 << 16)) return ODPL_EINVAL; odpl::g_bn_max_rows_per_tile = value; return 0;
         case ODPL_TUNE_BN_SLICE_FROM_C: if (value < 4) return ODPL_EINVAL; odpl::g_bn_slice_from_c = value; return 0;
+        case ODPL_TUNE_BN_FOLD_FINALIZE: odpl::g_bn_fold_finalize = value ? 1 : 0; return 0;
         default: return ODPL_EINVAL;
     }
 }
