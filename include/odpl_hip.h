@@ -682,6 +682,8 @@ int odpl_bn_act_backward_strided(const void* x, const void* grad_y, int64_t gy_r
 #define ODPL_TUNE_BN_STREAM_MAX_BLOCKS 4  /* grid cap of the BN apply / dx streams (0 = by size: 4096 / 16384) */
 #define ODPL_TUNE_BN_MAX_ROWS_PER_TILE 5  /* rows per reduce tile at most (default 2048) */
 #define ODPL_TUNE_BN_SLICE_FROM_C 6       /* BN reduce passes cut rows into 16-quad channel slices from this C on (default 256) */
+#define ODPL_TUNE_YOLO_FUSED_MAX_TARGETS 7 /* region loss: assignment + loss are ONE launch up to this many target rows (default and at most 512);
+                                           * 0: always the assign launch + the loss launch over the global state map */
 int odpl_tune_set(int32_t key, int32_t value);
 /* diagnostic: when non-NULL, every workgroup w of yolo_expand_kernel stores its start / end reading of the
  * constant 100 MHz counter into dev_u64[2w], dev_u64[2w+1] (buffer >= 2 * grid entries); NULL disables it. */

@@ -283,7 +283,7 @@ RETINA_ASSIGN_ONLY = 4
 RETINA_ASSIGNED = 8
 YOLOV5_STATE_CLEAN = 1
 IOU_MODES = {"iou": 0, "giou": 1, "diou": 2, "ciou": 3}
-TUNE_KEYS = {"yolo_fill_f4_per_block": 0, "yolo_fill_nt": 1, "retina_fill_nt": 2, "bn_target_blocks": 3, "bn_stream_max_blocks": 4, "bn_max_rows_per_tile": 5, "bn_slice_from_c": 6}
+TUNE_KEYS = {"yolo_fill_f4_per_block": 0, "yolo_fill_nt": 1, "retina_fill_nt": 2, "bn_target_blocks": 3, "bn_stream_max_blocks": 4, "bn_max_rows_per_tile": 5, "bn_slice_from_c": 6, "yolo_fused_max_targets": 7}
 
 
 def tune_set(name, value):

@@ -16,6 +16,11 @@
 //                                    sums, gconf[cell] = d loss/d logit, state reset; "obj" blocks (1 / target / scale):
 //                                    the 5+C logits of an obj cell -> x,y,w,h,cls terms, gobj[t][5+C], "Size" metric
 //   finalize (1 workgroup)           fixed-order reduction -> the reference's 7 scalars per scale and total
+// [r4] Up to kFusedMaxT targets (every training batch of the BASELINE configs) assign + loss are ONE launch with no state map and no
+// global atomics (yolo_fused_kernel): the assignment is a function of the <= 512 target rows alone, so every workgroup derives
+// what it needs of it from the rows themselves in LDS -- its scale's guards, winners (last row on a cell wins), distinct-cell counts
+// nObj / nNoobj, and the state of ITS OWN cells -- while its logits are already in flight.  Same arithmetic, same partial sums, same
+// bits as the two launches; one dependent launch (and its 3-4 dependent trips to memory) less: 6.8 + 7.0 us -> one launch.
 // backward consumes the compact gradient:
 //   expand + patch                   the dense tensor autograd hands to a generic producer: zeros streamed with 16-B
 //                                    non-temporal stores and gconf in the confidence slots (HBM-write bound; the kernel the
@@ -43,6 +48,8 @@ constexpr int kExpandThreads = 256;
 int g_fill_f4_per_block = 2048;         // float4 stores per expand block (x16 B)
 unsigned long long* g_stamp = nullptr;
 int g_fill_nt = 1;                      // 1: non-temporal stores for the zero stream (in-step: 11.4 vs 12.1 us)
+constexpr int kFusedMaxT = 512;         // targets per call up to which assignment + loss are one launch (LDS tables, an O(nT) scan per row)
+int g_fused_max_t = kFusedMaxT;         // odpl_tune_set(ODPL_TUNE_YOLO_FUSED_MAX_TARGETS): 0 = always assign launch + loss launch
 
 struct Scale {
     const float* head;
@@ -221,59 +228,93 @@ __device__ __forceinline__ void stamp_end(const Params& P) {
     if (P.stamp) { __syncthreads(); if (threadIdx.x == 0) { __builtin_amdgcn_s_waitcnt(0); P.stamp[2 * blockIdx.x + 1] = (unsigned long long)wall_clock64(); } }
 }
 
-__device__ __forceinline__ void conf_block(const Params& P, const Scale& S, int local, float* sh) {
+// The confidence logits of this workgroup's cells, requested before anything else the workgroup does (the fused launch decodes the
+// target rows while they travel).  idx: float4 index within the plane (planar, vector), cell within the plane (planar, scalar) or
+// global cell (interleaved); ok: the lane has cells.
+struct ConfIn { float4 z; int idx; bool ok; };
+__device__ __forceinline__ ConfIn conf_load(const Params& P, const Scale& S, int local) {
     const int tid = threadIdx.x, G2 = S.G2, CH = P.CH;
-    const float w_obj = P.obj_scale * P.inv_S / (float)S.counts[0];
-    const float w_noobj = P.noobj_scale * P.inv_S / (float)S.counts[1];
-    float acc[2] = {0.f, 0.f};
+    ConfIn in; in.z = make_float4(0.f, 0.f, 0.f, 0.f); in.ok = false; in.idx = 0;
     if (S.layout == ODPL_LAYOUT_PLANAR) {
         const int plane = local / S.conf_blk_per_row, part = local - plane * S.conf_blk_per_row;
         const float* __restrict__ z = S.head + ((size_t)plane * CH + 4) * G2;
+        in.idx = part * kConfThreads + tid;
+        if (S.conf_vec) { in.ok = in.idx < G2 / 4; if (in.ok) in.z = reinterpret_cast<const float4*>(z)[in.idx]; }
+        else { in.ok = in.idx < G2; if (in.ok) in.z.x = z[in.idx]; }
+    } else {
+        // interleaved: thread = cell; the logit sits CH floats from its neighbour's (one memory request per cell), the
+        // state map and gconf are compact and coalesced
+        in.idx = local * kConfThreads + tid;
+        in.ok = in.idx < S.cells;
+        if (in.ok) in.z.x = S.head[(size_t)in.idx * CH + 4];
+    }
+    return in;
+}
+
+// lstate != null (fused launch): the states of this workgroup's cells, in LDS, already final; counts come from the caller; the
+// global state map is not touched.  lstate == null: the state map of the assign launch (read, then reset to -1).
+__device__ __forceinline__ void conf_finish(const Params& P, const Scale& S, int local, const ConfIn& in, float* sh, const int* lstate,
+                                            int nObj, int nNoobj) {
+    const int tid = threadIdx.x, G2 = S.G2;
+    const float w_obj = P.obj_scale * P.inv_S / (float)nObj;
+    const float w_noobj = P.noobj_scale * P.inv_S / (float)nNoobj;
+    float acc[2] = {0.f, 0.f};
+    if (S.layout == ODPL_LAYOUT_PLANAR) {
+        const int plane = local / S.conf_blk_per_row;
         float* __restrict__ g = S.gconf ? S.gconf + (size_t)plane * G2 : nullptr;
-        int* __restrict__ st = S.state + (size_t)plane * G2;
+        int* __restrict__ st = lstate ? nullptr : S.state + (size_t)plane * G2;
         if (S.conf_vec) {
-            const int i4 = part * kConfThreads + tid;
-            if (i4 < G2 / 4) {
-                const float4 zv = reinterpret_cast<const float4*>(z)[i4];
-                const int4 sv = reinterpret_cast<const int4*>(st)[i4];
+            if (in.ok) {
+                const int i4 = in.idx;
+                const float4 zv = in.z;
+                const int4 sv = lstate ? reinterpret_cast<const int4*>(lstate)[tid] : reinterpret_cast<const int4*>(st)[i4];
                 float4 gv;
                 conf_cell(zv.x, sv.x, w_obj, w_noobj, gv.x, acc[0], acc[1]);
                 conf_cell(zv.y, sv.y, w_obj, w_noobj, gv.y, acc[0], acc[1]);
                 conf_cell(zv.z, sv.z, w_obj, w_noobj, gv.z, acc[0], acc[1]);
                 conf_cell(zv.w, sv.w, w_obj, w_noobj, gv.w, acc[0], acc[1]);
                 if (g) reinterpret_cast<float4*>(g)[i4] = gv;
-                reinterpret_cast<int4*>(st)[i4] = make_int4(-1, -1, -1, -1);      // leave the map clean for the next call
+                if (!lstate) reinterpret_cast<int4*>(st)[i4] = make_int4(-1, -1, -1, -1);      // leave the map clean for the next call
             }
-        } else {
-            const int i = part * kConfThreads + tid;
-            if (i < G2) {
-                float gv;
-                conf_cell(z[i], st[i], w_obj, w_noobj, gv, acc[0], acc[1]);
-                if (g) g[i] = gv;
-                st[i] = -1;
-            }
-        }
-    } else {
-        // interleaved: thread = cell; the logit sits CH floats from its neighbour's (one memory request per cell), the
-        // state map and gconf are compact and coalesced
-        const int c = local * kConfThreads + tid;
-        if (c < S.cells) {
+        } else if (in.ok) {
+            const int i = in.idx;
             float gv;
-            conf_cell(S.head[(size_t)c * CH + 4], S.state[c], w_obj, w_noobj, gv, acc[0], acc[1]);
-            if (S.gconf) S.gconf[c] = gv;
-            S.state[c] = -1;
+            conf_cell(in.z.x, lstate ? lstate[tid] : st[i], w_obj, w_noobj, gv, acc[0], acc[1]);
+            if (g) g[i] = gv;
+            if (!lstate) st[i] = -1;
         }
+    } else if (in.ok) {
+        const int c = in.idx;
+        float gv;
+        conf_cell(in.z.x, lstate ? lstate[tid] : S.state[c], w_obj, w_noobj, gv, acc[0], acc[1]);
+        if (S.gconf) S.gconf[c] = gv;
+        if (!lstate) S.state[c] = -1;
     }
     block_sum<2>(acc, sh);
     if (tid == 0) { S.conf_part[local * 2] = acc[0]; S.conf_part[local * 2 + 1] = acc[1]; }
 }
 
-__device__ __forceinline__ void obj_block(const Params& P, const Scale& S, int t, float* sh, float* sh_bc) {
-    // one workgroup per target that may own an obj cell; the first kObjThreads threads work, all join the barriers
+// first cell (layout order) and number of cells of conf workgroup `local` -- the range its LDS state table covers
+__device__ __forceinline__ void conf_range(const Scale& S, int local, int& c0, int& n) {
+    if (S.layout == ODPL_LAYOUT_PLANAR) {
+        const int plane = local / S.conf_blk_per_row, part = local - plane * S.conf_blk_per_row;
+        const int per = S.conf_vec ? 4 * kConfThreads : kConfThreads;
+        c0 = plane * S.G2 + part * per;
+        n = S.G2 - part * per; if (n > per) n = per;
+    } else {
+        c0 = local * kConfThreads;
+        n = S.cells - c0; if (n > kConfThreads) n = kConfThreads;
+    }
+}
+
+// one workgroup per target that may own an obj cell; the first kObjThreads threads work, all join the barriers.
+// cell: the target's obj cell (layout order) if it owns one, else < 0; r: tx, ty, tw, th; bits: class bitset of the cell; rk: raster
+// rank of the cell among the obj cells -- from the assign launch's workspace, or from the fused launch's LDS
+__device__ __forceinline__ void obj_block(const Params& P, const Scale& S, int t, int cell, const float* r, const unsigned* bits, int rk,
+                                          int nObj, float* sh, float* sh_bc) {
     const int tid = threadIdx.x, CH = P.CH, C = P.C, G2 = S.G2;
     const bool act = tid < kObjThreads;
     float* part = S.obj_part + (size_t)t * 8;
-    const int cell = S.tcell[t];
     if (cell < 0 || cell >= S.cells) { if (tid < 8) part[tid] = 0.f; return; }       // uniform per block
     size_t base, cs;
     int a;
@@ -285,10 +326,7 @@ __device__ __forceinline__ void obj_block(const Params& P, const Scale& S, int t
     }
     const float* __restrict__ zp = S.head + base;
     float* __restrict__ go = S.gobj ? S.gobj + (size_t)t * CH : nullptr;
-    const int nObj = S.counts[0];
     const float w = P.inv_S / (float)nObj;                 // mean over nObj, then the 1/len(output)
-    const float* r = S.rec + (size_t)t * 4;
-    const unsigned* bits = S.bits + (size_t)t * P.W;
     const int sl1 = P.coord_sl1;
 
     float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};        // lx, ly, lw, lh, lcls, size
@@ -341,7 +379,7 @@ __device__ __forceinline__ void obj_block(const Params& P, const Scale& S, int t
     }
     // "Size" metric (losses.py:568-573): obj cells in raster order vs target COLUMNS 3:5 of row `rank`
     if (tid == 0) {
-        const int k = nObj < P.nT ? nObj : P.nT, rk = S.trank[t];
+        const int k = nObj < P.nT ? nObj : P.nT;
         if (rk < k) {
             const float pw = expf(zp[(size_t)2 * cs]) * S.aw[a], ph = expf(zp[(size_t)3 * cs]) * S.ah[a];
             const float* yr = P.target + (size_t)rk * 6;
@@ -369,8 +407,189 @@ __global__ __launch_bounds__(kConfThreads) void yolo_loss_kernel(const Params P)
         if (bid >= T.obj_blk0 && bid < T.obj_blk0 + P.nT) { si = i; is_conf = false; }
     }
     const Scale& S = P.s[si];
-    if (is_conf) conf_block(P, S, bid - S.conf_blk0, sh);
-    else obj_block(P, S, bid - S.obj_blk0, sh, sh_bc);
+    if (is_conf) { const ConfIn in = conf_load(P, S, bid - S.conf_blk0); conf_finish(P, S, bid - S.conf_blk0, in, sh, nullptr, S.counts[0], S.counts[1]); }
+    else {
+        const int t = bid - S.obj_blk0;
+        obj_block(P, S, t, S.tcell[t], S.rec + (size_t)t * 4, S.bits + (size_t)t * P.W, S.trank[t], S.counts[0], sh, sh_bc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// [r4] assignment + loss in one launch (nT <= kFusedMaxT).  Grid as yolo_loss_kernel.  Every workgroup:
+//   1. requests its logits (conf workgroups; they do not depend on the assignment),
+//   2. decodes the target rows of ITS scale into LDS: position key (b, gj, gi) or -1, best anchor, ignore mask, validity -- the
+//      per-row guards of accuracy.py:340-367 exactly as yolo_assign_kernel applies them,
+//   3. scans the table once per own row: a row WINS its cell unless a later row claims the same (cell, best anchor) ("last row
+//      in row order wins", as index_put does); its ignore touches are NEW unless an obj touch or an earlier row's ignore touch
+//      sits on the same cell.  nObj = winners, nNoobj = cells - (winners + new ignore touches): the integers the state map's
+//      atomicMax returns used to count,
+//   4. conf workgroups: scatter the touches that fall into their own <= 1024 cells into an LDS state table, then the confidence
+//      terms as ever; obj workgroups: the class bitset (rows sharing the winner's cell) and the raster rank from the same table,
+//      then the x, y, w, h, class terms as ever.
+// No global state map, no global atomics, nothing to keep clean between calls.
+struct FusedTables {
+    __attribute__((aligned(16))) int pos[kFusedMaxT];            // (b * G + gj) * G + gi after python's negative-index wrap, or -1 (the reference would skip / raise)
+    unsigned meta[kFusedMaxT];      // bits 0-2 best anchor | 8-15 ignore mask (per-target guard passed) | 16 obj touch valid | 17 winner
+    int lab[kFusedMaxT];            // wrapped label if it may set a class bit (guard 2 passed), else -1
+};
+
+__global__ __launch_bounds__(kConfThreads) void yolo_fused_kernel(const Params P) {
+    __shared__ float sh[8 * (kConfThreads / 64)];
+    __shared__ float sh_bc[2];
+    __shared__ FusedTables T;
+    __shared__ __attribute__((aligned(16))) int lstate[4 * kConfThreads];
+    __shared__ int s_flags, s_cnt[2];
+    // Which rows share their position (b, gj, gi) with another row?  Almost none do, and only those need the scan of step 3: every row
+    // sets its position's bit in `seen`; a row that finds the bit already set marks the position in `twice`.  65 536 positions
+    // (B * G^2: 43 264 at config 2's finest scale); larger maps scan every row.
+    constexpr int kBmWords = 2048;
+    __shared__ unsigned bm_seen[kBmWords], bm_twice[kBmWords];
+    __shared__ unsigned s_bits[8];          // C <= 256 classes on this path (checked on the host)
+    __shared__ int s_rank;
+    __shared__ float s_rec[4];
+    __shared__ float s_aw[ODPL_MAX_ANCHORS], s_ah[ODPL_MAX_ANCHORS];
+    const int bid = blockIdx.x, tid = threadIdx.x, nT = P.nT, B = P.B, C = P.C;
+    int si = 0;
+    bool is_conf = true;
+    for (int i = 0; i < P.nscales; ++i) {
+        const Scale& Q = P.s[i];
+        if (bid >= Q.conf_blk0 && bid < Q.conf_blk0 + Q.conf_nblk) { si = i; is_conf = true; }
+        if (bid >= Q.obj_blk0 && bid < Q.obj_blk0 + P.nT) { si = i; is_conf = false; }
+    }
+    const Scale& S = P.s[si];
+    const int G = S.G, A = S.A, G2 = S.G2;
+    const int own = is_conf ? -1 : bid - S.obj_blk0;
+    if (tid < ODPL_MAX_ANCHORS) { s_aw[tid] = S.aw[tid]; s_ah[tid] = S.ah[tid]; }
+    if (tid == 0) { s_flags = 0; s_cnt[0] = s_cnt[1] = 0; s_rank = 0; }
+    if (tid < 8) s_bits[tid] = 0u;
+    int c0 = 0, cn = 0;
+    ConfIn cin; cin.ok = false;
+    if (is_conf) {
+        cin = conf_load(P, S, bid - S.conf_blk0);       // 1. in flight while the rows are decoded
+        conf_range(S, bid - S.conf_blk0, c0, cn);
+        for (int i = tid; i < 4 * kConfThreads; i += kConfThreads) lstate[i] = -1;
+    }
+    for (int t = nT + tid; t < ((nT + 3) & ~3); t += kConfThreads) T.pos[t] = -2;      // pad the scan's last vector (matches nothing)
+    const int npos = B * G2;
+    const bool use_bm = npos <= 32 * kBmWords;
+    if (use_bm) for (int i = tid; i < (npos + 31) >> 5; i += kConfThreads) { bm_seen[i] = 0u; bm_twice[i] = 0u; }
+    __syncthreads();
+    // 2. decode; flags as yolo_assign_kernel's first pass
+    int flags = 0;
+    for (int t = tid; t < nT; t += kConfThreads) {
+        const TDec d = decode_target(P.target + (size_t)t * 6, G, A, s_aw, s_ah, P.ignore_thres);
+        flags |= ((d.b >= B) | (d.best >= A) | (d.gj >= G) | (d.gi >= G)) ? 1 : 0;      // accuracy.py:340-343
+        flags |= (d.lab >= C) ? 2 : 0;                                                   // accuracy.py:365
+        flags |= ((d.b < -B) | (d.gj < -G) | (d.gi < -G) | (d.lab < -C)) ? 4 : 0;
+        long long b = d.b, gj = d.gj, gi = d.gi, lab = d.lab;
+        const bool upper_ok = (d.b < B) & (d.gj < G) & (d.gi < G);                       // accuracy.py:354-356
+        const bool ok = wrap_idx(b, B) & wrap_idx(gj, G) & wrap_idx(gi, G);
+        const int pp = ok ? (int)((b * G + gj) * G + gi) : -1;
+        T.pos[t] = pp;
+        if (use_bm && pp >= 0 && ((atomicOr(&bm_seen[pp >> 5], 1u << (pp & 31)) >> (pp & 31)) & 1u)) atomicOr(&bm_twice[pp >> 5], 1u << (pp & 31));
+        T.meta[t] = (unsigned)d.best | ((ok && upper_ok) ? (d.over & 0xffu) << 8 : 0u) | (ok ? 1u << 16 : 0u);
+        T.lab[t] = wrap_idx(lab, C) ? (int)lab : -1;
+        if (t == own) {
+            s_rec[0] = d.gx - floorf(d.gx); s_rec[1] = d.gy - floorf(d.gy);              // accuracy.py:368-372
+            s_rec[2] = logf(d.gw / s_aw[d.best] + 1e-16f); s_rec[3] = logf(d.gh / s_ah[d.best] + 1e-16f);
+        }
+    }
+    if (flags) atomicOr(&s_flags, flags);
+    __syncthreads();
+    flags = s_flags;
+    const int g1 = flags & 1 ? 1 : 0, g2 = (flags & 3) ? 1 : 0, st = flags & 4 ? 1 : 0;
+    // 3. one scan of the table per own row
+    int n_win = 0, n_new = 0;
+    for (int t = tid; t < nT; t += kConfThreads) {
+        const int p = T.pos[t];
+        unsigned m = T.meta[t];
+        if (g1) m &= ~(1u << 16);                       // accuracy.py:344-346: one bad row switches every obj touch off
+        const unsigned best = m & 7u, over = (m >> 8) & 0xffu;
+        bool later_same = false;
+        // anchors with an obj touch on this position (any row; the row itself first) / an ignore touch by an earlier row
+        unsigned obj_here = ((m >> 16) & 1u) ? 1u << best : 0u, ign_before = 0u;
+        auto other = [&](int u) {                       // another row on the same position: rare
+            const unsigned mu = T.meta[u];
+            const bool objv = !g1 && ((mu >> 16) & 1u);
+            if (objv) { obj_here |= 1u << (mu & 7u); later_same |= (u > t) && (mu & 7u) == best; }
+            if (u < t) ign_before |= (mu >> 8) & 0xffu;
+        };
+        if (p >= 0 && !(use_bm && !((bm_twice[p >> 5] >> (p & 31)) & 1u))) {
+            // four position keys per LDS read, no dependent branch in the common case (a data-dependent `continue` per key cost one
+            // LDS round trip per row: 5 us at 112 rows); positions are unique but for duplicates, which take the branch
+            const int4* pos4 = reinterpret_cast<const int4*>(T.pos);
+            const int n4 = (nT + 3) >> 2;
+#pragma unroll 4
+            for (int u4 = 0; u4 < n4; ++u4) {
+                const int4 q = pos4[u4];
+                const int u = u4 * 4;
+                if (((q.x == p) & (u != t)) | ((q.y == p) & (u + 1 != t)) | ((q.z == p) & (u + 2 != t)) | ((q.w == p) & (u + 3 != t))) {
+                    if (q.x == p && u != t) other(u);
+                    if (q.y == p && u + 1 != t) other(u + 1);
+                    if (q.z == p && u + 2 != t) other(u + 2);
+                    if (q.w == p && u + 3 != t) other(u + 3);
+                }
+            }
+        }
+        const bool win = p >= 0 && ((m >> 16) & 1u) && !later_same;
+        if (win) m |= 1u << 17;
+        T.meta[t] = m;
+        n_win += win;
+        n_new += __popc(over & ~obj_here & ~ign_before);
+    }
+    n_win = wave_sum_i(n_win); n_new = wave_sum_i(n_new);
+    if ((tid & 63) == 0 && (n_win | n_new)) { atomicAdd(&s_cnt[0], n_win); atomicAdd(&s_cnt[1], n_new); }     // integer adds: order-free
+    __syncthreads();
+    const int nObj = s_cnt[0], nNoobj = B * A * G2 - (s_cnt[0] + s_cnt[1]);
+    if (is_conf) {
+        if (bid == S.conf_blk0 && tid == 0) {           // one workgroup per scale publishes the counts (finalize, out_counts)
+            S.counts[0] = nObj; S.counts[1] = nNoobj; S.counts[2] = g1; S.counts[3] = g2; S.counts[4] = st;
+            S.counts[5] = S.counts[6] = S.counts[7] = 0;
+        }
+        // 4a. the touches that land in this workgroup's cells
+        for (int t = tid; t < nT; t += kConfThreads) {
+            const int p = T.pos[t];
+            if (p < 0) continue;
+            const unsigned m = T.meta[t];
+            const int b = p / G2, s = p - b * G2;
+            unsigned touch = (m >> 8) & 0xffu;          // ignore touches: state 0
+            const unsigned objbit = ((m >> 16) & 1u) ? 1u << (m & 7u) : 0u;
+            touch |= objbit;
+            while (touch) {
+                const int a = __ffs(touch) - 1; touch &= touch - 1;
+                const int cell = S.layout == ODPL_LAYOUT_PLANAR ? (b * A + a) * G2 + s : (b * G2 + s) * A + a;
+                if (cell >= c0 && cell < c0 + cn) atomicMax(&lstate[cell - c0], (objbit >> a) & 1u ? 1 : 0);
+            }
+        }
+        __syncthreads();
+        conf_finish(P, S, bid - S.conf_blk0, cin, sh, lstate, nObj, nNoobj);
+        return;
+    }
+    // 4b. obj workgroup of row `own`
+    const unsigned mo = T.meta[own];
+    const bool win = (mo >> 17) & 1u;
+    const int po = T.pos[own];
+    int cell = -1, rkey_own = 0;
+    if (win) {
+        const int b = po / G2, s = po - b * G2, a = (int)(mo & 7u);
+        cell = S.layout == ODPL_LAYOUT_PLANAR ? (b * A + a) * G2 + s : (b * G2 + s) * A + a;
+        rkey_own = (b * A + a) * G2 + s;                // raster order of pred_boxes[obj_mask]: (b, a, j, i) ascending (losses.py:568)
+        int below = 0;
+        for (int u = tid; u < nT; u += kConfThreads) {
+            const unsigned mu = T.meta[u];
+            const int pu = T.pos[u];
+            if (pu < 0) continue;
+            if ((mu >> 17) & 1u) { const int bu = pu / G2, su = pu - bu * G2; below += ((bu * A + (int)(mu & 7u)) * G2 + su) < rkey_own; }
+            // class bits: every row that sits on the winner's cell (valid obj touch) sets its label (accuracy.py:374, multi-hot)
+            if (!g2 && pu == po && ((mu >> 16) & 1u) && (mu & 7u) == (mo & 7u) && T.lab[u] >= 0) atomicOr(&s_bits[T.lab[u] >> 5], 1u << (T.lab[u] & 31));
+        }
+        below = wave_sum_i(below);
+        if ((tid & 63) == 0 && below) atomicAdd(&s_rank, below);
+    }
+    if (tid == 0) S.tcell[own] = cell;
+    if (win && g2 && tid < 4) s_rec[tid] = 0.f;         // guard 2: tx..th stay zero (accuracy.py:365-372 skipped)
+    __syncthreads();
+    obj_block(P, S, own, cell, s_rec, s_bits, s_rank, nObj, sh, sh_bc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -664,6 +883,17 @@ int run_forward(const odpl_yolo_loss_desc_t* d, const Plan& pl, void* workspace,
     int nblk = 0;
     for (int i = 0; i < d->nscales; ++i) { P.s[i].conf_blk0 = nblk; nblk += P.s[i].conf_nblk; }     // confidence blocks first
     for (int i = 0; i < d->nscales; ++i) { P.s[i].obj_blk0 = nblk; nblk += d->nT; }
+    if (d->nT <= g_fused_max_t && d->nT <= kFusedMaxT && d->C <= 256) {      // one launch, no state map (left as it is: still clean if it was)
+        prof_begin(ODPL_PROF_YOLO_LOSS, stream);
+        hipLaunchKernelGGL(yolo_fused_kernel, dim3(nblk), dim3(kConfThreads), 0, stream, P);
+        prof_end(ODPL_PROF_YOLO_LOSS, stream);
+        ODPL_HIP_TRY(hipGetLastError());
+        prof_begin(ODPL_PROF_YOLO_FINALIZE, stream);
+        hipLaunchKernelGGL(yolo_finalize_kernel, dim3(1), dim3(64 * ODPL_MAX_SCALES), 0, stream, P);
+        prof_end(ODPL_PROF_YOLO_FINALIZE, stream);
+        ODPL_HIP_TRY(hipGetLastError());
+        return 0;
+    }
     if (!(d->flags & ODPL_YOLO_STATE_CLEAN)) ODPL_HIP_TRY(odpl::fill_bytes(workspace, 0xFF, pl.state_bytes_total, stream));
     prof_begin(ODPL_PROF_YOLO_ASSIGN, stream);
     hipLaunchKernelGGL(yolo_assign_kernel, dim3(d->nscales), dim3(kAssignThreads), 0, stream, P);
@@ -779,6 +1009,7 @@ extern "C" int odpl_tune_set(int32_t key, int32_t value) {
         case ODPL_TUNE_BN_STREAM_MAX_BLOCKS: if (value != 0 && (value < 64 || value > (1 << 20))) return ODPL_EINVAL; odpl::g_bn_stream_max_blocks = value; return 0;
         case ODPL_TUNE_BN_MAX_ROWS_PER_TILE: if (value < 16 || value > (1 << 16)) return ODPL_EINVAL; odpl::g_bn_max_rows_per_tile = value; return 0;
         case ODPL_TUNE_BN_SLICE_FROM_C: if (value < 4) return ODPL_EINVAL; odpl::g_bn_slice_from_c = value; return 0;
+        case ODPL_TUNE_YOLO_FUSED_MAX_TARGETS: if (value < 0) return ODPL_EINVAL; g_fused_max_t = value > kFusedMaxT ? kFusedMaxT : value; return 0;
         default: return ODPL_EINVAL;
     }
 }

@@ -83,11 +83,15 @@ class Trainer:
                  num_sanity_val_steps=2, auto_lr_find=False, auto_scale_batch_size=False, device=None, accelerator=None,
                  num_processes=1, ddp_impl="bucketed", checkpoint_callback=True, benchmark=False, **_ignored):
         # PL's `benchmark` flag (Trainer(benchmark=True) -> torch.backends.cudnn.benchmark): on ROCm that is MIOpen's solver search --
-        # minutes on the first steps of a fresh machine, then 20-40 % faster convolutions than its immediate mode on these networks
-        # (YOLOv4, RetinaNet and YOLOv5 steps with and without).  Default as PL's: off.
+        # minutes on the first steps of a fresh machine, re-measured in every process.  Default as PL's: off, i.e. MIOpen's immediate
+        # mode -- which, on the committed find-db (miopen.py), picks the search's solvers for the BASELINE networks without searching
+        # (profiles/r04_immediate_vs_find.jsonl); for a network the db does not cover the search is 20-40 % faster than the fallback ranking.
         self.benchmark = bool(benchmark)
         if self.benchmark:
             torch.backends.cudnn.benchmark = True
+        if not (accelerator == "ddp_cpu" or (device is not None and torch.device(device).type == "cpu")):
+            from . import miopen
+            miopen.stage_user_db()          # immediate mode then picks the solvers recorded in miopen_db/: every rank alike, no search
         self.max_epochs, self.min_epochs = int(max_epochs), int(min_epochs)
         self.limits = dict(train=limit_train_batches, val=limit_val_batches, test=limit_test_batches)
         self.accumulate = max(1, int(accumulate_grad_batches))

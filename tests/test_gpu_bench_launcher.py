@@ -26,3 +26,14 @@ def test_bench_self_launches_two_ranks():
     assert d["value"] > 0 and d["scaling"] == "weak"
     assert d["allreduce"]["bytes"] == 4 * 64363101 and d["allreduce"]["bus_GBps"] > 0       # 64.363 M parameters
     assert d["roofline"]["launches"] == 2
+    # what a poor N-GPU number would be made of: every rank's own step and host-enqueue time, and the part of the
+    # gradient exchange that backward did not hide (step - the same step inside no_sync(), same process)
+    pr = d["per_rank"]
+    assert len(pr["by_rank_ms_per_step"]) == 2 and all(v > 0 for v in pr["by_rank_ms_per_step"])
+    for k in ("ms_per_step", "host_enqueue_ms_per_step"):
+        assert 0 < pr[k]["min"] <= pr[k]["median"] <= pr[k]["max"]
+    assert pr["ms_per_step"]["max"] <= d["ms_per_step"] * 1.001 + 1e-3            # the headline is the slowest rank's clock
+    assert isinstance(d["exposed_comm_ms"], float) and d["exposed_comm"]["step_ms"] > 0 and d["exposed_comm"]["step_without_exchange_ms"] > 0
+    assert d["config"]["miopen"].startswith("immediate mode")                    # one solver choice for every rank: no per-rank search
+    assert "secondary" not in d and "cpu_baseline" not in d                      # N = 1 only
+    assert d["loss_path"]["budget_us"] == 20.7 and d["loss_path"]["live_sum_us"] > 0

@@ -265,7 +265,16 @@ def test_dirty_workspace_is_flagged_and_never_indexes_out_of_bounds():
     """a caller that breaks the STATE_CLEAN promise (a stale / garbage state map) must not make the
     kernels index with it.  The map is filled with large positive owners and the call is told it is clean: status bit 1
     comes back, nothing faults, every output is finite memory; the next honest call is correct again."""
+    from objectdetectionpl_amd import _lib
     from objectdetectionpl_amd.LightningFunc.losses import MultiScaleRegionLoss_v4
+    _lib.tune_set("yolo_fused_max_targets", 0)                  # the state map is the assign launch's: up to 512 rows the fused launch needs none
+    try:
+        _dirty_workspace_body(MultiScaleRegionLoss_v4)
+    finally:
+        _lib.tune_set("yolo_fused_max_targets", 512)
+
+
+def _dirty_workspace_body(MultiScaleRegionLoss_v4):
     heads, tgt = _config2_inputs()
     d = dev()
     crit = MultiScaleRegionLoss_v4(V4_ANCHORS, V4_MASKS, "bce_loss", "smooth_l1_loss", "bce_loss", 80, 416)
@@ -321,3 +330,96 @@ def test_one_call_c_abi_entry_still_produces_dense_gradients():
     assert out7[0].item() == ref["loss"].item()
     for g, h in zip(grads, hs):
         assert torch.equal(g, h.grad)
+
+
+def _run_both_paths(make_crit, heads, tgt, channels_last=False):
+    """the criterion once through the fused launch (assignment + loss, <= 512 rows) and once through assign launch + loss launch"""
+    from objectdetectionpl_amd import _lib
+    d = dev()
+    res = []
+    for fused_max in (512, 0):
+        _lib.tune_set("yolo_fused_max_targets", fused_max)
+        try:
+            crit = make_crit()
+            hs = [(h.to(d).contiguous(memory_format=torch.channels_last) if channels_last else h.to(d)).requires_grad_() for h in heads]
+            out = crit(hs, tgt.to(d))
+            out["loss"].backward()
+            torch.cuda.synchronize()
+            res.append(({k: v.detach().clone() for k, v in out.items()}, [h.grad.clone() for h in hs], crit.last_counts.clone()))
+        finally:
+            _lib.tune_set("yolo_fused_max_targets", 512)
+    return res
+
+
+def _assert_same_bits(a, b):
+    (oa, ga, ca), (ob, gb, cb) = a, b
+    assert torch.equal(ca, cb), (ca, cb)                                           # nObj, nNoobj, guards, status: integers
+    for k in oa:
+        assert torch.equal(oa[k], ob[k]) or (torch.isnan(oa[k]).all() and torch.isnan(ob[k]).all()), (k, oa[k], ob[k])
+    for x, y in zip(ga, gb):
+        assert torch.equal(torch.isnan(x), torch.isnan(y))
+        assert torch.equal(torch.nan_to_num(x), torch.nan_to_num(y))
+
+
+@pytest.mark.parametrize("coord,cls", [("smooth_l1_loss", "bce_loss"), ("mse_loss", "ce_loss")])
+@pytest.mark.parametrize("case", ["plain", "dup", "oor", "lab", "empty", "neg"])
+def test_fused_launch_equals_assign_plus_loss_bit_for_bit(golden, coord, cls, case):
+    """[r4] Up to 512 target rows the assignment runs INSIDE the loss launch (every workgroup derives guards, winners, counts and the
+    state of its own cells from the rows in LDS): same integers, same partial sums, same gradient bits as the assign launch + loss
+    launch over the global state map -- on every edge case of the golden set (duplicates on a cell, out-of-range rows, labels >= C,
+    no rows, negative indices)."""
+    from objectdetectionpl_amd.LightningFunc.losses import MultiScaleRegionLoss_v4
+    g = golden("yolo_loss")
+    heads = [T(g[f"v4_head{i}"]) for i in range(3)]
+    tgt = T(g[f"v4_{coord}_{cls}_{case}_target"])
+    a, b = _run_both_paths(lambda: MultiScaleRegionLoss_v4(V4_ANCHORS, V4_MASKS, cls, coord, "bce_loss", 4, 416), heads, tgt)
+    _assert_same_bits(a, b)
+
+
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_fused_launch_equals_assign_plus_loss_at_config2(channels_last):
+    from objectdetectionpl_amd.LightningFunc.losses import MultiScaleRegionLoss_v4
+    heads, tgt = _config2_inputs()
+    # crowd it: rows repeated on the same cells with other labels (multi-hot bits, last row wins) and boxes matching several anchors
+    extra = tgt[:40].clone()
+    extra[:, 1] = (extra[:, 1] + 17) % 80
+    extra2 = tgt[10:30].clone()
+    extra2[:, 4:6] *= 0.9
+    tgt = torch.cat([tgt, extra, extra2], 0)
+    a, b = _run_both_paths(lambda: MultiScaleRegionLoss_v4(V4_ANCHORS, V4_MASKS, "bce_loss", "smooth_l1_loss", "bce_loss", 80, 416), heads, tgt,
+                           channels_last)
+    _assert_same_bits(a, b)
+    assert int(a[2][:, 0].sum()) > 0
+
+
+def test_fused_launch_limit_falls_back_to_the_state_map_path():
+    """more rows than the LDS tables hold (512): the call takes assign launch + loss launch; 600 rows vs the CPU oracle"""
+    from objectdetectionpl_amd.LightningFunc.losses import MultiScaleRegionLoss_v4
+    gen = torch.Generator().manual_seed(5)
+    B, C, n = 4, 6, 600
+    heads = [torch.randn(B, 3 * (5 + C), G, G, generator=gen) for G in (52, 26, 13)]
+    wh = torch.rand(n, 2, generator=gen) * 0.4 + 0.03
+    tgt = torch.cat([torch.randint(0, B, (n, 1), generator=gen).float(), torch.randint(0, C, (n, 1), generator=gen).float(),
+                     torch.rand(n, 2, generator=gen) * (1 - wh), wh], 1)
+    d = dev()
+    crit = MultiScaleRegionLoss_v4(V4_ANCHORS, V4_MASKS, "bce_loss", "smooth_l1_loss", "bce_loss", C, 416)
+    hs = [h.to(d).requires_grad_() for h in heads]
+    out = crit(hs, tgt.to(d))
+    out["loss"].backward()
+    rh = [h.clone().requires_grad_() for h in heads]
+    ref = oracle_yolo.multiscale_region_loss_v4(rh, tgt, V4_ANCHORS, V4_MASKS, C, 416)
+    ref["loss"].backward()
+    _check_dict(out, {k: v.detach().numpy() for k, v in ref.items()})
+    for h, r in zip(hs, rh):
+        _check_grad(h.grad, r.grad.numpy())
+    # ... and 500 rows (the fused launch with two rows per thread) against the same oracle
+    tgt2 = tgt[:500]
+    hs2 = [h.to(d).requires_grad_() for h in heads]
+    out2 = crit(hs2, tgt2.to(d))
+    out2["loss"].backward()
+    rh2 = [h.clone().requires_grad_() for h in heads]
+    ref2 = oracle_yolo.multiscale_region_loss_v4(rh2, tgt2, V4_ANCHORS, V4_MASKS, C, 416)
+    ref2["loss"].backward()
+    _check_dict(out2, {k: v.detach().numpy() for k, v in ref2.items()})
+    for h, r in zip(hs2, rh2):
+        _check_grad(h.grad, r.grad.numpy())

@@ -19,6 +19,61 @@ class Args:
     type = "Yolov5l"; lr = 1e-3; weight_decay = 1e-5
 
 
+def run(dtype="bf16", batch=32, img=640, steps=10, warmup=3, type_="Yolov5l", miopen_find=False, log=None):
+    """One measurement on cuda:0 with the class switches as they are set (bench.py's `secondary` leg calls this in-process)."""
+    from objectdetectionpl_amd import _lib
+    dev = torch.device("cuda:0")
+    prev_bench = torch.backends.cudnn.benchmark
+    torch.backends.cudnn.benchmark = bool(miopen_find)
+    try:
+        torch.manual_seed(0)
+        Args.type = type_
+        model = YOLOv5([str(i) for i in range(80)], Args()).to(dev).to(memory_format=torch.channels_last).train()
+        model.img_size = img
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5, fused=True)
+        g = torch.Generator().manual_seed(1)
+        x = torch.rand(batch, 3, img, img, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+        n = batch * 7
+        wh = torch.rand(n, 2, generator=g) * 0.48 + 0.02
+        y = torch.cat([torch.arange(batch).repeat_interleave(7).float()[:, None], torch.randint(0, 80, (n, 1), generator=g).float(),
+                       torch.rand(n, 2, generator=g) * (1 - wh), wh], 1).to(dev)
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == "bf16"):
+                out = model(x)
+            d = model.criterion(out, y)
+            d["loss"].backward()
+            opt.step()
+            return d, out
+
+        t0 = time.perf_counter()
+        for i in range(warmup):
+            d, out = step()
+            torch.cuda.synchronize()
+            msg = f"[{time.perf_counter() - t0:6.1f}s] config 5 warmup {i + 1}/{warmup}"
+            log(msg) if log else print(msg, file=sys.stderr, flush=True)
+        PROF = ("yolov5_obj", "yolov5_dense", "headgrad_stream", "headgrad_finish")
+        for k in PROF:
+            _lib.profile_enable(k, True)
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            d, out = step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / steps
+        kern = {}
+        for k in PROF:
+            _lib.profile_enable(k, False)
+            ms = _lib.profile_collect(k)[0]
+            if ms:
+                kern[k + "_us"] = round(1e3 * sum(ms) / len(ms), 2)
+        return {"workload": f"{type_} {img}x{img} bs={batch} training step, convs {dtype}", "img_per_s": round(batch / dt, 1),
+                "ms_per_step": round(dt * 1e3, 2), "head_dtype": str(out[0].dtype), "loss": round(float(d["loss"].detach()), 4),
+                "miopen_find": bool(miopen_find), "head_contiguous": bool(out[0].is_contiguous()), **kern}
+    finally:
+        torch.backends.cudnn.benchmark = prev_bench
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
@@ -34,8 +89,6 @@ def main():
     ap.add_argument("--no-upsample-cat", action="store_true", help="A/B: neck merges as upsample followed by torch.cat")
     ap.add_argument("--no-bn-of-cat", action="store_true", help="A/B: BottleneckCSP with torch.cat before its BatchNorm (the reference's op sequence)")
     a = ap.parse_args()
-    dev = torch.device("cuda:0")
-    from objectdetectionpl_amd import _lib
     from objectdetectionpl_amd.LightningFunc.losses_dense import MultiScaleRegionLoss_v5
     from objectdetectionpl_amd.LightningFunc.utils.headconv import HeadConv2d
     from objectdetectionpl_amd.model.YOLOV5 import Yolo_Layers
@@ -46,50 +99,7 @@ def main():
     _bnact_mod.bn_of_cat_enabled = not a.no_bn_of_cat
     from objectdetectionpl_amd.LightningFunc.utils import upsample as _up_mod
     _up_mod.cat_enabled = not a.no_upsample_cat
-    torch.backends.cudnn.benchmark = bool(a.miopen_find)
-    torch.manual_seed(0)
-    Args.type = a.type
-    model = YOLOv5([str(i) for i in range(80)], Args()).to(dev).to(memory_format=torch.channels_last).train()
-    model.img_size = a.img
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5, fused=True)
-    g = torch.Generator().manual_seed(1)
-    x = torch.rand(a.batch, 3, a.img, a.img, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
-    n = a.batch * 7
-    wh = torch.rand(n, 2, generator=g) * 0.48 + 0.02
-    y = torch.cat([torch.arange(a.batch).repeat_interleave(7).float()[:, None], torch.randint(0, 80, (n, 1), generator=g).float(),
-                   torch.rand(n, 2, generator=g) * (1 - wh), wh], 1).to(dev)
-
-    def step():
-        opt.zero_grad(set_to_none=True)
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=a.dtype == "bf16"):
-            out = model(x)
-        d = model.criterion(out, y)
-        d["loss"].backward()
-        opt.step()
-        return d, out
-
-    t0 = time.perf_counter()
-    for i in range(a.warmup):
-        d, out = step()
-        torch.cuda.synchronize()
-        print(f"[{time.perf_counter() - t0:6.1f}s] warmup {i + 1}/{a.warmup}", file=sys.stderr, flush=True)
-    PROF = ("yolov5_obj", "yolov5_dense", "headgrad_stream", "headgrad_finish")
-    for k in PROF:
-        _lib.profile_enable(k, True)
-    t1 = time.perf_counter()
-    for _ in range(a.steps):
-        d, out = step()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t1) / a.steps
-    kern = {}
-    for k in PROF:
-        _lib.profile_enable(k, False)
-        ms = _lib.profile_collect(k)[0]
-        if ms:
-            kern[k + "_us"] = round(1e3 * sum(ms) / len(ms), 2)
-    print(json.dumps({"workload": f"{a.type} {a.img}x{a.img} bs={a.batch} training step, convs {a.dtype}", "img_per_s": round(a.batch / dt, 1),
-                      "ms_per_step": round(dt * 1e3, 2), "head_dtype": str(out[0].dtype), "loss": round(float(d["loss"].detach()), 4),
-                      "miopen_find": bool(a.miopen_find), "head_contiguous": bool(out[0].is_contiguous()), **kern}))
+    print(json.dumps(run(a.dtype, a.batch, a.img, a.steps, a.warmup, a.type, a.miopen_find)))
 
 
 if __name__ == "__main__":
