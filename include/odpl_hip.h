@@ -454,8 +454,11 @@ typedef struct {
     int32_t nscales, B, A, no;            /* no = 5 + C ("answers", YOLOV4.py:240) */
     float conf_thres;                     /* -0.0151: YOLOV4.py:228 overwrites the argument */
     float nms_thres;                      /* 0.4 */
-    int32_t flags;
+    int32_t flags;                        /* ODPL_YOLO_NMS_ONE_WORKGROUP or 0 */
 } odpl_yolo_nms_desc_t;
+/* flags: keep the one-workgroup-per-image kernel also for networks with >= 8 classes (default there: class histogram -> one
+ * workgroup per (image, class) -> rank order of the surviving rows; same output) */
+#define ODPL_YOLO_NMS_ONE_WORKGROUP 1
 
 size_t odpl_yolo_nms_workspace_bytes(const odpl_yolo_nms_desc_t* desc);
 /*

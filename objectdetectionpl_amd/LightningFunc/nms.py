@@ -19,11 +19,12 @@ def _workspace(tag, dev, need):
     return ws, True
 
 
-def yolo_non_max_suppression(predictions, conf_thres=-0.0151, nms_thres=0.4, num_anchors=3):
+def yolo_non_max_suppression(predictions, conf_thres=-0.0151, nms_thres=0.4, num_anchors=3, one_workgroup=False):
     """model/YOLOV4.py:221-283.  `predictions`: a raw head tensor or a list of them, [B, A*(5+C), G, G]
     (YOLOv5: [B, 3, G, G, 5+C], whose memory the reference reinterprets as [B, 3, 5+C, G, G]).
     The reference overwrites conf_thres with -0.0151 whatever the caller passes (YOLOV4.py:228).
-    Returns List[Optional[Tensor[K,7]]] = (x1, y1, x2, y2, object_conf, class_score, class_pred)."""
+    Returns List[Optional[Tensor[K,7]]] = (x1, y1, x2, y2, object_conf, class_score, class_pred).
+    one_workgroup: A/B switch -- keep the one-workgroup-per-image kernel where the class-split pipeline is the default (>= 8 classes)."""
     if not isinstance(predictions, (list, tuple)):
         predictions = [predictions]
     _lib.require_cuda(*predictions)
@@ -50,7 +51,7 @@ def yolo_non_max_suppression(predictions, conf_thres=-0.0151, nms_thres=0.4, num
     N = sum(A * h.shape[2] * h.shape[2] if h.dim() == 4 else A * h.shape[2] * h.shape[3] for h in heads)
     out = torch.empty(d.B, N, 7, dtype=torch.float32, device=dev)
     counts = torch.empty(d.B, dtype=torch.int32, device=dev)
-    d.flags = 0
+    d.flags = _lib.YOLO_NMS_ONE_WORKGROUP if one_workgroup else 0
     _lib.check(L.odpl_yolo_nms(ctypes.byref(d), _lib.ptr(ws), ws.numel(), _lib.ptr(out), _lib.ptr(counts),
                                _lib.current_stream(dev)), "odpl_yolo_nms")
     ks = counts.tolist()          # the list-of-tensors API has data-dependent shapes: one sync, as in the reference

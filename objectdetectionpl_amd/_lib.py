@@ -277,6 +277,7 @@ def require_cuda(*tensors):
 
 
 YOLO_STATE_CLEAN = 1
+YOLO_NMS_ONE_WORKGROUP = 1
 RETINA_STATE_CLEAN = 1
 RETINA_ROWS_ONLY = 2
 RETINA_ASSIGN_ONLY = 4

@@ -44,6 +44,14 @@ struct YParams {
     float4* sbox; float* sconf; float* scconf; int* slabel;
     float* key; unsigned* idx;           // [B*Npad] sort buffers
     float* out; int* out_counts;
+    // [r4] class-split pipeline (bucket -> class -> order)
+    int* cls_off; int* cls_cnt;          // [B*kMaxCls] first slot / number of valid candidates of each class
+    int* nvalid;                         // [B]
+    int* ktot;                           // [B*kKtotPitch] rows kept so far per image: every class reserves a run of the compact kept list
+    int* ksrc;                           // [B*Npad] compact kept list: the row's slot in krow (kkey / kidx: its pivot's score / candidate)
+    float* ckey; unsigned* cidx;         // [B*Npad] (score, candidate) pairs grouped by class
+    float* kkey; unsigned* kidx;         // [B*Npad] compact kept list: (score, candidate) of every kept pivot, class runs in arrival order
+    float* krow;                         // [B*N*7] merged rows: class c's rows at the front of the class's own slots cls_off[c] ..
 };
 
 // A workgroup = 256 / SPLIT consecutive candidates; thread group q scans classes [q*nc/SPLIT, (q+1)*nc/SPLIT).  Lanes run
@@ -182,9 +190,10 @@ constexpr int kRegE = 4;               // register-resident class lists: up to 6
 
 __device__ __forceinline__ void bitonic_sort_lds(float* key, unsigned* idx, int npad) {
     for (int k = 2; k <= npad; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int lj = __ffs(k) - 2; lj >= 0; --lj) {            // j = 2^lj: shifts and masks instead of run-time divisions
+            const int j = 1 << lj;
             for (int t = threadIdx.x; t < npad / 2; t += kImgT) {
-                const int i = ((t / j) * 2 * j) + (t % j), l = i + j;
+                const int i = ((t >> lj) << (lj + 1)) + (t & (j - 1)), l = i + j;
                 const bool up = ((i & k) == 0);
                 const float ki = key[i], kl = key[l];
                 const unsigned ii = idx[i], il = idx[l];
@@ -400,10 +409,401 @@ __global__ __launch_bounds__(kImgT) void yolo_nms_image_kernel(const YParams P) 
     if (tid == 0) P.out_counts[b] = K;
 }
 
+// =================================================================================================
+// [r4] The same NMS split across the chip (networks with >= kSplitMinCls classes).  One workgroup per image left 240 of 256 CUs
+// idle and spent most of its time in a 91-stage LDS bitonic sort of ~5 000 keys.  But a pivot only ever removes boxes of ITS
+// class (YOLOV4.py:271-274), so no global order is needed before the loops -- only inside each class -- and the reference's output
+// order (pivots in rank order) is a sort of the ~1 000 rows that survive:
+//   bucket (1 WG / image)        LDS class histogram + scan, (score, candidate) pairs scattered into class-contiguous segments
+//   class  (1 WG / image, class) sorts its segment by (score desc, candidate asc) -- <= 256 entries: one wave, LDS bitonic network,
+//                                the pivot loop with the list in registers (the loop of yolo_nms_image_kernel, same sums in the same
+//                                order); longer segments: rank by counting + a workgroup-wide sweep per pivot -- and appends each
+//                                merged row at the front of the class's own slots and, with ONE integer add per class, its pivots'
+//                                (score, candidate, slot) as a run of the image's compact kept list
+//   order  (64 rows / WG)        the rank of every kept row's (score, candidate) among the image's kept rows, all pairs by ballot +
+//                                popcount; copies the rows out
+// (score desc, candidate asc) is a strict total order: the output does not depend on which class finished first.
+constexpr int kSplitMinCls = 8;        // below this many classes segments are long and the single-workgroup kernel is the better shape
+constexpr int kClsT = 256;
+constexpr int kKtotPitch = 64;         // one counter per 256-B line: agent-scope atomics on one line are served one at a time
+
+constexpr int kBkU = 16;              // candidates per thread held in registers between the two passes (16 384 per image; more: chunks)
+
+__global__ __launch_bounds__(kImgT) void yolo_nms_bucket_kernel(const YParams P) {
+    __shared__ int s_cnt[kMaxCls], s_off[kMaxCls], s_cur[kMaxCls];
+    __shared__ int s_wtot[kImgT / 64];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nc = P.no - 5;
+    const float* key = P.key + (size_t)b * P.Npad;
+    const unsigned* idx = P.idx + (size_t)b * P.Npad;
+    const int* label = P.label + (size_t)b * P.N;
+    for (int c = tid; c < kMaxCls; c += kImgT) { s_cnt[c] = 0; s_cur[c] = 0; }
+    // every load of the first chunk is requested before anything is consumed: one trip to memory instead of one per iteration
+    // (the loop with its LDS atomics in between took 16 us for 11 iterations); an invalid candidate carries label -1
+    int lab[kBkU]; float ky[kBkU];
+#pragma unroll
+    for (int u = 0; u < kBkU; ++u) {
+        const int n = tid + u * kImgT, nn = n < P.N ? n : P.N - 1;
+        const unsigned id = idx[nn];
+        const int l = label[nn];
+        ky[u] = key[nn];
+        lab[u] = (n < P.N && id != 0xffffffffu) ? l : -1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kBkU; ++u) if (lab[u] >= 0) atomicAdd(&s_cnt[lab[u]], 1);
+    for (int n = tid + kBkU * kImgT; n < P.N; n += kImgT) if (idx[n] != 0xffffffffu) atomicAdd(&s_cnt[label[n]], 1);
+    __syncthreads();
+    {   // exclusive scan of the class counts (kMaxCls == kImgT: one class per thread)
+        const int c = s_cnt[tid];
+        int inc = c;
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+        if (lane == 63) s_wtot[wv] = inc;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wv; ++w) woff += s_wtot[w];
+        s_off[tid] = woff + inc - c;
+        if (tid < nc) { P.cls_off[(size_t)b * kMaxCls + tid] = woff + inc - c; P.cls_cnt[(size_t)b * kMaxCls + tid] = c; }
+        if (tid == kImgT - 1) {
+            const int nv = woff + inc;
+            P.nvalid[b] = nv; P.ktot[(size_t)b * kKtotPitch] = 0;
+            if (nv == 0) P.out_counts[b] = -1;                  // "continue": output[image_i] stays None
+        }
+        __syncthreads();
+    }
+    float* ckey = P.ckey + (size_t)b * P.Npad;
+    unsigned* cidx = P.cidx + (size_t)b * P.Npad;
+#pragma unroll
+    for (int u = 0; u < kBkU; ++u) if (lab[u] >= 0) {
+        const int slot = s_off[lab[u]] + atomicAdd(&s_cur[lab[u]], 1);   // any order inside the segment: the class kernel sorts it
+        ckey[slot] = ky[u]; cidx[slot] = (unsigned)(tid + u * kImgT);
+    }
+    for (int n = tid + kBkU * kImgT; n < P.N; n += kImgT) if (idx[n] != 0xffffffffu) {
+        const int l = label[n];
+        const int slot = s_off[l] + atomicAdd(&s_cur[l], 1);
+        ckey[slot] = key[n]; cidx[slot] = (unsigned)n;
+    }
+}
+
+// one merged row of image b at slot `slot` of krow
+__device__ __forceinline__ void emit_row(const YParams& P, int b, int slot, const float (&acc)[5], float cf, float ccf, int c) {
+    float* row = P.krow + ((size_t)b * P.N + slot) * 7;                                                    // YOLOV4.py:275-279
+    row[0] = acc[1] / acc[0]; row[1] = acc[2] / acc[0]; row[2] = acc[3] / acc[0]; row[3] = acc[4] / acc[0];
+    row[4] = cf; row[5] = ccf; row[6] = (float)c;
+}
+
+// Sum over the 64 lanes without LDS traffic: an inclusive scan inside each row of 16 lanes by four data-parallel-primitive adds
+// (row_shr 1, 2, 4, 8; out-of-row sources read 0), then the four row totals (lanes 15, 31, 47, 63) added in row order.  A fixed order
+// (reproducible); the total is wave-uniform.  (__shfl_down trees are ds_bpermute chains: ~40 % of a pivot's time with five sums.)
+__device__ __forceinline__ float wave_total_dpp(float v) {
+#define ODPL_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true))
+    ODPL_DPP_ADD(0x111); ODPL_DPP_ADD(0x112); ODPL_DPP_ADD(0x114); ODPL_DPP_ADD(0x118);
+#undef ODPL_DPP_ADD
+    const int iv = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 15)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 31));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 47)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 63));
+    return ((r0 + r1) + r2) + r3;
+}
+
+__device__ __forceinline__ int wave_total_dpp_i(int v) {
+#define ODPL_DPP_ADDI(ctrl) v += __builtin_amdgcn_update_dpp(0, v, ctrl, 0xf, 0xf, true)
+    ODPL_DPP_ADDI(0x111); ODPL_DPP_ADDI(0x112); ODPL_DPP_ADDI(0x114); ODPL_DPP_ADDI(0x118);
+#undef ODPL_DPP_ADDI
+    return __builtin_amdgcn_readlane(v, 15) + __builtin_amdgcn_readlane(v, 31) + __builtin_amdgcn_readlane(v, 47) + __builtin_amdgcn_readlane(v, 63);
+}
+
+// A class of <= 64 candidates (the usual case with many classes): the pairwise decisions `IoU(+1) > thr` do not depend on the order of
+// the loop, so the whole m x m matrix is evaluated up front, one row per lane and all rows in parallel (m steps of one IoU), and the
+// sequential pivot loop works on 64-bit masks in scalar registers: pivot = first alive bit, invalid = its row & alive.  A pivot that
+// absorbs nobody but itself -- most of them -- yields the row (w x) / w of its own box, computed for every lane beforehand and written
+// after the loop, all of them at once; only a real merge takes the wave sums.  Same rows as class_pivots<1> (the +1 IoU is symmetric
+// in its arguments: max / min and one commutative sum per term), in the same order.
+__device__ __forceinline__ int class_pivots_small(const YParams& P, int b, int c, int m, int off, float* s_k, unsigned* s_i) {
+    const int lane = threadIdx.x & 63;
+    const size_t o0 = (size_t)b * P.N;
+    const bool in = lane < m;
+    const unsigned cn = in ? s_i[lane] : 0u;
+    const float kk = in ? s_k[lane] : 0.f;
+    const float4 bx = in ? P.box[o0 + cn] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float cf = in ? P.conf[o0 + cn] : 0.f, ccf = in ? P.cconf[o0 + cn] : 0.f;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // the sorted list is in registers: s_k / s_i now collect the kept pivots
+    __builtin_amdgcn_wave_barrier();
+    Box4 me; me.x1 = bx.x; me.y1 = bx.y; me.x2 = bx.z; me.y2 = bx.w;
+    unsigned long long row = 0ull;
+    for (int j = 0; j < m; ++j) {                               // (uniform trip count)
+#define ODPL_RLJ(x) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), j))
+        Box4 o; o.x1 = ODPL_RLJ(bx.x); o.y1 = ODPL_RLJ(bx.y); o.x2 = ODPL_RLJ(bx.z); o.y2 = ODPL_RLJ(bx.w);
+#undef ODPL_RLJ
+        if (iou_plus1(o, me) > P.nms_thres) row |= 1ull << j;   // YOLOV4.py:271-274: this lane as the pivot, candidate j against it
+    }
+    // the row a pivot leaves when it is alone in its `invalid` set: (w * x) / w per coordinate (YOLOV4.py:275-279 on one box)
+    const float solo0 = (cf * bx.x) / cf, solo1 = (cf * bx.y) / cf, solo2 = (cf * bx.z) / cf, solo3 = (cf * bx.w) / cf;
+    const unsigned row_lo = (unsigned)row, row_hi = (unsigned)(row >> 32);
+    unsigned long long alive = m >= 64 ? ~0ull : ((1ull << m) - 1ull);
+    int my_slot = -1;                                           // >= 0: this lane's candidate was a pivot and kept row `my_slot`
+    bool my_solo = false;
+    int nrows = 0;
+    while (alive) {
+        const int p = __ffsll((long long)alive) - 1;
+        const unsigned long long rp = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)row_hi, p) << 32) |
+                                      (unsigned)__builtin_amdgcn_readlane((int)row_lo, p);
+        const unsigned long long inv = rp & alive;
+        const bool solo = inv == (1ull << p);
+        if (lane == p) { my_slot = nrows; my_solo = solo; }
+        if (!solo) {                                            // (uniform) a merge, or a box whose own IoU is not above the threshold
+            const bool mine = (inv >> lane) & 1ull;
+            float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+            if (mine) { acc[0] = cf; acc[1] = cf * bx.x; acc[2] = cf * bx.y; acc[3] = cf * bx.z; acc[4] = cf * bx.w; }
+#pragma unroll
+            for (int i = 0; i < 5; ++i) acc[i] = wave_total_dpp(acc[i]);
+            const float tcf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cf), p));
+            const float tccf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ccf), p));
+            const float num = lane == 0 ? acc[1] : lane == 1 ? acc[2] : lane == 2 ? acc[3] : acc[4];
+            const float v = lane < 4 ? num / acc[0] : lane == 4 ? tcf : lane == 5 ? tccf : (float)c;
+            if (lane < 7) P.krow[(o0 + off + nrows) * 7 + lane] = v;
+        }
+        alive &= ~(inv | (1ull << p));                          // the pivot is always retired
+        ++nrows;
+    }
+    if (my_slot >= 0) {
+        if (my_solo) {
+            float* r = P.krow + (o0 + off + my_slot) * 7;
+            r[0] = solo0; r[1] = solo1; r[2] = solo2; r[3] = solo3; r[4] = cf; r[5] = ccf; r[6] = (float)c;
+        }
+        s_k[my_slot] = kk; s_i[my_slot] = cn;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&P.ktot[(size_t)b * kKtotPitch], nrows);
+    base = __builtin_amdgcn_readfirstlane(base);
+    const size_t op = (size_t)b * P.Npad;
+    if (lane < nrows) { P.kkey[op + base + lane] = s_k[lane]; P.kidx[op + base + lane] = s_i[lane]; P.ksrc[op + base + lane] = off + lane; }
+    return nrows;
+}
+
+// the pivot loop of one class with its (sorted) list in RE x 64 register slots; returns the number of rows it kept
+template <int RE>
+__device__ __forceinline__ int class_pivots(const YParams& P, int b, int c, int m, int off, float* s_k, unsigned* s_i) {
+    const int lane = threadIdx.x & 63;
+    const size_t o0 = (size_t)b * P.N;
+    float4 bx[RE]; float cf[RE], ccf[RE], kk[RE]; unsigned cn[RE];
+    unsigned long long am[RE];
+#pragma unroll
+    for (int u = 0; u < RE; ++u) {
+        const int e = lane + 64 * u;
+        const bool in = e < m;
+        cn[u] = in ? s_i[e] : 0u; kk[u] = in ? s_k[e] : 0.f;
+        bx[u] = in ? P.box[o0 + cn[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
+        cf[u] = in ? P.conf[o0 + cn[u]] : 0.f; ccf[u] = in ? P.cconf[o0 + cn[u]] : 0.f;
+        am[u] = __ballot(in);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // the sorted list is in registers: s_k / s_i now collect the kept pivots
+    __builtin_amdgcn_wave_barrier();
+    int nrows = 0;
+    for (;;) {
+        int pu = -1;
+#pragma unroll
+        for (int u = RE - 1; u >= 0; --u) if (am[u]) pu = u;
+        if (pu < 0) break;
+        float4 tb = make_float4(0.f, 0.f, 0.f, 0.f); float tcf = 0.f, tccf = 0.f, tk = 0.f; unsigned tn = 0u; int pl = 0;
+#pragma unroll
+        for (int u = 0; u < RE; ++u) if (u == pu) {             // the pivot's lane is wave-uniform: v_readlane, no LDS crossbar
+            pl = __ffsll((long long)am[u]) - 1;
+#define ODPL_RL(x) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), pl))
+            tb.x = ODPL_RL(bx[u].x); tb.y = ODPL_RL(bx[u].y); tb.z = ODPL_RL(bx[u].z); tb.w = ODPL_RL(bx[u].w);
+            tcf = ODPL_RL(cf[u]); tccf = ODPL_RL(ccf[u]); tk = ODPL_RL(kk[u]); tn = (unsigned)__builtin_amdgcn_readlane((int)cn[u], pl);
+#undef ODPL_RL
+        }
+        Box4 top; top.x1 = tb.x; top.y1 = tb.y; top.x2 = tb.z; top.y2 = tb.w;
+        float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < RE; ++u) {
+            Box4 bj; bj.x1 = bx[u].x; bj.y1 = bx[u].y; bj.x2 = bx[u].z; bj.y2 = bx[u].w;
+            const bool inv = ((am[u] >> lane) & 1ull) && (iou_plus1(top, bj) > P.nms_thres);          // YOLOV4.py:271-274
+            if (inv) { const float w = cf[u]; acc[0] += w; acc[1] += w * bx[u].x; acc[2] += w * bx[u].y; acc[3] += w * bx[u].z; acc[4] += w * bx[u].w; }
+            am[u] &= ~__ballot(inv);
+        }
+#pragma unroll
+        for (int u = 0; u < RE; ++u) if (u == pu) am[u] &= ~(1ull << pl);                           // the pivot is always retired
+#pragma unroll
+        for (int i = 0; i < 5; ++i) acc[i] = wave_total_dpp(acc[i]);
+        {   // the row (YOLOV4.py:275-279): the sums are wave-uniform, so lanes 0..3 take one quotient each and lanes 0..6 one store each
+            const float num = lane == 0 ? acc[1] : lane == 1 ? acc[2] : lane == 2 ? acc[3] : acc[4];
+            const float v = lane < 4 ? num / acc[0] : lane == 4 ? tcf : lane == 5 ? tccf : (float)c;
+            if (lane < 7) P.krow[(o0 + off + nrows) * 7 + lane] = v;
+            if (lane == 0) { s_k[nrows] = tk; s_i[nrows] = tn; }
+        }
+        ++nrows;
+    }
+    // a run of the image's compact kept list for this class: one integer add, then the pairs from LDS
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&P.ktot[(size_t)b * kKtotPitch], nrows);
+    base = __shfl(base, 0, 64);
+    const size_t op = (size_t)b * P.Npad;
+    for (int j = lane; j < nrows; j += 64) { P.kkey[op + base + j] = s_k[j]; P.kidx[op + base + j] = s_i[j]; P.ksrc[op + base + j] = off + j; }
+    return nrows;
+}
+
+__global__ __launch_bounds__(kClsT) void yolo_nms_class_kernel(const YParams P) {
+    __shared__ float s_k[64 * kRegE];
+    __shared__ unsigned s_i[64 * kRegE];
+    __shared__ float s_red[6 * (kClsT / 64)];
+    __shared__ int s_min[kClsT / 64];
+    __shared__ int s_p;
+    const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int m = P.cls_cnt[(size_t)b * kMaxCls + c];
+    if (m == 0) return;
+    const int off = P.cls_off[(size_t)b * kMaxCls + c];
+    int nrows = 0;                                              // (the long-segment path's count)
+    const size_t o0 = (size_t)b * P.N, op = (size_t)b * P.Npad;
+    const float* ckey = P.ckey + op + off;
+    const unsigned* cidx = P.cidx + op + off;
+    if (m <= 64 * kRegE) {
+        if (wv != 0) return;                                    // one wave: LDS traffic of a single wave is ordered, no barriers needed
+        int npad = 64; while (npad < m) npad <<= 1;
+        for (int e = lane; e < npad; e += 64) { s_k[e] = e < m ? ckey[e] : -INFINITY; s_i[e] = e < m ? cidx[e] : 0xffffffffu; }
+        __builtin_amdgcn_wave_barrier();
+        for (int k = 2; k <= npad; k <<= 1)
+            for (int lj = __ffs(k) - 2; lj >= 0; --lj) {        // j = 2^lj: shifts and masks (t / j with a run-time j is a 40-instruction division)
+                const int j = 1 << lj;
+                for (int t = lane; t < npad / 2; t += 64) {
+                    const int i = ((t >> lj) << (lj + 1)) + (t & (j - 1)), l = i + j;
+                    const bool up = ((i & k) == 0);
+                    const float ki = s_k[i], kl = s_k[l];
+                    const unsigned ii = s_i[i], il = s_i[l];
+                    const bool sw = up ? before(kl, il, ki, ii) : before(ki, ii, kl, il);
+                    if (sw) { s_k[i] = kl; s_k[l] = ki; s_i[i] = il; s_i[l] = ii; }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        if (m <= 64) class_pivots_small(P, b, c, m, off, s_k, s_i);
+        else if (m <= 128) class_pivots<2>(P, b, c, m, off, s_k, s_i);
+        else class_pivots<kRegE>(P, b, c, m, off, s_k, s_i);
+        return;
+    }
+    // ---- a long segment (a class that dominates its image): rank by counting into the image's sorted arrays, then one workgroup-wide
+    // sweep per pivot.  key / idx (the prep kernel's unsorted pairs) are dead after the bucket launch: their rows [off, off + m)
+    // receive this segment in order; sbox / sconf / scconf / slabel (alive flag) likewise.
+    float* skey = P.key + op + off; unsigned* sidx = P.idx + op + off;
+    float4* sbox = P.sbox + o0 + off; float* sconf = P.sconf + o0 + off; float* scconf = P.scconf + o0 + off; int* alive = P.slabel + o0 + off;
+    for (int e = tid; e < m; e += kClsT) {
+        const float k = ckey[e]; const unsigned n = cidx[e];
+        int r = 0;
+        for (int f = 0; f < m; ++f) r += before(ckey[f], cidx[f], k, n);          // (a strict total order: ranks are a permutation)
+        skey[r] = k; sidx[r] = n;
+        sbox[r] = P.box[o0 + n]; sconf[r] = P.conf[o0 + n]; scconf[r] = P.cconf[o0 + n]; alive[r] = 1;
+    }
+    __threadfence_block();
+    __syncthreads();
+    int p = 0;
+    while (p < m) {
+        const float4 tb = sbox[p];
+        Box4 top; top.x1 = tb.x; top.y1 = tb.y; top.x2 = tb.z; top.y2 = tb.w;
+        float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        int nxt = INT_MAX;
+        for (int j = p + tid; j < m; j += kClsT) {
+            if (!alive[j]) continue;
+            const float4 q = sbox[j];
+            Box4 bj; bj.x1 = q.x; bj.y1 = q.y; bj.x2 = q.z; bj.y2 = q.w;
+            if (iou_plus1(top, bj) > P.nms_thres) {                               // YOLOV4.py:271-277 (same label: same segment)
+                const float w = sconf[j];
+                acc[0] += w; acc[1] += w * q.x; acc[2] += w * q.y; acc[3] += w * q.z; acc[4] += w * q.w;
+                alive[j] = 0;
+            } else if (j != p) {
+                nxt = min(nxt, j);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 5; ++i) acc[i] = wave_sum(acc[i]);
+        for (int o = 32; o > 0; o >>= 1) nxt = min(nxt, __shfl_down(nxt, o, 64));
+        if (lane == 0) { for (int i = 0; i < 5; ++i) s_red[wv * 6 + i] = acc[i]; s_min[wv] = nxt; }
+        __syncthreads();
+        if (tid == 0) {
+            float a[5] = {0.f, 0.f, 0.f, 0.f, 0.f}; int mn = INT_MAX;
+            for (int w = 0; w < kClsT / 64; ++w) { for (int i = 0; i < 5; ++i) a[i] += s_red[w * 6 + i]; mn = min(mn, s_min[w]); }
+            emit_row(P, b, off + nrows, a, sconf[p], scconf[p], c);
+            const int at = atomicAdd(&P.ktot[(size_t)b * kKtotPitch], 1);         // (rare path: one reservation per row)
+            P.kkey[op + at] = skey[p]; P.kidx[op + at] = sidx[p]; P.ksrc[op + at] = off + nrows;
+            alive[p] = 0;                                                         // the pivot is always retired
+            s_p = mn;
+        }
+        ++nrows;
+        __threadfence_block();
+        __syncthreads();
+        p = s_p;
+        __syncthreads();
+    }
+}
+
+// order: the reference's output order is the rank of each kept row's (score, candidate) among all kept rows of its image (a strict
+// total order).  K ~ 1 000 rows per image: all pairs is 1.2 M comparisons per image spread over the chip -- cheaper than any sort here (a
+// 66-stage LDS bitonic network over 2 048 entries took 54 us in one workgroup; per-class binary searches are chains of dependent
+// LDS reads: 79 us; all pairs out of LDS, one read per step: 33 us; out of registers with the two-part comparison: 31 us, 23 of them
+// the comparisons).  Workgroup = kOrdRows rows of one image, kOrdRows / 4 per wave: every lane holds kOrdS kept pairs in REGISTERS (one
+// trip to memory per chunk) as ONE 64-bit integer each whose unsigned order is (score desc, candidate asc), so a row against 64 pairs
+// is one compare + one add per lane (the lanes' counts are summed once per row at the end), no memory access inside the loops.
+constexpr int kOrdT = 256;
+constexpr int kOrdRows = 64;
+constexpr int kOrdS = 16;              // kept pairs per lane per chunk (1 024 pairs per chunk)
+
+// a < b  <=>  before(ka, ia, kb, ib) for finite scores: descending score = ascending complement of the order-preserving bits
+// (-0.0 is folded onto +0.0, which `before` treats as equal), candidate index in the low half
+__device__ __forceinline__ unsigned long long order_key(float k, unsigned i) {
+    const unsigned u = __float_as_uint(k + 0.0f);
+    const unsigned asc = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long)(~asc) << 32) | i;
+}
+
+__global__ __launch_bounds__(kOrdT) void yolo_nms_order_kernel(const YParams P) {
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (P.nvalid[b] == 0) return;                               // out_counts[b] = -1 was written by the bucket launch
+    const int K = P.ktot[(size_t)b * kKtotPitch];
+    if (blockIdx.x == 0 && tid == 0) P.out_counts[b] = K;
+    constexpr int RPW = kOrdRows / (kOrdT / 64);                // rows per wave
+    const int r0 = blockIdx.x * kOrdRows + wv * RPW;
+    if (r0 >= K) return;                                        // the grid is sized for every candidate surviving
+    const size_t o0 = (size_t)b * P.N, op = (size_t)b * P.Npad;
+    const float* __restrict__ kkey = P.kkey + op; const unsigned* __restrict__ kidx = P.kidx + op;
+    unsigned long long rkey[RPW]; int rank[RPW];
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) { const int r = min(r0 + q, K - 1); rkey[q] = order_key(kkey[r], kidx[r]); rank[q] = 0; }      // (wave-uniform)
+    for (int c0 = 0; c0 < K; c0 += 64 * kOrdS) {
+        unsigned long long ek[kOrdS];
+#pragma unroll
+        for (int u = 0; u < kOrdS; ++u) {                      // pairs past the end: the largest key is in front of nothing
+            const int e = c0 + u * 64 + lane;
+            ek[u] = e < K ? order_key(kkey[e], kidx[e]) : ~0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < kOrdS; ++u) {
+            if (c0 + u * 64 >= K) break;                        // (uniform)
+#pragma unroll
+            for (int q = 0; q < RPW; ++q) rank[q] += ek[u] < rkey[q];      // per lane: compare + add-with-carry, no scalar round trip
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) rank[q] = wave_total_dpp_i(rank[q]);
+    // the rows: every slot index first, then every value, then the stores (three trips for the wave's rows, not two per row)
+    const int* __restrict__ ksrc = P.ksrc + op;
+    const float* __restrict__ krow = P.krow + o0 * 7;
+    float* __restrict__ out = P.out + o0 * 7;
+    int src[RPW]; float val[RPW];
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) src[q] = ksrc[min(r0 + q, K - 1)];
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) val[q] = lane < 7 ? krow[(size_t)src[q] * 7 + lane] : 0.f;
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) if (r0 + q < K && lane < 7) out[(size_t)rank[q] * 7 + lane] = val[q];
+}
+
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 inline int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
-struct YPlan { size_t box, conf, cconf, label, sbox, sconf, scconf, slabel, key, idx, total; int N, Npad; };
+struct YPlan { size_t box, conf, cconf, label, sbox, sconf, scconf, slabel, key, idx, cls_off, cls_cnt, nvalid, ktot, ksrc, ckey, cidx, kkey, kidx, krow, total; int N, Npad; };
 
 bool make_yplan(const odpl_yolo_nms_desc_t* d, YPlan* p) {
     if (!d || d->nscales < 1 || d->nscales > ODPL_MAX_SCALES || d->B < 1 || d->A < 1 || d->no < 6) return false;
@@ -423,6 +823,16 @@ bool make_yplan(const odpl_yolo_nms_desc_t* d, YPlan* p) {
     p->slabel = off; off += align_up(BN * 4, 256);
     p->key = off;    off += align_up(BP * 4, 256);
     p->idx = off;    off += align_up(BP * 4, 256);
+    p->cls_off = off; off += align_up((size_t)d->B * kMaxCls * 4, 256);
+    p->cls_cnt = off; off += align_up((size_t)d->B * kMaxCls * 4, 256);
+    p->nvalid = off; off += align_up((size_t)d->B * 4, 256);
+    p->ktot = off;   off += align_up((size_t)d->B * kKtotPitch * 4, 256);
+    p->ksrc = off;   off += align_up(BP * 4, 256);
+    p->ckey = off;   off += align_up(BP * 4, 256);
+    p->cidx = off;   off += align_up(BP * 4, 256);
+    p->kkey = off;   off += align_up(BP * 4, 256);
+    p->kidx = off;   off += align_up(BP * 4, 256);
+    p->krow = off;   off += align_up(BN * 28, 256);
     p->total = off;
     return true;
 }
@@ -455,18 +865,33 @@ extern "C" int odpl_yolo_nms(const odpl_yolo_nms_desc_t* d, void* workspace, siz
     P.sbox = (float4*)(ws + pl.sbox); P.sconf = (float*)(ws + pl.sconf); P.scconf = (float*)(ws + pl.scconf);
     P.slabel = (int*)(ws + pl.slabel); P.key = (float*)(ws + pl.key); P.idx = (unsigned*)(ws + pl.idx);
     P.out = out_dets; P.out_counts = out_counts;
+    P.cls_off = (int*)(ws + pl.cls_off); P.cls_cnt = (int*)(ws + pl.cls_cnt); P.nvalid = (int*)(ws + pl.nvalid); P.ktot = (int*)(ws + pl.ktot); P.ksrc = (int*)(ws + pl.ksrc);
+    P.ckey = (float*)(ws + pl.ckey); P.cidx = (unsigned*)(ws + pl.cidx); P.kkey = (float*)(ws + pl.kkey); P.kidx = (unsigned*)(ws + pl.kidx);
+    P.krow = (float*)(ws + pl.krow);
     prof_begin(ODPL_PROF_YOLO_NMS_PREP, stream);
     // class ranges per candidate split over 4 thread groups: measured 13.5 us at config 2 against 16.3 / 13.6 / 18.2 us for 1 / 2 / 8
     hipLaunchKernelGGL(yolo_nms_prep_kernel<4>, dim3((pl.Npad + 63) / 64, d->B), dim3(kPrepT), 0, stream, P);
     prof_end(ODPL_PROF_YOLO_NMS_PREP, stream);
     ODPL_HIP_TRY(hipGetLastError());
     prof_begin(ODPL_PROF_YOLO_NMS_IMAGE, stream);
-    static bool lds_attr_set = false;                          // 128 KB of dynamic LDS needs the opt-in once per process
-    if (!lds_attr_set) {
+    static bool lds_attr_set[16] = {};                         // 128 KB of dynamic LDS needs the opt-in once per device
+    int dev_id = 0;
+    ODPL_HIP_TRY(hipGetDevice(&dev_id));
+    if (dev_id < 0 || dev_id >= 16) return ODPL_EINVAL;
+    if (!lds_attr_set[dev_id]) {
         ODPL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(yolo_nms_image_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * kCap));
-        lds_attr_set = true;
+        lds_attr_set[dev_id] = true;
     }
-    hipLaunchKernelGGL(yolo_nms_image_kernel, dim3(d->B), dim3(kImgT), 8 * kCap, stream, P);
+    const int nc = d->no - 5;
+    if (nc >= kSplitMinCls && nc <= kMaxCls && !(d->flags & ODPL_YOLO_NMS_ONE_WORKGROUP)) {
+        hipLaunchKernelGGL(yolo_nms_bucket_kernel, dim3(d->B), dim3(kImgT), 0, stream, P);
+        ODPL_HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(yolo_nms_class_kernel, dim3(nc, d->B), dim3(kClsT), 0, stream, P);
+        ODPL_HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(yolo_nms_order_kernel, dim3((pl.N + kOrdRows - 1) / kOrdRows, d->B), dim3(kOrdT), 0, stream, P);
+    } else {
+        hipLaunchKernelGGL(yolo_nms_image_kernel, dim3(d->B), dim3(kImgT), 8 * kCap, stream, P);
+    }
     prof_end(ODPL_PROF_YOLO_NMS_IMAGE, stream);
     ODPL_HIP_TRY(hipGetLastError());
     return 0;

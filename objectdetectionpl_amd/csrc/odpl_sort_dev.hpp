@@ -11,9 +11,10 @@ __device__ __forceinline__ bool before(float ka, unsigned ia, float kb, unsigned
 
 __device__ void bitonic_sort_global(float* key, unsigned* idx, int npad) {
     for (int k = 2; k <= npad; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int lj = __ffs(k) - 2; lj >= 0; --lj) {            // j = 2^lj: shifts and masks instead of run-time divisions
+            const int j = 1 << lj;
             for (int t = threadIdx.x; t < npad / 2; t += blockDim.x) {
-                const int i = ((t / j) * 2 * j) + (t % j), l = i + j;
+                const int i = ((t >> lj) << (lj + 1)) + (t & (j - 1)), l = i + j;
                 const bool up = ((i & k) == 0);
                 const float ki = key[i], kl = key[l];
                 const unsigned ii = idx[i], il = idx[l];

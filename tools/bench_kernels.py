@@ -49,6 +49,8 @@ def measure(name, kernels, fn, alg_bytes, note):
     for k in kernels:
         _lib.profile_enable(k, False)
         ms, _ = _lib.profile_collect(k)
+        if not ms:                      # (a launch this route no longer makes, e.g. yolo_assign when the assignment runs inside yolo_loss)
+            continue
         ms.sort()
         us = 1e3 * ms[len(ms) // 2]
         b = alg_bytes.get(k)
@@ -82,7 +84,10 @@ def main():
     kept = sum(o.shape[0] for o in nms.yolo_non_max_suppression(hn) if o is not None)
     measure(f"config2 YOLO weighted-merge NMS (10647 cand/img, {kept} kept over 16 img)", ["yolo_nms_prep", "yolo_nms_image"],
             lambda: nms.yolo_non_max_suppression(hn), {"yolo_nms_prep": 4 * cells * 85 + cells * 40},
-            {"yolo_nms_prep": "head read + SoA write", "yolo_nms_image": "1 WG/image: bitonic sort + sequential pivots"})
+            {"yolo_nms_prep": "head read + SoA write", "yolo_nms_image": "[r4] bucket (1 WG/image) + class (1 WG per image and class) + order (1 WG/image): three launches"})
+    measure(f"config2 YOLO weighted-merge NMS, one workgroup per image (round 3's kernel; A/B flag)", ["yolo_nms_image"],
+            lambda: nms.yolo_non_max_suppression(hn, one_workgroup=True), {},
+            {"yolo_nms_image": "1 WG/image: LDS bitonic sort of every valid candidate + one wave per class"})
     measure("config2 YOLOv4 inference decode", ["yolo_decode"],
             lambda: YoloV4Utils.decode_heads([h.detach() for h in heads], C, A18, M3, [8, 16, 32]),
             {"yolo_decode": 4 * cells * 85 + 4 * cells * 84}, {"yolo_decode": "head read + boxes/confs write"})
