@@ -119,3 +119,70 @@ def test_hosted_heads_and_structured_backward_replay_from_a_hip_graph():
             assert torch.equal(got[k], ref[k]), (trial, k)
         for a, b in zip(got_g, ref_g):
             assert torch.equal(a, b)
+
+
+def test_whole_training_step_captures_when_every_warm_up_runs_on_the_capture_stream():
+    """[r4] VERDICT r03 item 4 / ADVICE r03: `profiles/r03_probe_step_graph.jsonl` showed rc -11 while capturing the YOLOv4 backward.
+    The bisection (`tools/probe_step_graph3.py`, `profiles/r04_probe_step_graph.jsonl`) found the cause outside this repo: the probe
+    had run eager steps on the DEFAULT stream first, which pins autograd's AccumulateGrad nodes there; the captured backward then
+    touches the legacy stream and `torch.cuda.CUDAGraph.capture_end()` (hipStreamEndCapture) dies instead of reporting an invalid
+    capture.  With every warm-up on the capture's side stream the whole step -- MIOpen convolutions, this package's BN / activation
+    epilogues (odpl_torch_ext autograd functions), hosted head convolutions, the region loss, its structured head backward and a
+    capturable fused Adam -- captures and replays; here at a small size, replays against eager steps from the same initial state."""
+    import copy
+
+    from objectdetectionpl_amd.model.YOLOV4 import YOLOv4
+
+    class A:
+        model_name = "YOLOv4"; cls_criterion = "bce_loss"; coord_criterion = "smooth_l1_loss"; data_module = "synthetic"
+        optimizer = "Adam"; lr = 1e-3; weight_decay = 1e-5
+
+    dev = torch.device("cuda:0")
+    C, B, img = 4, 2, 128
+    torch.manual_seed(0)
+    g = torch.Generator().manual_seed(9)
+    model = YOLOv4([str(i) for i in range(C)], A()).to(dev).train().to(memory_format=torch.channels_last)
+    eager = copy.deepcopy(model)
+    warm0 = copy.deepcopy(model)                     # the initial weights
+    x = torch.rand(B, 3, img, img, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    y = _targets(g, B, 3, C).to(dev)
+    side = torch.cuda.Stream()
+
+    def make(m):
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=1e-5, fused=True, capturable=True)
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            d = m.criterion(m(x), y)
+            d["loss"].backward()
+            opt.step()
+            return d["loss"].detach()
+        return step
+
+    warm = copy.deepcopy(model)                      # warm-up (MIOpen kernel selection, workspaces) on a throw-away replica, on the side stream ONLY
+    wstep = make(warm)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            wstep()
+        gstep = make(model)
+        gstep()                                      # one step of the captured replica itself: its AccumulateGrad nodes and Adam state on this stream
+        estep = make(eager)
+        ref = [estep()]                              # the eager replica takes the same first step
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            static_loss = gstep()
+        got = []
+        for _ in range(3):
+            graph.replay()
+            got.append(static_loss.clone())
+            ref.append(estep())
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    for a, b in zip(got, ref[1:]):                   # MIOpen's split-K kernels sum with atomics: close, not equal
+        assert torch.isfinite(a) and abs(float(a) - float(b)) <= 2e-3 * abs(float(b)) + 1e-5, (float(a), float(b))
+    p0 = torch.cat([p.detach().reshape(-1) for p in warm0.parameters()])
+    pa = torch.cat([p.detach().reshape(-1) for p in model.parameters()]) - p0
+    pb = torch.cat([p.detach().reshape(-1) for p in eager.parameters()]) - p0
+    assert float(pa.abs().max()) > 1e-3                                   # the replays did step the weights ...
+    assert float(torch.nn.functional.cosine_similarity(pa, pb, dim=0)) > 0.98      # ... the way the eager steps did
