@@ -309,6 +309,7 @@ def main():
     ap.add_argument("--secondary-steps", type=int, default=8)
     ap.add_argument("--comm-probe-steps", type=int, default=4, help="N > 1: steps inside no_sync() that price the exposed gradient exchange")
     ap.add_argument("--no-fused-adam", dest="fused_adam", action="store_false", help="foreach Adam instead of the fused one")
+    ap.add_argument("--torch-adam", action="store_true", help="A/B: torch's own fused Adam launches instead of the one-launch HIP step (optim.py)")
     ap.add_argument("--no-channels-last", dest="channels_last", action="store_false", help="NCHW memory format for the network")
     ap.add_argument("--no-head-gemm", dest="head_gemm", action="store_false",
                     help="A/B: head 1x1 convolutions on MIOpen (channels-last heads) instead of utils/headconv.py")
@@ -385,7 +386,9 @@ def main():
         model = model.to(memory_format=torch.channels_last)
     crit = model.criterion
     net = wrap_data_parallel(model, dev, bucket_mb=a.bucket_mb, impl=a.ddp_impl) if use_ddp else model
-    opt = torch.optim.Adam(model.parameters(), lr=Args.lr, weight_decay=Args.weight_decay, fused=bool(a.fused_adam))
+    from objectdetectionpl_amd.optim import Adam as OdplAdam            # what the package's configure_optimizers returns (optimizer.py:6-38)
+    OdplAdam.one_launch = not a.torch_adam
+    opt = OdplAdam(model.parameters(), lr=Args.lr, weight_decay=Args.weight_decay, fused=bool(a.fused_adam))
     x, y = synthetic_batch(1 + rank, a.batch, a.classes, a.img, dev)       # rank r draws from seed 1 + r
     if a.channels_last:
         x = x.contiguous(memory_format=torch.channels_last)

@@ -32,7 +32,7 @@ extern "C" {
                               * 5: odpl_sparse_conv3x3_t grew stats; ODPL_RETINA_ASSIGN_ONLY / _ASSIGNED, odpl_pixel_support, odpl_sparse_conv3x3_forward,
                               *    ksize on both sparse-convolution descriptors, odpl_pixel_union_lists, odpl_sparse_upsample_add
                               * 6: the two probes left the library (tools/probes/: odpl_conv1x1_*, odpl_bn_fused_*, ODPL_TUNE_BN_FUSED*);
-                              */
+                              *    odpl_adam_step; ODPL_YOLO_NMS_ONE_WORKGROUP; ODPL_TUNE_YOLO_FUSED_MAX_TARGETS */
 #define ODPL_EINVAL (-1)
 #define ODPL_MAX_SCALES 4
 #define ODPL_MAX_ANCHORS 8
@@ -676,6 +676,26 @@ int odpl_bn_act_backward_strided(const void* x, const void* grad_y, int64_t gy_r
                                  const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
                                  int32_t training, int32_t act, void* grad_x, float* grad_gamma, float* grad_beta,
                                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- Adam over every parameter in one launch: LightningFunc/optimizer.py:6-38 (torch.optim.Adam, weight_decay as an L2 term) -------
+ * The arithmetic of ATen's fused Adam kernel (fp32 parameters, double hyper-parameters, bias corrections from the device step count),
+ * one flat launch instead of ten multi-tensor ones.  The caller builds the tables ONCE (they hold what never changes: where each
+ * parameter, its exp_avg / exp_avg_sq and its step count live, and which tensor each ODPL_ADAM_BLOCK-element block belongs to); the
+ * gradient pointers, which autograd renews every step, are a HOST array and travel as kernel arguments (ODPL_ADAM_MAX_TENSORS per
+ * launch: more tensors take more launches).  The step counts are incremented by the caller BEFORE the call (torch._foreach_add_). */
+#define ODPL_ADAM_BLOCK 4096
+#define ODPL_ADAM_MAX_TENSORS 384
+typedef struct {
+    const uint64_t* table;          /* device [n_tensors][4]: parameter, exp_avg, exp_avg_sq, step (float32 scalar) device addresses */
+    const uint32_t* numel;          /* device [n_tensors] */
+    const uint32_t* blk0;           /* device [n_tensors + 1]: first block of each tensor, blocks of ODPL_ADAM_BLOCK elements */
+    const uint32_t* blk_tensor;     /* device [n_blocks]: the tensor of each block */
+    const uint32_t* host_blk0;      /* HOST copy of blk0 (launch geometry) */
+    int32_t n_tensors, n_blocks;
+    int32_t maximize;
+    double lr, beta1, beta2, eps, weight_decay;
+} odpl_adam_desc_t;
+int odpl_adam_step(const odpl_adam_desc_t* desc, const float* const* host_grads, void* stream);
 
 /* launch-geometry knobs (process-wide; defaults are the tuned values) */
 #define ODPL_TUNE_YOLO_FILL_F4_PER_BLOCK 0

@@ -1,10 +1,13 @@
 """`configure_optimizers` of the reference (`LightningFunc/optimizer.py:6-38`): same `args` fields, same choices and
 hyper-parameters (including `ReduceLROnPlateau(mode='max')` on `val_loss`), returned in the same
-`{'optimizer', 'lr_scheduler', 'monitor'}` dict.  Adam runs fused (one multi-tensor launch) when the parameters are on the GPU."""
-from torch.optim import SGD, Adagrad, Adam, RMSprop, lr_scheduler as _sched
+`{'optimizer', 'lr_scheduler', 'monitor'}` dict.  Adam is `optim.Adam`: torch.optim.Adam (same state, same arithmetic) whose update is
+one HIP launch over every parameter when they live on the GPU (csrc/odpl_adam.hip), torch's own step otherwise."""
+from torch.optim import SGD, Adagrad, RMSprop, lr_scheduler as _sched
+
+from ..optim import Adam
 
 _OPTIMIZERS = {
-    "Adam": lambda p, a: Adam(p, lr=a.lr, weight_decay=a.weight_decay, fused=all(q.is_cuda for q in p)),
+    "Adam": lambda p, a: Adam(p, lr=a.lr, weight_decay=a.weight_decay),
     "Adagrad": lambda p, a: Adagrad(p, lr=a.lr, lr_decay=a.lr_decay, weight_decay=a.weight_decay),
     "RMSprop": lambda p, a: RMSprop(p, lr=a.lr, alpha=a.alpha, momentum=a.momentum, weight_decay=a.weight_decay),
     "SGD": lambda p, a: SGD(p, lr=a.lr, momentum=a.momentum, weight_decay=a.weight_decay),

@@ -92,6 +92,16 @@ class YoloNmsDesc(ctypes.Structure):
                 ("conf_thres", c_float), ("nms_thres", c_float), ("flags", c_int32)]
 
 
+class AdamDesc(ctypes.Structure):
+    _fields_ = [("table", c_void_p), ("numel", c_void_p), ("blk0", c_void_p), ("blk_tensor", c_void_p), ("host_blk0", c_void_p),
+                ("n_tensors", c_int32), ("n_blocks", c_int32), ("maximize", c_int32),
+                ("lr", ctypes.c_double), ("beta1", ctypes.c_double), ("beta2", ctypes.c_double), ("eps", ctypes.c_double),
+                ("weight_decay", ctypes.c_double)]
+
+
+ADAM_BLOCK, ADAM_MAX_TENSORS = 4096, 384
+
+
 class GreedyNmsDesc(ctypes.Structure):
     _fields_ = [("loc", c_void_p), ("cls", c_void_p), ("anchors", c_void_p),
                 ("B", c_int32), ("An", c_int32), ("C", c_int32), ("topk", c_int32),
@@ -164,6 +174,7 @@ SIGNATURES = {
     "odpl_xywh2xyxy": (c_int32, [c_void_p, c_void_p, ctypes.c_int64, c_void_p]),
     "odpl_ssd_priors": (c_int32, [POINTER(c_int32), POINTER(c_int32), POINTER(c_float), c_void_p, ctypes.c_int64, c_void_p]),
     "odpl_yolo_nms_workspace_bytes": (c_size_t, [POINTER(YoloNmsDesc)]),
+    "odpl_adam_step": (c_int32, [POINTER(AdamDesc), c_void_p, c_void_p]),
     "odpl_yolo_nms": (c_int32, [POINTER(YoloNmsDesc), c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "odpl_greedy_nms_workspace_bytes": (c_size_t, [POINTER(GreedyNmsDesc)]),
     "odpl_greedy_nms": (c_int32, [POINTER(GreedyNmsDesc), c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),

@@ -48,7 +48,8 @@ def test_ctypes_layouts_against_the_compiled_header(tmp_path):
     cases = [("odpl_retina_loss_desc_t", _lib.RetinaLossDesc, "num_pos"), ("odpl_retina_head_t", _lib.RetinaHead, "no"),
              ("odpl_retina_heads_desc_t", _lib.RetinaHeadsDesc, "upstream"), ("odpl_sparse_conv3x3_t", _lib.SparseConv3x3, "stats"),
              ("odpl_pixel_support_t", _lib.PixelSupport, "counts"), ("odpl_sparse_conv3x3_fwd_t", _lib.SparseConv3x3Fwd, "ksize"),
-             ("odpl_yolo_scale_t", _lib.YoloScale, "stride"), ("odpl_sparse_grad_t", _lib.SparseGrad, None)]
+             ("odpl_yolo_scale_t", _lib.YoloScale, "stride"), ("odpl_sparse_grad_t", _lib.SparseGrad, None),
+             ("odpl_adam_desc_t", _lib.AdamDesc, "weight_decay"), ("odpl_yolo_nms_desc_t", _lib.YoloNmsDesc, "flags")]
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{REPO}/include/odpl_hip.h"', 'int main(void) {']
     for cname, _, last in cases:
         off = f"offsetof({cname}, {last})" if last else "(size_t)0"

@@ -1,0 +1,76 @@
+"""The one-launch Adam step (csrc/odpl_adam.hip through optim.Adam) against torch's fused Adam on the device."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(make_opt, shapes, steps, seed, channels_last=True):
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(seed)
+    ps = []
+    for s in shapes:
+        w = torch.randn(*s, generator=g).to(dev)
+        if channels_last and len(s) == 4:
+            w = w.contiguous(memory_format=torch.channels_last)
+        ps.append(torch.nn.Parameter(w))
+    opt = make_opt(ps)
+    for k in range(steps):
+        for p in ps:                                      # autograd hands the optimizer NEW gradient tensors every step
+            gr = torch.randn(p.shape, generator=g).to(dev) * (0.5 + k)
+            p.grad = gr.contiguous(memory_format=torch.channels_last) if (channels_last and p.dim() == 4) else gr
+        opt.step()
+    torch.cuda.synchronize()
+    return ps, opt
+
+
+SHAPES = [(64, 32, 3, 3), (255, 1024, 1, 1), (1024,), (3,), (5, 7), (33, 16, 1, 1), (4097,), (1,), (128, 64, 3, 3)]
+
+
+@pytest.mark.parametrize("wd", [1e-5, 0.0])
+def test_one_launch_adam_equals_torchs_fused_adam_bit_for_bit(wd):
+    """three steps, parameters of every alignment class (4096-multiple, ragged tails, fewer than four elements,
+    channels-last 4-d weights), weight decay on and off: parameters, exp_avg, exp_avg_sq and step equal torch.optim.Adam(fused=True)."""
+    from objectdetectionpl_amd.optim import Adam
+    mine, om = _run(lambda ps: Adam(ps, lr=1e-3, weight_decay=wd), SHAPES, 3, 4)
+    ref, ot = _run(lambda ps: torch.optim.Adam(ps, lr=1e-3, weight_decay=wd, fused=True), SHAPES, 3, 4)
+    assert om._flat, "the HIP step did not run"
+    for p, q in zip(mine, ref):
+        assert torch.equal(p, q), float((p - q).abs().max())
+        for k in ("exp_avg", "exp_avg_sq"):
+            assert torch.equal(om.state[p][k], ot.state[q][k]), k
+        assert float(om.state[p]["step"]) == float(ot.state[q]["step"]) == 3.0
+
+
+def test_state_dict_round_trip_and_fallbacks():
+    from objectdetectionpl_amd.optim import Adam
+    mine, om = _run(lambda ps: Adam(ps, lr=2e-3, weight_decay=1e-4), SHAPES[:4], 2, 5)
+    sd = om.state_dict()
+    ref, ot = _run(lambda ps: torch.optim.Adam(ps, lr=2e-3, weight_decay=1e-4, fused=True), SHAPES[:4], 2, 5)
+    for a, b in zip(sd["state"].values(), ot.state_dict()["state"].values()):
+        assert float(a["step"]) == float(b["step"]) and torch.equal(a["exp_avg"], b["exp_avg"])
+    # load into a fresh optimizer of each kind and take one more (identical) step
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(6)
+    grads = [torch.randn(p.shape, generator=g).to(dev) for p in mine]
+    p1 = [torch.nn.Parameter(p.detach().clone()) for p in mine]
+    p2 = [torch.nn.Parameter(p.detach().clone()) for p in mine]
+    o1, o2 = Adam(p1, lr=2e-3, weight_decay=1e-4), torch.optim.Adam(p2, lr=2e-3, weight_decay=1e-4, fused=True)
+    import copy
+    o1.load_state_dict(copy.deepcopy(sd)); o2.load_state_dict(copy.deepcopy(sd))      # (load_state_dict keeps the tensors it is given)
+    for p, q, gr in zip(p1, p2, grads):
+        p.grad = gr.clone().contiguous(memory_format=torch.channels_last) if p.dim() == 4 else gr.clone()
+        q.grad = p.grad.clone()
+    o1.step(); o2.step()
+    for p, q in zip(p1, p2):
+        assert torch.equal(p, q)
+    assert float(o1.state[p1[0]]["step"]) == 3.0
+    # a gradient whose strides differ from its parameter's is re-laid in the parameter's format, then stepped by the HIP launch
+    w = torch.randn(8, 4, 3, 3, device=dev).contiguous(memory_format=torch.channels_last)
+    gn = torch.randn(8, 4, 3, 3, device=dev)                                                # NCHW-contiguous gradient
+    pa, pb = torch.nn.Parameter(w.clone()), torch.nn.Parameter(w.clone())
+    o3, o4 = Adam([pa], lr=1e-3), torch.optim.Adam([pb], lr=1e-3, fused=True)
+    pa.grad = gn.clone()
+    pb.grad = gn.clone().contiguous(memory_format=torch.channels_last)
+    o3.step(); o4.step()
+    assert o3._flat and torch.equal(pa, pb)
