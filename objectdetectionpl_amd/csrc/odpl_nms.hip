@@ -913,6 +913,7 @@ struct GParams {
     float* ckey; int* cidx;            // [B*An] candidates (compacted, index order)
     unsigned magic_c4, magic_c;        // fastdiv16 magics of C/4 and C (tile-local indices < 2^16)
     int* tile_cnt; int ntiles;         // [B*ntiles] candidates per kRows-anchor tile (written by the prep kernel)
+    int* ncand;                        // [B] candidates per image (scan launch)
     float* out; int* out_counts;
 };
 
@@ -1043,18 +1044,21 @@ __global__ __launch_bounds__(256) void greedy_nms_prep_kernel(const GParams P) {
     prep_combine_and_store(P, b, a0, r, q, nr, best, bi);
 }
 
-__global__ __launch_bounds__(kImgT) void greedy_nms_image_kernel(const GParams P) {
-    __shared__ int s_wcnt[kImgT / 64], s_wcnt2[kImgT / 64];
-    __shared__ int s_off, s_p;
-    __shared__ float s_key[kMaxTopk]; __shared__ int s_pos[kMaxTopk];
-    __shared__ float4 s_box[kMaxTopk]; __shared__ float s_area[kMaxTopk]; __shared__ int s_alive[kMaxTopk];
-    __shared__ int s_keep[kMaxTopk];
+// [r4] The per-image part as three launches.  One 1024-thread workgroup per image used to do everything -- four workgroups of a
+// 256-CU chip at config 4 (166 us): 50 us walking 3 136 tiles eight at a time, 31 bisection rounds of two barriers each for the
+// k-th largest score, up to 100 sequential pivots of ~0.4 us.  Now:
+//   scan    (1 WG / image)     block scan of the prep kernel's per-tile counts -> tile offsets, the number of candidates
+//   scatter (ntiles / 32 WGs)  the stable compaction itself, spread over the chip: wave = 8 tiles, ballot + popcount positions
+//   final   (1 WG / image)     k-th largest score by a three-level radix select on the float bits with the keys in registers
+//                              (an LDS histogram + one suffix scan per level instead of 31 rounds), the same gather / LDS sort /
+//                              box decode as before, then the greedy loop on an overlap MATRIX: `ovr(i, j) > thr` does not depend on
+//                              the order of the loop, so every lane evaluates its candidates' rows up front, all in parallel, and
+//                              the sequential part works on bit masks in scalar registers (topk <= 128; longer lists keep the
+//                              sweep).  Same kept sets, same output quirks.
+__global__ __launch_bounds__(kImgT) void greedy_nms_scan_kernel(const GParams P) {
+    __shared__ int s_wcnt[kImgT / 64];
+    __shared__ int s_off;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const size_t o0 = (size_t)b * P.An;
-    const float* score = P.score + o0;
-    float* ckey = P.ckey + o0; int* cidx = P.cidx + o0;
-    // ---- stable compaction of score > class_thresh (RetinaNet.py:129-130) from the per-tile counts of the prep kernel:
-    //      block scan of the counts (tile offsets, in place), then every wave walks its tiles and touches only non-empty ones
     int* tcnt = P.tile_cnt + (size_t)b * P.ntiles;
     if (tid == 0) s_off = 0;
     __syncthreads();
@@ -1072,36 +1076,58 @@ __global__ __launch_bounds__(kImgT) void greedy_nms_image_kernel(const GParams P
         if (tid == 0) s_off += tot;
         __syncthreads();
     }
-    constexpr int kTU = 8;                                                        // tiles in flight per wave: independent loads first
-    for (int t0 = wv; t0 < P.ntiles; t0 += kTU * (kImgT / 64)) {
-        int oc[kTU]; float sc[kTU];
+    if (tid == 0) P.ncand[b] = s_off;
+}
+
+constexpr int kScT = 256, kScTU = 8;                 // scatter: 4 waves x 8 tiles per workgroup
+
+__global__ __launch_bounds__(kScT) void greedy_nms_scatter_kernel(const GParams P) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const size_t o0 = (size_t)b * P.An;
+    const float* score = P.score + o0;
+    float* ckey = P.ckey + o0; int* cidx = P.cidx + o0;
+    const int* tcnt = P.tile_cnt + (size_t)b * P.ntiles;
+    const int t0 = (blockIdx.x * (kScT / 64) + wv) * kScTU;
+    int oc[kScTU]; float sc[kScTU];
 #pragma unroll
-        for (int u = 0; u < kTU; ++u) {
-            const int t = t0 + u * (kImgT / 64);
-            oc[u] = t < P.ntiles ? tcnt[t] : -1;                                  // written by this workgroup above (barrier in between)
-            const int a = t * kRows + lane;
-            sc[u] = (t < P.ntiles && a < P.An) ? score[a] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < kTU; ++u) {
-            if (oc[u] < 0) continue;
-            const int a = (t0 + u * (kImgT / 64)) * kRows + lane;
-            const bool f = a < P.An && sc[u] > P.class_thresh;
-            const unsigned long long mk = __ballot(f);
-            if (f) { const int pos = (oc[u] & 0xffffff) + __popcll(mk & ((1ull << lane) - 1ull)); ckey[pos] = sc[u]; cidx[pos] = a; }
-        }
+    for (int u = 0; u < kScTU; ++u) {                // independent loads first
+        const int t = t0 + u;
+        oc[u] = t < P.ntiles ? tcnt[t] : -1;
+        const int a = t * kRows + lane;
+        sc[u] = (t < P.ntiles && a < P.An) ? score[a] : 0.f;
     }
-    __threadfence_block();
-    __syncthreads();
-    const int n = s_off;
+#pragma unroll
+    for (int u = 0; u < kScTU; ++u) {
+        if (oc[u] < 0) continue;
+        const int a = (t0 + u) * kRows + lane;
+        const bool f = a < P.An && sc[u] > P.class_thresh;                        // RetinaNet.py:129-130
+        const unsigned long long mk = __ballot(f);
+        if (f) { const int pos = (oc[u] & 0xffffff) + __popcll(mk & ((1ull << lane) - 1ull)); ckey[pos] = sc[u]; cidx[pos] = a; }
+    }
+}
+
+constexpr int kSelBins = 2048;                       // radix select: bins per level (two per thread)
+
+__global__ __launch_bounds__(kImgT) void greedy_nms_image_kernel(const GParams P) {
+    __shared__ int s_wcnt[kImgT / 64], s_wcnt2[kImgT / 64];
+    __shared__ int s_hist[kSelBins];
+    __shared__ int s_sel[2];
+    __shared__ float s_key[kMaxTopk]; __shared__ int s_pos[kMaxTopk];
+    __shared__ float4 s_box[kMaxTopk]; __shared__ float s_area[kMaxTopk]; __shared__ int s_alive[kMaxTopk];
+    __shared__ int s_keep[kMaxTopk];
+    __shared__ int s_p;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const size_t o0 = (size_t)b * P.An;
+    float* ckey = P.ckey + o0; int* cidx = P.cidx + o0;
+    const int n = P.ncand[b];
     float* out = P.out + (size_t)b * P.topk * 7;
     if (n <= 1) {            // 0: nothing; 1: the reference raises IndexError (0-dim squeeze) -- reported via counts
         if (tid == 0) { P.out_counts[b * 2] = 0; P.out_counts[b * 2 + 1] = n; }
         return;
     }
-    // ---- top-k by score (RetinaNet.py:140-141): k-th largest by bisection on the float bits.  Up to kKeyRegs * 1024
-    //      candidate keys are held in registers, so the <= 31 bisection rounds are compares + one block reduction each
-    //      (no memory traffic); more candidates than that fall back to re-reading the keys from L2.
+    // ---- top-k by score (RetinaNet.py:140-141): the k-th largest key T by radix select on the float bits (scores are positive
+    //      finite floats: the bits order like the values).  Up to kKeyRegs * 1024 candidate keys are held in registers, so a level is
+    //      one LDS-histogram pass + one suffix scan; more candidates than that re-read the keys from L2.
     int m = n < P.topk ? n : P.topk;
     unsigned T = 0;
     unsigned kreg[kKeyRegs];
@@ -1111,29 +1137,76 @@ __global__ __launch_bounds__(kImgT) void greedy_nms_image_kernel(const GParams P
         for (int j = 0; j < kKeyRegs; ++j) { const int i = tid + j * kImgT; kreg[j] = i < n ? __float_as_uint(ckey[i]) : 0u; }
     }
     if (n > P.topk) {
-        unsigned lo = 0u, hi = 0x7f800000u;                 // scores are positive finite floats
-        while (lo < hi) {                                   // largest T with count(bits >= T) >= topk
-            const unsigned mid = lo + (hi - lo + 1) / 2;
-            int c = 0;
+        // current range [base, base + 2^span_log), cut into bins of 2^shift; keys above it: c_above.  The first range is where the keys
+        // can be -- above class_thresh, at most sigmoid's 1.0 -- so that the first histogram spreads over ~1 000 bins (the whole
+        // positive range put 38 000 keys on ten LDS addresses: 17 us of same-address atomics)
+        const unsigned lo_bits = P.class_thresh > 0.f ? __float_as_uint(P.class_thresh) : 0u;
+        const unsigned hi_bits = lo_bits < 0x3f800000u ? 0x3f800000u : lo_bits;      // scores are sigmoids: 1 / (1 + e^-x) <= 1.0f
+        unsigned base = lo_bits;
+        int span_log = 1; while (span_log < 31 && (1u << span_log) <= hi_bits - lo_bits) ++span_log;
+        int shift = span_log > 11 ? span_log - 11 : 0, c_above = 0;
+        for (;;) {
+            s_hist[tid] = 0; s_hist[tid + kImgT] = 0;
+            __syncthreads();
+            auto add = [&](unsigned u) { const unsigned d = u - base; if (u >= base && (d >> span_log) == 0u) atomicAdd(&s_hist[d >> shift], 1); };
             if (in_regs) {
 #pragma unroll
-                for (int j = 0; j < kKeyRegs; ++j) c += (kreg[j] >= mid);       // padding keys are 0 < mid
+                for (int j = 0; j < kKeyRegs; ++j) if (tid + j * kImgT < n) add(kreg[j]);
             } else {
-                for (int i = tid; i < n; i += kImgT) c += (__float_as_uint(ckey[i]) >= mid);
+                for (int i = tid; i < n; i += kImgT) add(__float_as_uint(ckey[i]));
             }
-            c = wave_sum_i(c);
             __syncthreads();
-            if (lane == 0) s_wcnt[wv] = c;
+            // suffix sums S(b) = hist[b] + hist[b + 1] + ...: thread t owns bins 2t, 2t + 1; waves scanned from the top
+            const int h0 = s_hist[2 * tid], h1 = s_hist[2 * tid + 1];
+            int inc = h0 + h1;                               // inclusive suffix over threads tid .. 1023
+            for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_down(inc, o, 64); if (lane + o < 64) inc += u; }
+            if (lane == 0) s_wcnt[wv] = inc;
             __syncthreads();
-            int tot = 0;
-            for (int w = 0; w < kImgT / 64; ++w) tot += s_wcnt[w];
-            if (tot >= P.topk) lo = mid; else hi = mid - 1;
+            int above = 0;
+            for (int w = wv + 1; w < kImgT / 64; ++w) above += s_wcnt[w];
+            const int S0 = c_above + above + inc;            // keys in bins >= 2t
+            const int S1 = S0 - h0;                          // keys in bins >= 2t + 1
+            const int S2 = S1 - h1;                          // keys in bins >= 2t + 2
+            if (S1 >= m && S2 < m) { s_sel[0] = 2 * tid + 1; s_sel[1] = S2; }        // the bin that holds the m-th largest: exactly one
+            else if (S0 >= m && S1 < m) { s_sel[0] = 2 * tid; s_sel[1] = S1; }
+            __syncthreads();
+            base += (unsigned)s_sel[0] << shift; c_above = s_sel[1];
+            __syncthreads();
+            if (shift == 0) break;
+            span_log = shift; shift = shift > 11 ? shift - 11 : 0;
         }
-        T = lo;
+        T = base;                                            // largest T with count(bits >= T) >= topk
     }
-    // gather the selected candidates in index order: every key > T, then keys == T until m are taken.  Each wave owns a
-    // contiguous slice of the candidate list: count, one block scan, then write -- no barrier inside the sweeps.
-    {
+    // gather the selected candidates: every key > T, then keys == T in index order until m are taken.  The survivors are sorted
+    // below, so their order here is free -- except among ties at T when not all of them fit.  With the keys in registers and every tie
+    // fitting (the usual case: distinct scores), each thread appends its own hits through an LDS cursor: no pass over memory.
+    bool gathered = false;
+    if (in_regs) {
+        int cg = 0, ce = 0;
+#pragma unroll
+        for (int j = 0; j < kKeyRegs; ++j) { const bool v = tid + j * kImgT < n; cg += v && kreg[j] > T; ce += v && kreg[j] == T; }
+        cg = wave_sum_i(cg); ce = wave_sum_i(ce);
+        if (tid == 0) { s_sel[0] = 0; s_sel[1] = 0; }
+        __syncthreads();
+        if (lane == 0) { if (cg) atomicAdd(&s_sel[0], cg); if (ce) atomicAdd(&s_sel[1], ce); }
+        __syncthreads();
+        const int n_gt = s_sel[0], n_eq = s_sel[1];
+        __syncthreads();
+        if (n <= P.topk || n_gt + n_eq == m) {               // every candidate at or above T is selected: no order to respect
+            if (tid == 0) s_sel[0] = 0;
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < kKeyRegs; ++j) {
+                const int i = tid + j * kImgT;
+                if (i < n && (n <= P.topk || kreg[j] >= T)) { const int pos = atomicAdd(&s_sel[0], 1); if (pos < m) { s_key[pos] = __uint_as_float(kreg[j]); s_pos[pos] = i; } }
+            }
+            __syncthreads();
+            gathered = true;
+        }
+    }
+    if (!gathered) {
+        // more ties at T than fit (or keys not in registers): index order decides.  Each wave owns a contiguous slice of the
+        // candidate list: count, one block scan, then write -- no barrier inside the sweeps.
         const int per = ((n + kImgT / 64 - 1) / (kImgT / 64) + 63) / 64 * 64;   // slice length, multiple of 64
         const int i0 = wv * per, i1 = (i0 + per) < n ? (i0 + per) : n;
         int cg = 0, ce = 0;
@@ -1157,53 +1230,120 @@ __global__ __launch_bounds__(kImgT) void greedy_nms_image_kernel(const GParams P
         }
         __syncthreads();
     }
-    // ---- sort the m survivors by (score desc, filtered position asc) in LDS
+    // ---- sort the m survivors by (score desc, filtered position asc) in LDS, then the candidate boxes (decode of the candidate's
+    //      anchor) and areas (RetinaNet.py:133-139).  Up to 128 survivors (topk = 100) ONE wave does both without a workgroup barrier
+    //      (LDS traffic of a single wave is ordered); longer lists take the whole workgroup.
     int mp = 1; while (mp < m) mp <<= 1;
-    for (int i = m + tid; i < mp; i += kImgT) { s_key[i] = -INFINITY; s_pos[i] = 0x7fffffff; }
-    __syncthreads();
-    for (int k = 2; k <= mp; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < mp / 2; t += kImgT) {
-                const int i = ((t / j) * 2 * j) + (t % j), l = i + j;
-                const bool up = ((i & k) == 0);
-                const float ki = s_key[i], kl = s_key[l]; const int pi = s_pos[i], pl = s_pos[l];
-                const bool sw = up ? before(kl, (unsigned)pl, ki, (unsigned)pi) : before(ki, (unsigned)pi, kl, (unsigned)pl);
-                if (sw) { s_key[i] = kl; s_key[l] = ki; s_pos[i] = pl; s_pos[l] = pi; }
+    if (mp < 64) mp = 64;
+    const bool one_wave = m <= 128;
+    if (one_wave) {
+        if (wv == 0) {
+            for (int i = m + lane; i < mp; i += 64) { s_key[i] = -INFINITY; s_pos[i] = 0x7fffffff; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int k = 2; k <= mp; k <<= 1)
+                for (int lj = __ffs(k) - 2; lj >= 0; --lj) {
+                    const int j = 1 << lj;
+                    for (int t = lane; t < mp / 2; t += 64) {
+                        const int i = ((t >> lj) << (lj + 1)) + (t & (j - 1)), l = i + j;
+                        const bool up = ((i & k) == 0);
+                        const float ki = s_key[i], kl = s_key[l]; const int pi = s_pos[i], pl = s_pos[l];
+                        const bool sw = up ? before(kl, (unsigned)pl, ki, (unsigned)pi) : before(ki, (unsigned)pi, kl, (unsigned)pl);
+                        if (sw) { s_key[i] = kl; s_key[l] = ki; s_pos[i] = pl; s_pos[l] = pi; }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            for (int e = lane; e < m; e += 64) {
+                const int a = cidx[s_pos[e]];
+                const Box4 bx = decode_anchor(P.loc + (o0 + a) * 4, P.anchors + (size_t)a * 4);
+                s_box[e] = make_float4(bx.x1, bx.y1, bx.x2, bx.y2);
+                s_area[e] = (bx.x2 - bx.x1 + 1.0f) * (bx.y2 - bx.y1 + 1.0f);
             }
-            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
-    }
-    // ---- candidate boxes (decode of the candidate's anchor) and areas (RetinaNet.py:133-139)
-    if (tid < m) {
-        const int a = cidx[s_pos[tid]];
-        const Box4 bx = decode_anchor(P.loc + (o0 + a) * 4, P.anchors + (size_t)a * 4);
-        s_box[tid] = make_float4(bx.x1, bx.y1, bx.x2, bx.y2);
-        s_area[tid] = (bx.x2 - bx.x1 + 1.0f) * (bx.y2 - bx.y1 + 1.0f);
-        s_alive[tid] = 1;
-    }
-    __syncthreads();
-    // ---- greedy loop (RetinaNet.py:143-169): stop WITHOUT keeping when one box is left.  <= topk boxes: ONE wave runs the
-    //      whole loop out of LDS (entry j always belongs to lane j % 64), wave reductions only -- the 4 workgroup barriers per
-    //      pivot of a block-wide loop were ~2 us x 100 pivots.
-    if (wv == 0) {
-        int K = 0, p = 0, alive = m;
-        while (alive > 1) {
-            const float4 tb = s_box[p]; const float ta = s_area[p];
-            int nxt = INT_MAX, killed = 0;
-            for (int j = lane; j < m; j += 64) {
-                if (j == p || !s_alive[j]) continue;
-                const float4 q = s_box[j];
-                const float w = fmaxf(fminf(q.z, tb.z) - fmaxf(q.x, tb.x) + 1.0f, 0.0f);     // clamp(min=x1[i]) etc.
-                const float h = fmaxf(fminf(q.w, tb.w) - fmaxf(q.y, tb.y) + 1.0f, 0.0f);
-                const float inter = w * h;
-                const float ovr = inter / (ta + s_area[j] - inter);
-                if (ovr <= P.nms_thresh) nxt = min(nxt, j); else { s_alive[j] = 0; ++killed; }
+    } else {
+        for (int i = m + tid; i < mp; i += kImgT) { s_key[i] = -INFINITY; s_pos[i] = 0x7fffffff; }
+        __syncthreads();
+        for (int k = 2; k <= mp; k <<= 1) {
+            for (int lj = __ffs(k) - 2; lj >= 0; --lj) {
+                const int j = 1 << lj;
+                for (int t = tid; t < mp / 2; t += kImgT) {
+                    const int i = ((t >> lj) << (lj + 1)) + (t & (j - 1)), l = i + j;
+                    const bool up = ((i & k) == 0);
+                    const float ki = s_key[i], kl = s_key[l]; const int pi = s_pos[i], pl = s_pos[l];
+                    const bool sw = up ? before(kl, (unsigned)pl, ki, (unsigned)pi) : before(ki, (unsigned)pi, kl, (unsigned)pl);
+                    if (sw) { s_key[i] = kl; s_key[l] = ki; s_pos[i] = pl; s_pos[l] = pi; }
+                }
+                __syncthreads();
             }
-            for (int o = 32; o > 0; o >>= 1) { nxt = min(nxt, __shfl_xor(nxt, o, 64)); killed += __shfl_xor(killed, o, 64); }
-            if (lane == (p & 63)) { s_alive[p] = 0; s_keep[K] = s_pos[p]; }
-            ++K;
-            alive -= killed + 1;
-            p = nxt == INT_MAX ? 0 : nxt;
+        }
+        if (tid < m) {
+            const int a = cidx[s_pos[tid]];
+            const Box4 bx = decode_anchor(P.loc + (o0 + a) * 4, P.anchors + (size_t)a * 4);
+            s_box[tid] = make_float4(bx.x1, bx.y1, bx.x2, bx.y2);
+            s_area[tid] = (bx.x2 - bx.x1 + 1.0f) * (bx.y2 - bx.y1 + 1.0f);
+            s_alive[tid] = 1;
+        }
+        __syncthreads();
+    }
+    // ---- greedy loop (RetinaNet.py:143-169): stop WITHOUT keeping when one box is left.  ONE wave runs it out of LDS.
+    if (wv == 0) {
+        int K = 0;
+        if (m <= 128) {
+            // overlap matrix: lane owns candidates lane and lane + 64; bit j of a row = ovr(candidate, j) > thr (symmetric: max / min
+            // and one commutative sum per term).  Then: pivot = first alive bit; keep it; alive &= ~(its row | itself).
+            unsigned long long r0lo = 0ull, r0hi = 0ull, r1lo = 0ull, r1hi = 0ull;      // rows of candidates lane / lane + 64: bits 0-63 / 64-127
+            const int e0 = lane, e1 = lane + 64;
+            const float4 b0 = e0 < m ? s_box[e0] : make_float4(0.f, 0.f, 0.f, 0.f), b1 = e1 < m ? s_box[e1] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float a0 = e0 < m ? s_area[e0] : 0.f, a1 = e1 < m ? s_area[e1] : 0.f;
+            for (int j = 0; j < m; ++j) {                    // (uniform) candidate j against this lane's two
+                const float4 q = s_box[j]; const float aj = s_area[j];
+                auto over = [&](const float4& tb, float ta) {
+                    const float w = fmaxf(fminf(q.z, tb.z) - fmaxf(q.x, tb.x) + 1.0f, 0.0f);     // clamp(min=x1[i]) etc.
+                    const float h = fmaxf(fminf(q.w, tb.w) - fmaxf(q.y, tb.y) + 1.0f, 0.0f);
+                    const float inter = w * h;
+                    return inter / (ta + aj - inter) > P.nms_thresh;
+                };
+                const bool o0b = over(b0, a0), o1b = over(b1, a1);
+                if (j < 64) { if (o0b) r0lo |= 1ull << j; if (o1b) r1lo |= 1ull << j; }
+                else { if (o0b) r0hi |= 1ull << (j - 64); if (o1b) r1hi |= 1ull << (j - 64); }
+            }
+            unsigned long long alo = m >= 64 ? ~0ull : ((1ull << m) - 1ull), ahi = m > 64 ? (m >= 128 ? ~0ull : ((1ull << (m - 64)) - 1ull)) : 0ull;
+            auto rl64 = [&](unsigned long long v, int src) {
+                return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), src) << 32) |
+                       (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, src);
+            };
+            while (__popcll(alo) + __popcll(ahi) > 1) {
+                const int p = alo ? __ffsll((long long)alo) - 1 : 64 + __ffsll((long long)ahi) - 1;
+                unsigned long long klo, khi;                 // the pivot's row
+                if (p < 64) { klo = rl64(r0lo, p); khi = rl64(r0hi, p); } else { klo = rl64(r1lo, p - 64); khi = rl64(r1hi, p - 64); }
+                if (lane == 0) s_keep[K] = s_pos[p];
+                ++K;
+                if (p < 64) alo &= ~(1ull << p); else ahi &= ~(1ull << (p - 64));
+                alo &= ~klo; ahi &= ~khi;
+            }
+        } else {
+            int p = 0, alive = m;
+            while (alive > 1) {
+                const float4 tb = s_box[p]; const float ta = s_area[p];
+                int nxt = INT_MAX, killed = 0;
+                for (int j = lane; j < m; j += 64) {
+                    if (j == p || !s_alive[j]) continue;
+                    const float4 q = s_box[j];
+                    const float w = fmaxf(fminf(q.z, tb.z) - fmaxf(q.x, tb.x) + 1.0f, 0.0f);     // clamp(min=x1[i]) etc.
+                    const float h = fmaxf(fminf(q.w, tb.w) - fmaxf(q.y, tb.y) + 1.0f, 0.0f);
+                    const float inter = w * h;
+                    const float ovr = inter / (ta + s_area[j] - inter);
+                    if (ovr <= P.nms_thresh) nxt = min(nxt, j); else { s_alive[j] = 0; ++killed; }
+                }
+                for (int o = 32; o > 0; o >>= 1) { nxt = min(nxt, __shfl_xor(nxt, o, 64)); killed += __shfl_xor(killed, o, 64); }
+                if (lane == (p & 63)) { s_alive[p] = 0; s_keep[K] = s_pos[p]; }
+                ++K;
+                alive -= killed + 1;
+                p = nxt == INT_MAX ? 0 : nxt;
+            }
         }
         if (lane == 0) s_p = K;
     }
@@ -1220,7 +1360,7 @@ __global__ __launch_bounds__(kImgT) void greedy_nms_image_kernel(const GParams P
     if (tid == 0) { P.out_counts[b * 2] = K; P.out_counts[b * 2 + 1] = n; }
 }
 
-struct GPlan { size_t score, label, ckey, cidx, tile_cnt, total; int ntiles; };
+struct GPlan { size_t score, label, ckey, cidx, tile_cnt, ncand, total; int ntiles; };
 bool make_gplan(const odpl_greedy_nms_desc_t* d, GPlan* p) {
     if (!d || d->B < 1 || d->An < 1 || d->An >= (1 << 24) || d->C < 1 || d->topk < 1 || d->topk > kMaxTopk) return false;
     if (!d->loc || !d->cls || !d->anchors) return false;
@@ -1233,6 +1373,7 @@ bool make_gplan(const odpl_greedy_nms_desc_t* d, GPlan* p) {
     p->cidx = off;  off += align_up(BN * 4, 256);
     p->ntiles = (d->An + kRows - 1) / kRows;
     p->tile_cnt = off; off += align_up((size_t)d->B * p->ntiles * 4, 256);
+    p->ncand = off; off += align_up((size_t)d->B * 4, 256);
     p->total = off;
     return true;
 }
@@ -1253,7 +1394,7 @@ extern "C" int odpl_greedy_nms(const odpl_greedy_nms_desc_t* d, void* workspace,
     P.loc = d->loc; P.cls = d->cls; P.anchors = d->anchors; P.B = d->B; P.An = d->An; P.C = d->C; P.topk = d->topk;
     P.nms_thresh = d->nms_thresh; P.class_thresh = d->class_thresh;
     P.score = (float*)(ws + pl.score); P.label = (int*)(ws + pl.label); P.ckey = (float*)(ws + pl.ckey); P.cidx = (int*)(ws + pl.cidx);
-    P.tile_cnt = (int*)(ws + pl.tile_cnt); P.ntiles = pl.ntiles;
+    P.tile_cnt = (int*)(ws + pl.tile_cnt); P.ntiles = pl.ntiles; P.ncand = (int*)(ws + pl.ncand);
     P.magic_c = fastdiv16_magic((unsigned)d->C); P.magic_c4 = fastdiv16_magic((unsigned)(d->C >> 2));
     P.out = out_dets; P.out_counts = out_counts;
     prof_begin(ODPL_PROF_GREEDY_NMS_PREP, stream);
@@ -1262,6 +1403,10 @@ extern "C" int odpl_greedy_nms(const odpl_greedy_nms_desc_t* d, void* workspace,
     prof_end(ODPL_PROF_GREEDY_NMS_PREP, stream);
     ODPL_HIP_TRY(hipGetLastError());
     prof_begin(ODPL_PROF_GREEDY_NMS_IMAGE, stream);
+    hipLaunchKernelGGL(greedy_nms_scan_kernel, dim3(d->B), dim3(kImgT), 0, stream, P);
+    ODPL_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(greedy_nms_scatter_kernel, dim3((pl.ntiles + (kScT / 64) * kScTU - 1) / ((kScT / 64) * kScTU), d->B), dim3(kScT), 0, stream, P);
+    ODPL_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(greedy_nms_image_kernel, dim3(d->B), dim3(kImgT), 0, stream, P);
     prof_end(ODPL_PROF_GREEDY_NMS_IMAGE, stream);
     ODPL_HIP_TRY(hipGetLastError());

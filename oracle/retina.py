@@ -107,7 +107,9 @@ def greedy_nms(loc_preds, cls_preds, anchors, topk=100, nms_thresh=0.5, class_th
         bb, sc = boxes[ids], score[ids]
         x1, y1, x2, y2 = bb[:, 0], bb[:, 1], bb[:, 2], bb[:, 3]
         areas = (x2 - x1 + 1) * (y2 - y1 + 1)
-        order = sc.sort(0, descending=True)[1][:topk].tolist()
+        # (stable: among equal scores the first in index order -- the reference's plain sort leaves ties unspecified, RetinaNet.py:140;
+        # its fixtures hold no ties, the kernels define them like this)
+        order = sc.sort(dim=0, descending=True, stable=True)[1][:topk].tolist()
         keep = []
         while len(order) > 1:
             i = order[0]
