@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$C /tmp/pmck_$C
   ( while true; do sleep 60; echo "[alive $(date +%T)]"; done ) & HB=$!
-  timeout -k 10 600 rocprofv3 --pmc $C --kernel-trace --kernel-include-regex "yolo_|headgrad_" --output-format csv -d /tmp/pmc_$C -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline $EXTRA > $ROOT/gpurun_out/prof/pmc_${C}_bench.log 2> $ROOT/gpurun_out/prof/pmc_${C}_bench.err
+  timeout -k 10 600 rocprofv3 --pmc $C --kernel-trace --kernel-include-regex "yolo_|headgrad_" --output-format csv -d /tmp/pmc_$C -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary $EXTRA > $ROOT/gpurun_out/prof/pmc_${C}_bench.log 2> $ROOT/gpurun_out/prof/pmc_${C}_bench.err
   echo "$C exit=$?"; kill $HB
   F=$(find /tmp/pmc_$C -name '*counter_collection.csv' | head -1)
   python3 - "$F" "$C" > $ROOT/gpurun_out/prof/${TAG:-r02}_pmc_${C}.csv <<'PY'

@@ -5,7 +5,7 @@ ROOT=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 ( while true; do sleep 60; echo "[alive $(date +%T)]"; done ) &
 HB=$!
-timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_raw_$TAG -- python3 $ROOT/bench.py --steps ${STEPS:-10} --warmup ${WARMUP:-3} --no-cpu-baseline $EXTRA > $ROOT/gpurun_out/prof/${TAG}_bench.log 2> $ROOT/gpurun_out/prof/${TAG}_bench.err
+timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_raw_$TAG -- python3 $ROOT/bench.py --steps ${STEPS:-10} --warmup ${WARMUP:-3} --no-cpu-baseline --no-secondary $EXTRA > $ROOT/gpurun_out/prof/${TAG}_bench.log 2> $ROOT/gpurun_out/prof/${TAG}_bench.err
 echo exit=$? >> $ROOT/gpurun_out/prof/${TAG}_bench.log
 kill $HB
 T=$(find /tmp/prof_raw_$TAG -name '*kernel_trace.csv' | head -1)
