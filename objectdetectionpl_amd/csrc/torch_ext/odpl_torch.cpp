@@ -220,6 +220,7 @@ Tensor bn_act(Tensor x, Tensor weight, Tensor bias, Tensor running_mean, Tensor 
     if (!training && !wants_grad) return bn_act_infer(x, weight, bias, running_mean, running_var, eps, act, res.has_value() ? *res : Tensor());
     return BnActFn::apply(x, weight, bias, running_mean, running_var, num_batches_tracked, training, momentum, eps, act, res);
 }
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
