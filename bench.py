@@ -196,12 +196,13 @@ def cpu_baseline(B_sample, C, img, steps, warmup=1):
                       f"{1e3 * loss_s / steps:.0f} ms/step"}
 
 
-def rocprof_row(kernel):
+def rocprof_row(kernel, only_current=False):
     """Average duration of `kernel` in the committed `rocprofv3 --kernel-trace --stats` summary of this command
     (profiles/r04_rocprof_stats_bench.csv; the dense route's expand kernel: the round-2 pass of `--no-fused-head-backward`), so the live
     event timing and the profiler's figure sit side by side."""
     import csv
-    for name in ("r04_rocprof_stats_bench.csv", "r02dense_rocprof_stats_bench.csv"):
+    files = ("r04_rocprof_stats_bench.csv",) if only_current else ("r04_rocprof_stats_bench.csv", "r02dense_rocprof_stats_bench.csv")
+    for name in files:
         try:
             with open(os.path.join(REPO, "profiles", name)) as f:
                 for row in csv.DictReader(f):
@@ -535,7 +536,9 @@ def main():
         achieved, frac_src = min(cands) if cands else (None, None)
         launches_us = {k: round(1e3 * sum(v[0]) / len(v[0]), 2) for k, v in prof.items() if v[0]}
         loss_keys = [k for k in launches_us if k.startswith("yolo_") and k not in ("yolo_expand", "yolo_patch")]
-        rp_loss = {k: rocprof_row(k + "_kernel") for k in loss_keys}
+        # (the profile key "yolo_loss" is the fused assignment + loss launch up to 512 target rows: yolo_fused_kernel)
+        rp_loss = {k: (rocprof_row("yolo_fused_kernel", True) if k == "yolo_loss" and "yolo_assign" not in launches_us else None)
+                   or rocprof_row(k + "_kernel", True) for k in loss_keys}
         loss_live = round(sum(launches_us[k] for k in loss_keys), 2)
         loss_rp = round(sum(v["avg_us"] for v in rp_loss.values()), 2) if loss_keys and all(v is not None for v in rp_loss.values()) else None
         loss_path = {"launches": loss_keys, "live_us": {k: launches_us[k] for k in loss_keys}, "live_sum_us": loss_live,

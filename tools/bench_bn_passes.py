@@ -15,8 +15,6 @@ dev = torch.device("cuda:0")
 shapes = [(16, 32, 416, 416), (16, 64, 208, 208), (16, 128, 104, 104), (16, 256, 52, 52), (16, 512, 26, 26), (16, 1024, 13, 13)]
 _s = os.environ.get("SHAPE", "0")
 shp = tuple(int(v) for v in _s.split(",")) if "," in _s else shapes[int(_s)]
-if "FUSED" in os.environ:
-    _lib.tune_set("bn_fused", int(os.environ["FUSED"]))
 if "TB" in os.environ:
     _lib.tune_set("bn_target_blocks", int(os.environ["TB"]))
 if "SB" in os.environ:
