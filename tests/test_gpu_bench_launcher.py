@@ -37,3 +37,31 @@ def test_bench_self_launches_two_ranks():
     assert d["config"]["miopen"].startswith("immediate mode")                    # one solver choice for every rank: no per-rank search
     assert "secondary" not in d and "cpu_baseline" not in d                      # N = 1 only
     assert d["loss_path"]["budget_us"] == 20.7 and d["loss_path"]["live_sum_us"] > 0
+
+
+@pytest.mark.gpu
+def test_default_bench_line_carries_the_contract_and_the_secondary_configs():
+    """`python bench.py` (N = 1, a short run): ONE JSON line with the contract's keys, `roofline` (frac = the lower of the live and the
+    committed rocprofv3 figure), `loss_path` against SURVEY 8d's budget, `cpu_baseline` (the oracle on the host cores) and -- VERDICT r03
+    item 5 -- BASELINE configs 4 and 5 as `secondary` legs."""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "4", "--warmup", "2", "--cpu-sample-steps", "1",
+                        "--secondary-steps", "2"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["dtype"] == "f32" and d["vs_baseline"] is None and "workload" in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and 0 < rf["frac"] <= rf["frac_live_events"] + 1e-9 and rf["frac_source"]
+    lp = d["loss_path"]
+    assert lp["launches"] == ["yolo_loss", "yolo_finalize"] and lp["budget_us"] == 20.7 and 0 < lp["live_sum_us"] < 40    # assignment inside the loss launch
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
+    sec = d["secondary"]
+    for k in ("config4", "config4_small_boxes", "config5"):
+        assert sec[k].get("img_per_s", 0) > 0, (k, sec[k])
+    assert sec["config4"]["num_pos"] > 0 and sec["config4"]["loss_driven_forward"] and sec["config5"]["head_dtype"] == "torch.bfloat16"
