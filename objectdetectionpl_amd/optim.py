@@ -27,7 +27,9 @@ class Adam(torch.optim.Adam):
     one_launch = True                   # class switch (bench.py --torch-adam): False = torch's own step
 
     def _tables(self, gi, params):
-        key = tuple(id(p) for p in params)
+        # the cached table holds ADDRESSES: it is valid for these parameter objects at these storages only (a `model.to(...)` or a
+        # `p.data = ...` after the first step moves a parameter without changing its identity)
+        key = tuple((id(p), p.data_ptr()) for p in params)
         c = self._flat.get(gi)
         if c is not None and c["key"] == key:
             return c

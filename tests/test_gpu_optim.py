@@ -74,3 +74,13 @@ def test_state_dict_round_trip_and_fallbacks():
     pb.grad = gn.clone().contiguous(memory_format=torch.channels_last)
     o3.step(); o4.step()
     assert o3._flat and torch.equal(pa, pb)
+    # a parameter whose storage is replaced after the first step (model.to(memory_format=...), p.data = ...): the address table is rebuilt
+    q1, q2 = torch.nn.Parameter(w.clone()), torch.nn.Parameter(w.clone())
+    o5, o6 = Adam([q1], lr=1e-3), torch.optim.Adam([q2], lr=1e-3, fused=True)
+    for k in range(2):
+        g5 = torch.randn(8, 4, 3, 3, device=dev).contiguous(memory_format=torch.channels_last)
+        q1.grad, q2.grad = g5.clone(), g5.clone()
+        o5.step(); o6.step()
+        if k == 0:
+            q1.data = q1.data.clone()              # same values and strides, another allocation
+    assert torch.equal(q1, q2)
