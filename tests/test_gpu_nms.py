@@ -265,3 +265,20 @@ def test_greedy_nms_ties_at_the_topk_threshold_take_the_first_in_index_order():
         assert torch.equal(o[:, 4], r[:, 4]) and torch.equal(o[:, 6], r[:, 6])                   # the same candidates, in the same order
         assert torch.allclose(o[:, 5], r[:, 5], rtol=1e-6, atol=1e-7)                             # (device vs host expf in the sigmoid)
         assert torch.allclose(o[:, :4], r[:, :4], rtol=1e-5, atol=1e-3)
+
+
+def test_greedy_nms_longer_topk_takes_the_sweep_loop():
+    """topk = 300 (> 128 survivors): the workgroup-wide sort and the sweep loop instead of one wave's overlap matrix; vs the oracle"""
+    from objectdetectionpl_amd.LightningFunc.nms import greedy_non_max_suppression
+    g = torch.Generator().manual_seed(78)
+    An, C = 9000, 5
+    anchors = torch.cat([torch.rand(An, 2, generator=g) * 600 + 50, torch.rand(An, 2, generator=g) * 60 + 20], 1)
+    loc = torch.randn(2, An, 4, generator=g) * 0.1
+    cls = torch.randn(2, An, C, generator=g) * 1.5 - 1.0
+    ref = oracle_retina.greedy_nms(loc, cls, anchors, topk=300, nms_thresh=0.5, class_thresh=0.45)
+    out = greedy_non_max_suppression((loc.cuda(), cls.cuda()), anchors.cuda(), topk=300)
+    for r, o in zip(ref, out):
+        o = o.cpu()
+        assert o.shape == r.shape and o.shape[0] > 50
+        assert torch.equal(o[:, 4], r[:, 4]) and torch.equal(o[:, 6], r[:, 6])
+        assert torch.allclose(o[:, 5], r[:, 5], rtol=1e-6, atol=1e-7) and torch.allclose(o[:, :4], r[:, :4], rtol=1e-5, atol=1e-3)

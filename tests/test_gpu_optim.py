@@ -84,3 +84,14 @@ def test_state_dict_round_trip_and_fallbacks():
         if k == 0:
             q1.data = q1.data.clone()              # same values and strides, another allocation
     assert torch.equal(q1, q2)
+
+
+def test_more_tensors_than_one_launch_carries():
+    """ODPL_ADAM_MAX_TENSORS = 384 gradient addresses fit the kernel-argument block: 900 parameters take three launches"""
+    from objectdetectionpl_amd.optim import Adam
+    shapes = [(17 + i % 5, 3) for i in range(900)]
+    mine, om = _run(lambda ps: Adam(ps, lr=1e-3, weight_decay=1e-5), shapes, 2, 8)
+    ref, ot = _run(lambda ps: torch.optim.Adam(ps, lr=1e-3, weight_decay=1e-5, fused=True), shapes, 2, 8)
+    assert om._flat
+    for p, q in zip(mine, ref):
+        assert torch.equal(p, q)

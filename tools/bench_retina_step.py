@@ -17,6 +17,9 @@ from objectdetectionpl_amd.LightningFunc.utils.RetinaUtils import get_anchor_box
 from objectdetectionpl_amd.model.RetinaNet import RetinaNet
 
 
+from objectdetectionpl_amd.optim import Adam as OdplAdam
+
+
 class Args:
     model_name = "RetinaNet"; cls_criterion = "focal_loss"; coord_criterion = "smooth_l1_loss"; data_module = "synthetic"
     lr = 1e-3; weight_decay = 1e-5
@@ -42,7 +45,7 @@ def _measure(a, dev, retinahead, sparseconv, log):
     model = RetinaNet([str(i) for i in range(80)], Args()).to(dev).to(memory_format=torch.channels_last).train()
     anchors = get_anchor_boxes(torch.Tensor([a.width, a.height]), dev)              # RetinaUtils.get_anchor_boxes takes (w, h)
     crit = RetinaNetLoss(anchors, focal_loss, "smooth_l1_loss", 80, (a.width, a.height))
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5, fused=True)
+    opt = OdplAdam(model.parameters(), lr=1e-3, weight_decay=1e-5)             # what configure_optimizers returns (optimizer.py:6-38)
     g = torch.Generator().manual_seed(1)
     x = torch.rand(a.batch, 3, a.height, a.width, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
     n = a.batch * a.gt_per_image

@@ -14,6 +14,9 @@ import torch
 from objectdetectionpl_amd.model.YOLOV5 import YOLOv5
 
 
+from objectdetectionpl_amd.optim import Adam as OdplAdam
+
+
 class Args:
     model_name = "YOLOv5"; cls_criterion = "bce_loss"; coord_criterion = "smooth_l1_loss"; data_module = "synthetic"
     type = "Yolov5l"; lr = 1e-3; weight_decay = 1e-5
@@ -30,7 +33,7 @@ def run(dtype="bf16", batch=32, img=640, steps=10, warmup=3, type_="Yolov5l", mi
         Args.type = type_
         model = YOLOv5([str(i) for i in range(80)], Args()).to(dev).to(memory_format=torch.channels_last).train()
         model.img_size = img
-        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5, fused=True)
+        opt = OdplAdam(model.parameters(), lr=1e-3, weight_decay=1e-5)             # what configure_optimizers returns (optimizer.py:6-38)
         g = torch.Generator().manual_seed(1)
         x = torch.rand(batch, 3, img, img, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
         n = batch * 7
