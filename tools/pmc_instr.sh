@@ -4,7 +4,7 @@
 ROOT=$GRAFT_REPO_ROOT
 rm -rf /tmp/pmc_instr
 ( cd /tmp && TMPDIR=/tmp timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY --kernel-trace \
-    --kernel-include-regex "bn_reduce|bn_apply|bn_bwd_dx|spp_|s2d|focus" --output-format csv -d /tmp/pmc_instr -- python3 $ROOT/tools/pmc_instr.py > $ROOT/gpurun_out/pmc_instr.log 2>&1 )
+    --kernel-include-regex "bn_reduce|bn_apply|bn_bwd_dx|spp_|s2d|focus|yolo_nms_prep|bias_act_bwd|v5_expand" --output-format csv -d /tmp/pmc_instr -- python3 $ROOT/tools/pmc_instr.py > $ROOT/gpurun_out/pmc_instr.log 2>&1 )
 F=$(find /tmp/pmc_instr -name '*counter_collection.csv' 2>/dev/null | sort | sed -n 1p)
 if [ -z "$F" ]; then echo "no counter_collection.csv"; tail -5 $ROOT/gpurun_out/pmc_instr.log; exit 1; fi
 python3 - "$F" > $ROOT/gpurun_out/r04_pmc_instr.csv <<'PY'
