@@ -27,12 +27,13 @@
 extern "C" {
 #endif
 
-#define ODPL_ABI_VERSION 6   /* 3: memory-format strides + compact (structured) gradients on the YOLO losses, head-conv backward from them;
+#define ODPL_ABI_VERSION 7   /* 3: memory-format strides + compact (structured) gradients on the YOLO losses, head-conv backward from them;
                               * 4: odpl_retina_loss_desc_t grew pos_anchor / num_pos (ODPL_RETINA_ROWS_ONLY), odpl_retina_heads_backward
                               * 5: odpl_sparse_conv3x3_t grew stats; ODPL_RETINA_ASSIGN_ONLY / _ASSIGNED, odpl_pixel_support, odpl_sparse_conv3x3_forward,
                               *    ksize on both sparse-convolution descriptors, odpl_pixel_union_lists, odpl_sparse_upsample_add
                               * 6: the two probes left the library (tools/probes/: odpl_conv1x1_*, odpl_bn_fused_*, ODPL_TUNE_BN_FUSED*);
-                              *    odpl_adam_step; ODPL_YOLO_NMS_ONE_WORKGROUP; ODPL_TUNE_YOLO_FUSED_MAX_TARGETS */
+                              *    odpl_adam_step; ODPL_YOLO_NMS_ONE_WORKGROUP; ODPL_TUNE_YOLO_FUSED_MAX_TARGETS
+                              * 7: odpl_sparse_grad_t grew n_rows_dev (the produced row count of a capacity-sized row list) */
 #define ODPL_EINVAL (-1)
 #define ODPL_MAX_SCALES 4
 #define ODPL_MAX_ANCHORS 8
@@ -126,11 +127,14 @@ int odpl_yolo_region_loss_backward(const odpl_yolo_loss_desc_t* desc, const void
  *   dense     f32 [B*A*G2]: gradient of channel a*no + dense_ch of every cell, in the layout's cell order
  *             (planar: (b*A + a)*G2 + s; interleaved: (b*G2 + s)*A + a)
  *   rows      f32 [n_rows, no]: gradient of the `no` channels of anchor a at one cell (slot dense_ch is ignored: it is in `dense`)
- *   row_cell  int32 [n_rows]: that cell (same order as `dense`), or -1 = no row */
+ *   row_cell  int32 [n_rows]: that cell (same order as `dense`), or -1 = no row
+ *   n_rows_dev  optional device scalar <= n_rows: rows at and beyond it all carry row_cell -1 (a list sized for its capacity whose
+ *             count never visits the host: the YOLOv5 loss); a hint that lets consumers stop early, NULL = none */
 typedef struct {
     const float* dense;
     const float* rows;
     const int32_t* row_cell;
+    const int32_t* n_rows_dev;
     int32_t n_rows, B, G2, A, no, dense_ch, layout;
 } odpl_sparse_grad_t;
 /* the compact gradient of scale `scale` as left by odpl_yolo_region_loss_forward (host-side pointer arithmetic only) */

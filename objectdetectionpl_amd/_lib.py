@@ -6,7 +6,7 @@ from ctypes import POINTER, c_float, c_int32, c_size_t, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libodpl_hip.so")
 
-ABI_VERSION = 6            # include/odpl_hip.h: ODPL_ABI_VERSION
+ABI_VERSION = 7            # include/odpl_hip.h: ODPL_ABI_VERSION
 LAYOUT_PLANAR, LAYOUT_INTERLEAVED = 0, 1
 MAX_SCALES = 4
 MAX_ANCHORS = 8
@@ -26,7 +26,7 @@ class YoloScale(ctypes.Structure):
 
 class SparseGrad(ctypes.Structure):
     """odpl_sparse_grad_t: a structured head gradient (host struct, device pointers)."""
-    _fields_ = [("dense", c_void_p), ("rows", c_void_p), ("row_cell", c_void_p),
+    _fields_ = [("dense", c_void_p), ("rows", c_void_p), ("row_cell", c_void_p), ("n_rows_dev", c_void_p),
                 ("n_rows", c_int32), ("B", c_int32), ("G2", c_int32), ("A", c_int32), ("no", c_int32), ("dense_ch", c_int32), ("layout", c_int32)]
 
 

@@ -989,7 +989,7 @@ extern "C" int odpl_yolo_compact_view(const odpl_yolo_loss_desc_t* d, const void
     out->dense = (const float*)(c + pl.gconf_off[scale]);
     out->rows = (const float*)(c + pl.gobj_off[scale]);
     out->row_cell = (const int32_t*)(c + pl.tcell_off[scale]);
-    out->n_rows = d->nT;
+    out->n_rows = d->nT; out->n_rows_dev = nullptr;
     out->B = d->B; out->G2 = d->scale[scale].G * d->scale[scale].G; out->A = d->scale[scale].A; out->no = 5 + d->C;
     out->dense_ch = 4;
     out->layout = pl.layout[scale];

@@ -623,6 +623,7 @@ extern "C" int odpl_yolov5_compact_view(const odpl_yolov5_loss_desc_t* d, const 
         out->rows = (const float*)(c + pl.row_grad[layer]);
         out->row_cell = (const int32_t*)(c + pl.row_cell[layer]);
         out->n_rows = pl.cap;                                     // rows beyond the produced count carry row_cell = -1
+        out->n_rows_dev = (const int32_t*)(c + pl.nrows[layer]);
         out->B = d->B; out->G2 = d->layer[layer].G * d->layer[layer].G; out->A = d->na; out->no = pl.no; out->dense_ch = 4;
         out->layout = ODPL_LAYOUT_PLANAR;                         // the CELL order (b*na + a)*G2 + s, whatever the memory format of p
     }

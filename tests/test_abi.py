@@ -21,7 +21,7 @@ def test_header_symbols_exported_and_bound():
     for n in names:
         assert hasattr(raw, n), f"{n} declared in odpl_hip.h but not exported"
     assert sorted(_lib.SIGNATURES) == names, (set(names) ^ set(_lib.SIGNATURES))
-    assert _lib.lib().odpl_abi_version() == _lib.ABI_VERSION == 6
+    assert _lib.lib().odpl_abi_version() == _lib.ABI_VERSION == 7
 
 
 def test_struct_layout_matches_header():
@@ -30,7 +30,7 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(_lib.YoloScale) == 8 + 8 + 4 + 4 + 4 * 16 + 8 * 4
     assert _lib.YoloScale.stride.offset == 88
     # odpl_sparse_grad_t: 3 pointers + 7 int32 (+pad)
-    assert ctypes.sizeof(_lib.SparseGrad) == 56
+    assert ctypes.sizeof(_lib.SparseGrad) == 64
     # odpl_yolo_loss_desc_t: 8 int32 + 3 float (+pad) + pointer + 4 scales
     assert _lib.YoloLossDesc.target.offset == 48
     assert ctypes.sizeof(_lib.YoloLossDesc) == 56 + 4 * ctypes.sizeof(_lib.YoloScale)
@@ -48,7 +48,7 @@ def test_ctypes_layouts_against_the_compiled_header(tmp_path):
     cases = [("odpl_retina_loss_desc_t", _lib.RetinaLossDesc, "num_pos"), ("odpl_retina_head_t", _lib.RetinaHead, "no"),
              ("odpl_retina_heads_desc_t", _lib.RetinaHeadsDesc, "upstream"), ("odpl_sparse_conv3x3_t", _lib.SparseConv3x3, "stats"),
              ("odpl_pixel_support_t", _lib.PixelSupport, "counts"), ("odpl_sparse_conv3x3_fwd_t", _lib.SparseConv3x3Fwd, "ksize"),
-             ("odpl_yolo_scale_t", _lib.YoloScale, "stride"), ("odpl_sparse_grad_t", _lib.SparseGrad, None),
+             ("odpl_yolo_scale_t", _lib.YoloScale, "stride"), ("odpl_sparse_grad_t", _lib.SparseGrad, "layout"),
              ("odpl_adam_desc_t", _lib.AdamDesc, "weight_decay"), ("odpl_yolo_nms_desc_t", _lib.YoloNmsDesc, "flags")]
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{REPO}/include/odpl_hip.h"', 'int main(void) {']
     for cname, _, last in cases:

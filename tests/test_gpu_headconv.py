@@ -319,7 +319,7 @@ def test_structured_backward_under_the_rccl_gradient_averager():
 
 @pytest.mark.parametrize("layout", [0, 1])
 def test_c_abi_head_conv_backward_row_list_longer_than_one_lds_chunk(layout):
-    """9 500 rows on a 13 x 13 x 2 map: the finish launch walks the list in chunks of 4 096; cell-rows are shared by dozens of
+    """9 500 rows on a 13 x 13 x 2 map: the finish launch walks the list in chunks (1 792 rows); cell-rows are shared by dozens of
     rows spread over different chunks (the first of them rewrites the dX row, in row order); against float64 dense math."""
     from objectdetectionpl_amd import _lib
     g = torch.Generator().manual_seed(77)
@@ -357,6 +357,55 @@ def test_c_abi_head_conv_backward_row_list_longer_than_one_lds_chunk(layout):
     _close(outs[0][2], ref_gb, 1e-4, 1e-5)
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)                        # chunked or not: bitwise reproducible
+
+
+@pytest.mark.parametrize("bf16,Cin,produced,capacity", [(True, 1024, 700, 3360), (False, 256, 90, 240), (True, 512, 2500, 3000), (False, 64, 0, 64)])
+def test_c_abi_head_conv_backward_capacity_sized_row_list(bf16, Cin, produced, capacity):
+    """YOLOv5's row list (odpl_yolov5_compact_view): `capacity` row slots of which the first `produced` are rows and the rest carry cell
+    -1, the count on the device (n_rows_dev).  Same dX / dW / db, bit for bit, as the same list without the count (the count is a
+    hint that stops the scans early), and both match float64 dense math.  700 of 3 360 bf16 rows at Cin = 1 024: the (c) grid is
+    past one resident wave -> 64-column slices, four rounds of the combine; 2 500 rows: two chunks of the row list; 0 rows."""
+    from objectdetectionpl_amd import _lib
+    g = torch.Generator().manual_seed(produced + Cin)
+    A, no, G, B, dc, layout = 3, 13, 9, 2, 4, 0
+    G2 = G * G
+    N = B * G2
+    x = torch.randn(N, Cin, generator=g)
+    x = x.bfloat16() if bf16 else x
+    w = torch.randn(A * no, Cin, generator=g) * 0.1
+    gd = torch.randn(B * A * G2, generator=g)
+    gr = torch.randn(capacity, no, generator=g) * 0.1
+    cells = torch.full((capacity,), -1, dtype=torch.int32)
+    cells[:produced] = torch.randint(0, B * A * G2, (produced,), generator=g, dtype=torch.int32)        # cell-rows shared by many rows
+    dense = _dense_from_sparse(gd, gr[:produced], cells[:produced], B, G2, A, no, dc, layout)
+    xd = x.double().view(B, G2, Cin)
+    ref_gx = torch.einsum("bos,oc->bsc", dense, w.double()).reshape(N, Cin)
+    ref_gw = torch.einsum("bos,bsc->oc", dense, xd)
+    ref_gb = dense.sum((0, 2))
+    L = _lib.lib()
+    t = {k: v.to(DEV) for k, v in dict(x=x, w=w, gd=gd, gr=gr, cells=cells).items()}
+    count = torch.tensor([produced], dtype=torch.int32, device=DEV)
+    outs = []
+    for hint in (count.data_ptr(), None):
+        gx, gw, gb = torch.empty_like(t["x"]), torch.empty_like(t["w"]), torch.empty(A * no, device=DEV)
+        sg = _lib.SparseGrad(dense=t["gd"].data_ptr(), rows=t["gr"].data_ptr(), row_cell=t["cells"].data_ptr(), n_rows_dev=hint, n_rows=capacity,
+                             B=B, G2=G2, A=A, no=no, dense_ch=dc, layout=layout)
+        h = _lib.HeadConv(x=t["x"].data_ptr(), w=t["w"].data_ptr(), grad_x=gx.data_ptr(), grad_w=gw.data_ptr(), grad_b=gb.data_ptr(),
+                          upstream=None, Cin=Cin, bf16=1 if bf16 else 0)
+        nb = L.odpl_head_conv_backward_workspace_bytes(ctypes.byref(h), ctypes.byref(sg))
+        assert nb > 0
+        ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+        _lib.check(L.odpl_head_conv_backward(ctypes.byref(h), ctypes.byref(sg), _lib.ptr(ws), nb, _lib.current_stream(torch.device(DEV))), "head")
+        torch.cuda.synchronize()
+        outs.append((gx, gw, gb))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    if bf16:
+        _close(outs[0][0].float(), ref_gx, 1e-2, 1e-2)      # one bf16 rounding of the result
+    else:
+        _close(outs[0][0], ref_gx, 1e-4, 1e-5)
+    _close(outs[0][1], ref_gw, 1e-4, 1e-5)
+    _close(outs[0][2], ref_gb, 1e-4, 1e-5)
 
 
 def test_region_loss_with_more_targets_than_one_lds_chunk_stays_on_the_structured_route():
