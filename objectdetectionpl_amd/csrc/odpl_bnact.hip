@@ -274,7 +274,7 @@ __global__ __launch_bounds__(kT) void bn_bwd_dx_kernel(const BnParams P) {
 // activations whose derivative is a function of the output's sign.  Geometry and partial layout of the reduce passes.
 template <int ACT>
 __global__ __launch_bounds__(kT) void bias_act_bwd_kernel(const BnParams P) {
-    constexpr int K = 4;
+    constexpr int K = 8;
     extern __shared__ double s_red[];
     const int C = P.C, c4n = C >> 2;
     const int sq0 = blockIdx.y * P.slice_q;

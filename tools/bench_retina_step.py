@@ -118,6 +118,9 @@ def main():
                          "positives on the large FPN levels, where the loss-driven step has more pixels to evaluate)")
     ap.add_argument("--min-pixels", type=int, default=None, help="sparseconv.min_pixels: levels with fewer B*H*W pixels keep the library route")
     a = ap.parse_args()
+    if not a.miopen_find:
+        from objectdetectionpl_amd.miopen import stage_user_db
+        stage_user_db()                                   # the committed find-db, as bench.py's secondary leg and the Trainer run
     from objectdetectionpl_amd.LightningFunc.utils import sparseconv
     sparseconv.enabled = not a.dense_tower_backward
     if a.min_pixels is not None:

@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--no-upsample-cat", action="store_true", help="A/B: neck merges as upsample followed by torch.cat")
     ap.add_argument("--no-bn-of-cat", action="store_true", help="A/B: BottleneckCSP with torch.cat before its BatchNorm (the reference's op sequence)")
     a = ap.parse_args()
+    if not a.miopen_find:
+        from objectdetectionpl_amd.miopen import stage_user_db
+        stage_user_db()                                   # the committed find-db, as bench.py's secondary leg and the Trainer run
     from objectdetectionpl_amd.LightningFunc.losses_dense import MultiScaleRegionLoss_v5
     from objectdetectionpl_amd.LightningFunc.utils.headconv import HeadConv2d
     from objectdetectionpl_amd.model.YOLOV5 import Yolo_Layers
