@@ -33,7 +33,9 @@ extern "C" {
                               *    ksize on both sparse-convolution descriptors, odpl_pixel_union_lists, odpl_sparse_upsample_add
                               * 6: the two probes left the library (tools/probes/: odpl_conv1x1_*, odpl_bn_fused_*, ODPL_TUNE_BN_FUSED*);
                               *    odpl_adam_step; ODPL_YOLO_NMS_ONE_WORKGROUP; ODPL_TUNE_YOLO_FUSED_MAX_TARGETS
-                              * 7: odpl_sparse_grad_t grew n_rows_dev (the produced row count of a capacity-sized row list) */
+                              * 7: odpl_sparse_grad_t grew n_rows_dev (the produced row count of a capacity-sized row list); odpl_retina_heads_desc_t
+                              *    grew rows_per_image / flags (ODPL_HEADS_SHARED_INPUT); odpl_ssd_loss_desc_t grew flags / active / active_count
+                              *    (ODPL_SSD_ROWS_ONLY), odpl_ssd_level_lists */
 #define ODPL_EINVAL (-1)
 #define ODPL_MAX_SCALES 4
 #define ODPL_MAX_ANCHORS 8
@@ -326,8 +328,13 @@ int odpl_yolov5_compact_view(const odpl_yolov5_loss_desc_t* desc, const void* co
  * onto (level, pixel, anchor k) and only the num_pos rows of pos_anchor are non-zero.  What aten::convolution_backward computes from the
  * dense tensors, from those rows alone:  dW[k*no + c, :, ky, kx] += g[c] * X[b, y+ky-1, x+kx-1, :],  db[k*no + c] += g[c],
  * dX[b, y+ky-1, x+kx-1, :] += sum_c g[c] * W[k*no + c, :, ky, kx].  Every output is fully written (dX is zero away from the positives);
- * no float atomics.  X / dX: channels-last fp32 [B, H_l, W_l, Cin] per level, Cin % 4 == 0, Cin <= 448; weights through their element
- * strides (NCHW-contiguous or channels-last parameters).  The workspace query returns 0 for a descriptor outside these limits. */
+ * no float atomics.  X / dX: channels-last fp32 [B, H_l, W_l, Cin] per level, Cin % 4 == 0, min(no, 80) * Cin <= 37 000 (Cin <= 448 for
+ * RetinaNet's 80-class head; SSD's 21-class heads on 1024 channels fit), A <= 10; weights through their element strides
+ * (NCHW-contiguous or channels-last parameters).  The workspace query returns 0 for a descriptor outside these limits.
+ * SSD (model/SSD.py:249-310: cl{i} / bbx{i} = Conv2d(Cin_i, n_i * C | n_i * 4, 3, padding=1) on six sources with their own weights,
+ * channel counts and prior counts) is one call per source: nlevels = 1, the two heads hang on the SAME input (ODPL_HEADS_SHARED_INPUT:
+ * one dX = both heads' sum), grad_rows point at the source's first prior inside the [B, 8732, no] tensors (rows_per_image = 8732) and
+ * pos_anchor is the source's own list (odpl_ssd_level_lists). */
 #define ODPL_RETINA_LEVELS 5
 typedef struct {
     const float* x[ODPL_RETINA_LEVELS];      /* the convolution's input on each level */
@@ -345,7 +352,10 @@ typedef struct {
     const int32_t* pos_anchor;               /* device int32 [>= num_pos]: b * An + a, ascending (odpl_retina_loss, ODPL_RETINA_ROWS_ONLY) */
     const int32_t* num_pos;                  /* device int32 [1] */
     const float* upstream;                   /* device scalar multiplied into every gradient; NULL = 1 */
+    int32_t rows_per_image;                  /* rows per image of the grad_rows tensors when that is more than An (0 = An) */
+    int32_t flags;                           /* ODPL_HEADS_* */
 } odpl_retina_heads_desc_t;
+#define ODPL_HEADS_SHARED_INPUT 1            /* n_heads == 2 with x / grad_x of head 1 == head 0's: grad_x receives the SUM of both heads' dX */
 size_t odpl_retina_heads_backward_workspace_bytes(const odpl_retina_heads_desc_t* desc, int32_t n_heads, const odpl_retina_head_t* heads);
 int odpl_retina_heads_backward(const odpl_retina_heads_desc_t* desc, int32_t n_heads, const odpl_retina_head_t* heads,
                                void* workspace, size_t workspace_bytes, void* stream);
@@ -438,7 +448,18 @@ typedef struct {
     int32_t B, P, C, nT;
     int32_t cls_mode;                     /* ODPL_CLS_CE (nn.CrossEntropyLoss) or ODPL_CLS_SOFTMAX_FOCAL (focal_loss) */
     int32_t coord_mode;                   /* ODPL_COORD_* with reduction='none' then .sum() */
+    int32_t flags;                        /* ODPL_SSD_ROWS_ONLY */
+    int32_t* active;                      /* ODPL_SSD_ROWS_ONLY: out, int32 [B, P]: image b's priors that carry a gradient, ascending, in [b*P, b*P + count) */
+    int32_t* active_count;                /* ODPL_SSD_ROWS_ONLY: out, int32 [B] */
 } odpl_ssd_loss_desc_t;
+/* grad_off / grad_cls are written on the rows of the positives and the selected hard negatives only (d loss/d preds is zero elsewhere:
+ * losses.py:241-268 -- and those zeros are neither written nor read); `active` lists them.  For the structured backward of the heads. */
+#define ODPL_SSD_ROWS_ONLY 1
+/* `active` cut by source: list l receives b * An_l + (p - first[l]) for the active priors first[l] <= p < first[l+1] (ascending: the
+ * pos_anchor of odpl_retina_heads_backward for source l), at lists + B * first[l]; counts[l] their number.  first: HOST int32 [nlevels + 1],
+ * first[nlevels] = P; nlevels <= 8. */
+int odpl_ssd_level_lists(const int32_t* active, const int32_t* active_count, int32_t B, int32_t P, int32_t nlevels, const int32_t* first,
+                         int32_t* lists, int32_t* counts, void* stream);
 
 #define ODPL_CLS_SOFTMAX_FOCAL 2
 

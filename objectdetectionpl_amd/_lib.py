@@ -63,7 +63,11 @@ class RetinaHead(ctypes.Structure):
 class RetinaHeadsDesc(ctypes.Structure):
     """odpl_retina_heads_desc_t"""
     _fields_ = [("B", c_int32), ("A", c_int32), ("Cin", c_int32), ("nlevels", c_int32), ("H", c_int32 * RETINA_LEVELS), ("W", c_int32 * RETINA_LEVELS),
-                ("pos_anchor", c_void_p), ("num_pos", c_void_p), ("upstream", c_void_p)]
+                ("pos_anchor", c_void_p), ("num_pos", c_void_p), ("upstream", c_void_p), ("rows_per_image", c_int32), ("flags", c_int32)]
+
+
+HEADS_SHARED_INPUT = 1       # ODPL_HEADS_SHARED_INPUT
+SSD_ROWS_ONLY = 1            # ODPL_SSD_ROWS_ONLY
 
 
 class SparseConv3x3(ctypes.Structure):
@@ -141,7 +145,8 @@ class YoloV5LossDesc(ctypes.Structure):
 class SsdLossDesc(ctypes.Structure):
     _fields_ = [("off", c_void_p), ("cls", c_void_p), ("grad_off", c_void_p), ("grad_cls", c_void_p),
                 ("priors", c_void_p), ("target", c_void_p),
-                ("B", c_int32), ("P", c_int32), ("C", c_int32), ("nT", c_int32), ("cls_mode", c_int32), ("coord_mode", c_int32)]
+                ("B", c_int32), ("P", c_int32), ("C", c_int32), ("nT", c_int32), ("cls_mode", c_int32), ("coord_mode", c_int32),
+                ("flags", c_int32), ("active", c_void_p), ("active_count", c_void_p)]
 
 
 _lib = None
@@ -187,6 +192,7 @@ SIGNATURES = {
     "odpl_yolov5_compact_view": (c_int32, [POINTER(YoloV5LossDesc), c_void_p, c_int32, POINTER(SparseGrad), POINTER(YoloV5Rows)]),
     "odpl_ssd_loss_workspace_bytes": (c_size_t, [POINTER(SsdLossDesc)]),
     "odpl_ssd_loss": (c_int32, [POINTER(SsdLossDesc), c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "odpl_ssd_level_lists": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, POINTER(c_int32), c_void_p, c_void_p, c_void_p]),
     "odpl_debug_set_stamp_buffer": (c_int32, [c_void_p]),
     "odpl_batch_statistics": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p]),
     "odpl_ap_per_class_workspace_bytes": (c_size_t, [c_int32, c_int32]),

@@ -45,6 +45,8 @@ struct GP {
     float* stage;                                                // [cap * 9][kMaxHeads][Cin]: one row's contribution through one tap
     int B, A, Cin, cv, nlevels, nheads, An, npix_img, npix, cap; // npix_img = sum HW; npix = B * npix_img; cap: rows that own staging slots
     int pair_head;                                               // the head a pair launch works on
+    int rows_an;                                                 // anchors per image in the heads' gradient tensors (An, or more: a level of a wider tensor)
+    int shared_x;                                                // both heads read ONE input: their dX is summed into head 0's tensor
 };
 
 // anchor index a (within an image) -> level, cell, k
@@ -56,6 +58,9 @@ __device__ __forceinline__ void decode_anchor(const GP& P, int a, int& l, int& c
 }
 // map slot of (level l, image b, cell): pixels are laid out level-major, image-major inside a level
 __device__ __forceinline__ int map_slot(const GP& P, int l, int b, int cell) { return P.B * P.lv[l].pix0 + b * P.lv[l].HW + cell; }
+
+// row of anchor ga = b * An + a in a head's gradient tensor [B, rows_an, no]
+__device__ __forceinline__ size_t grad_row(const GP& P, int ga) { const int b = ga / P.An; return (size_t)b * P.rows_an + (ga - b * P.An); }
 
 __global__ __launch_bounds__(kT) void rh_map_kernel(const GP P) {
     const int n = *P.num_pos;
@@ -173,7 +178,7 @@ __global__ __launch_bounds__(kT) void rh_pair_kernel(const GP P) {
                     }
                     for (int e = tid; e < nb * nc; e += kT) {
                         const int u = e / nc, c = e - u * nc;
-                        s_gb[u * kSlabRows + c] = Hd.rows[(size_t)s_ga[i0 + u] * Hd.no + c0 + c];
+                        s_gb[u * kSlabRows + c] = Hd.rows[grad_row(P, s_ga[i0 + u]) * Hd.no + c0 + c];
                     }
                     __syncthreads();
                     if (ok) {
@@ -288,13 +293,16 @@ __global__ __launch_bounds__(kT) void rh_dx_kernel(const GP P) {
                         else {
                             const int ga = __builtin_amdgcn_readfirstlane(P.pos[r]);
                             const int a = ga - (ga / P.An) * P.An;
-                            c4 = pair_contrib(P.h[h], P.h[h].rows + (size_t)ga * P.h[h].no, (a - L.first) % P.A, ky, kx, v);
+                            c4 = pair_contrib(P.h[h], P.h[h].rows + grad_row(P, ga) * P.h[h].no, (a - L.first) % P.A, ky, kx, v);
                         }
                         acc[h].x += c4.x; acc[h].y += c4.y; acc[h].z += c4.z; acc[h].w += c4.w;
                     }
                 }
             }
-            if (ok) {
+            if (ok && P.shared_x) {                                     // both heads hang on one input (SSD's cl / bbx pairs): one dX, head 0 + head 1
+                const v4f o = {(acc[0].x + acc[1].x) * f, (acc[0].y + acc[1].y) * f, (acc[0].z + acc[1].z) * f, (acc[0].w + acc[1].w) * f};
+                __builtin_nontemporal_store(o, reinterpret_cast<v4f*>(P.h[0].gx[l]) + row + v);
+            } else if (ok) {
 #pragma unroll
                 for (int h = 0; h < kMaxHeads; ++h) {
                     if (h >= P.nheads || !P.h[h].gx[0]) continue;
@@ -355,7 +363,7 @@ __global__ __launch_bounds__(kT) void rh_dw_kernel(const GP P) {
             }
             const int cnt = base;
             for (int i = tid; i < cnt; i += kT) {
-                const float* g = Hd.rows + (size_t)s_ga[i] * Hd.no + c0;
+                const float* g = Hd.rows + grad_row(P, s_ga[i]) * Hd.no + c0;
                 float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
                 gv.x = g[0]; if (ncc > 1) gv.y = g[1]; if (ncc > 2) gv.z = g[2]; if (ncc > 3) gv.w = g[3];
                 reinterpret_cast<float4*>(s_g)[i] = gv;
@@ -423,22 +431,31 @@ __global__ __launch_bounds__(kT) void rh_dw_kernel(const GP P) {
 }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+constexpr size_t kPairLdsMax = 150 * 1024;
+inline size_t pair_lds_bytes(int no, int cv) { const int slab = no < kSlabRows ? no : kSlabRows; return ((size_t)slab * cv * 4 + 16 * kSlabRows) * sizeof(float); }
 
 bool valid(const odpl_retina_heads_desc_t* d, int n, const odpl_retina_head_t* h, long long* npix_img, long long* An) {
     if (!d || !h || n < 1 || n > kMaxHeads) return false;
-    if (d->B < 1 || d->A < 1 || d->A > 64 || d->Cin < 4 || (d->Cin & 3) || d->Cin > 448 || d->nlevels < 1 || d->nlevels > ODPL_RETINA_LEVELS) return false;      // Cin: the pair launch's LDS slab
+    // A: the dx launch lists <= 96 (row, tap) contributions per pixel = 9 taps x A rows
+    if (d->B < 1 || d->A < 1 || d->A > 10 || d->Cin < 4 || (d->Cin & 3) || d->nlevels < 1 || d->nlevels > ODPL_RETINA_LEVELS) return false;
+    if (d->flags & ~ODPL_HEADS_SHARED_INPUT) return false;
+    if ((d->flags & ODPL_HEADS_SHARED_INPUT) && n != 2) return false;
     if (!d->pos_anchor || !d->num_pos) return false;
     long long pix = 0;
     for (int l = 0; l < d->nlevels; ++l) { if (d->H[l] < 1 || d->W[l] < 1) return false; pix += (long long)d->H[l] * d->W[l]; }
     if (pix * d->B > 0x7fffffffLL || pix * d->A * d->B > 0x7fffffffLL || pix * d->B * d->Cin > 0x7fffffffLL * 4) return false;
     for (int i = 0; i < n; ++i) {
         if (h[i].no < 1 || h[i].no > 4096 || !h[i].w || !h[i].grad_rows) return false;
+        if (pair_lds_bytes(h[i].no, d->Cin / 4) > kPairLdsMax) return false;          // the pair launch's weight slab in LDS: Cin <= 448 at no >= 80
         bool any_gx = false, all_gx = true;
         for (int l = 0; l < d->nlevels; ++l) { if (!h[i].x[l]) return false; any_gx |= h[i].grad_x[l] != nullptr; all_gx &= h[i].grad_x[l] != nullptr; }
         if (any_gx != all_gx) return false;
         if (h[i].w_stride[1] != 1 && h[i].w_stride[1] < 1) return false;
     }
     *npix_img = pix; *An = pix * d->A;
+    if (d->rows_per_image != 0 && d->rows_per_image < *An) return false;
+    if (d->flags & ODPL_HEADS_SHARED_INPUT)
+        for (int l = 0; l < d->nlevels; ++l) if (h[0].x[l] != h[1].x[l] || h[0].grad_x[l] != h[1].grad_x[l]) return false;
     return true;
 }
 }  // namespace
@@ -460,6 +477,7 @@ extern "C" int odpl_retina_heads_backward(const odpl_retina_heads_desc_t* d, int
     P.B = d->B; P.A = d->A; P.Cin = d->Cin; P.cv = d->Cin / 4; P.nlevels = d->nlevels; P.nheads = n;
     P.An = (int)An; P.npix_img = (int)pix; P.npix = (int)(pix * d->B);
     P.pos = d->pos_anchor; P.num_pos = d->num_pos; P.upstream = d->upstream;
+    P.rows_an = d->rows_per_image ? d->rows_per_image : (int)An; P.shared_x = (d->flags & ODPL_HEADS_SHARED_INPUT) ? 1 : 0;
     int first = 0, pix0 = 0;
     for (int l = 0; l < d->nlevels; ++l) {
         P.lv[l].H = d->H[l]; P.lv[l].W = d->W[l]; P.lv[l].HW = d->H[l] * d->W[l]; P.lv[l].first = first; P.lv[l].pix0 = pix0;
@@ -497,9 +515,8 @@ extern "C" int odpl_retina_heads_backward(const odpl_retina_heads_desc_t* d, int
         if (lds_allowed == 0) lds_allowed = 64 * 1024;
         for (int i = 0; i < n; ++i) {
             if (!P.h[i].gx[0]) continue;
-            const int slab = P.h[i].no < kSlabRows ? P.h[i].no : kSlabRows;
-            const size_t lds_pair = ((size_t)slab * P.cv * 4 + 16 * kSlabRows) * sizeof(float);
-            if (lds_pair > 150 * 1024) return ODPL_EINVAL;          // Cin <= 448 with 80-row slabs (valid() checks it)
+            const size_t lds_pair = pair_lds_bytes(P.h[i].no, P.cv);
+            if (lds_pair > kPairLdsMax) return ODPL_EINVAL;          // valid() checks it
             if (lds_pair > lds_allowed) {
                 ODPL_HIP_TRY(hipFuncSetAttribute((const void*)rh_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pair));
                 lds_allowed = lds_pair;

@@ -30,6 +30,7 @@ struct SParams {
     float* part;                              // [B*2]
     int* meta;                                // [0] new_batch_size, [1] status
     float* out3; int* out_counts;
+    int rows_only; int* active; int* active_count;      // ODPL_SSD_ROWS_ONLY: gradients on the active rows only + their list per image
 };
 
 __device__ __forceinline__ Box4 clamp_points(float cx, float cy, float w, float h) {
@@ -99,11 +100,11 @@ __global__ __launch_bounds__(kT) void ssd_image_kernel(const SParams P) {
     if (j == 0 && tid == 0) P.meta[0] = new_bs;
     const bool want = P.g_cls != nullptr;
     if (j >= D) {                                           // "continue": the image contributes nothing
-        if (want) {
+        if (want && !P.rows_only) {
             for (size_t e = tid; e < (size_t)np * C; e += kT) P.g_cls[p0 * C + e] = 0.f;
             for (size_t e = tid; e < (size_t)np * 4; e += kT) P.g_off[p0 * 4 + e] = 0.f;
         }
-        if (tid == 0) { P.part[j * 2] = 0.f; P.part[j * 2 + 1] = 0.f; }
+        if (tid == 0) { P.part[j * 2] = 0.f; P.part[j * 2 + 1] = 0.f; if (want && P.rows_only) P.active_count[j] = 0; }
         return;
     }
     // ---- per prior: best annotation (max over dim 0, first index), losses.py:213
@@ -220,8 +221,24 @@ __global__ __launch_bounds__(kT) void ssd_image_kernel(const SParams P) {
     // ---- sums (fixed thread-strided order) and gradients
     const float w = 1.0f / ((float)N * (float)new_bs);
     float a_cls = 0.f, a_reg = 0.f;
-    for (int p = tid; p < np; p += kT) {
+    const bool rows_only = want && P.rows_only;
+    int n_act = 0;                                          // active priors listed so far (uniform)
+    for (int pb = 0; pb < np; pb += kT) {
+        const int p = pb + tid;
+        if (rows_only) {                                    // the image's active priors in index order (ballot prefix over the block)
+            const bool act = p < np && (flag[p] & 3);
+            const unsigned long long mk = __ballot(act);
+            __syncthreads();
+            if (lane == 0) s_i[wv] = __popcll(mk);
+            __syncthreads();
+            int offc = n_act, tot = 0;
+            for (int w2 = 0; w2 < kT / 64; ++w2) { if (w2 < wv) offc += s_i[w2]; tot += s_i[w2]; }
+            if (act) P.active[p0 + offc + __popcll(mk & ((1ull << lane) - 1ull))] = p;
+            n_act += tot;
+        }
+        if (p >= np) continue;
         const int f = flag[p];
+        if (rows_only && !(f & 3)) continue;                // nothing to add to the sums, no gradient row to write
         const float* x = P.cls + (p0 + p) * C;
         float* gx = want ? P.g_cls + (p0 + p) * C : nullptr;
         float* go = want ? P.g_off + (p0 + p) * 4 : nullptr;
@@ -270,6 +287,7 @@ __global__ __launch_bounds__(kT) void ssd_image_kernel(const SParams P) {
     }
     a_cls = block_sum_f(a_cls, s_f);
     a_reg = block_sum_f(a_reg, s_f);
+    if (rows_only && tid == 0) P.active_count[j] = n_act;
     if (tid == 0) {
         P.part[j * 2] = a_cls / (float)N;                   // losses.py:272
         P.part[j * 2 + 1] = a_reg / (float)N;               // losses.py:273
@@ -288,12 +306,43 @@ __global__ void ssd_finalize_kernel(const SParams P) {
     P.meta[1] = 0;
 }
 
+// `active` cut by source level: one workgroup per level walks the images' lists in order (ballot prefix), keeps the priors of its
+// range and rebases them to the level's own anchor numbering
+struct LevelP { const int* active; const int* active_count; int* lists; int* counts; int B, P, nlevels; int first[9]; };
+__global__ __launch_bounds__(256) void ssd_level_lists_kernel(const LevelP L) {
+    __shared__ int s_w[4];
+    const int l = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int lo = L.first[l], hi = L.first[l + 1], an = hi - lo;
+    int* out = L.lists + (size_t)L.B * lo;
+    int n = 0;
+    for (int b = 0; b < L.B; ++b) {
+        const int cnt = L.active_count[b];
+        const int* seg = L.active + (size_t)b * L.P;
+        for (int i0 = 0; i0 < cnt; i0 += 256) {
+            const int i = i0 + tid;
+            const int p = i < cnt ? seg[i] : -1;
+            const bool keep = p >= lo && p < hi;
+            const unsigned long long mk = __ballot(keep);
+            __syncthreads();
+            if (lane == 0) s_w[wv] = __popcll(mk);
+            __syncthreads();
+            int off = n, tot = 0;
+            for (int w = 0; w < 4; ++w) { if (w < wv) off += s_w[w]; tot += s_w[w]; }
+            if (keep) out[off + __popcll(mk & ((1ull << lane) - 1ull))] = b * an + (p - lo);
+            n += tot;
+        }
+    }
+    if (tid == 0) L.counts[l] = n;
+}
+
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 struct SPlan { size_t meta, loss, ann, flag, best, part, total; };
 bool make_splan(const odpl_ssd_loss_desc_t* d, SPlan* p) {
     if (!d || d->B < 1 || d->P < 1 || d->C < 1 || d->nT < 1 || d->nT > kMaxT) return false;
     if (!d->off || !d->cls || !d->priors || !d->target) return false;
     if ((d->grad_off == nullptr) != (d->grad_cls == nullptr)) return false;
+    if (d->flags & ~ODPL_SSD_ROWS_ONLY) return false;
+    if ((d->flags & ODPL_SSD_ROWS_ONLY) && (!d->grad_off || !d->active || !d->active_count)) return false;
     const size_t BP = (size_t)d->B * d->P;
     size_t off = 0;
     p->meta = off; off += 256;
@@ -326,10 +375,27 @@ extern "C" int odpl_ssd_loss(const odpl_ssd_loss_desc_t* d, void* workspace, siz
     P.loss = (float*)(ws + pl.loss); P.ann = (int*)(ws + pl.ann); P.flag = (int*)(ws + pl.flag);
     P.best_prior = (int*)(ws + pl.best); P.part = (float*)(ws + pl.part); P.meta = (int*)(ws + pl.meta);
     P.out3 = out3; P.out_counts = out_counts;
+    P.rows_only = (d->flags & ODPL_SSD_ROWS_ONLY) ? 1 : 0; P.active = d->active; P.active_count = d->active_count;
     ODPL_HIP_TRY(odpl::fill_bytes(P.meta, 0, 256, stream));
     hipLaunchKernelGGL(ssd_image_kernel, dim3(d->B), dim3(kT), 0, stream, P);
     ODPL_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(ssd_finalize_kernel, dim3(1), dim3(64), 0, stream, P);
+    ODPL_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int odpl_ssd_level_lists(const int32_t* active, const int32_t* active_count, int32_t B, int32_t P, int32_t nlevels, const int32_t* first,
+                                    int32_t* lists, int32_t* counts, void* stream) {
+    if (!active || !active_count || !first || !lists || !counts || B < 1 || P < 1 || nlevels < 1 || nlevels > 8) return ODPL_EINVAL;
+    if ((long long)B * P > 0x7fffffffLL) return ODPL_EINVAL;
+    LevelP L;
+    L.active = active; L.active_count = active_count; L.lists = lists; L.counts = counts; L.B = B; L.P = P; L.nlevels = nlevels;
+    for (int l = 0; l <= nlevels; ++l) {
+        L.first[l] = first[l];
+        if (first[l] < 0 || first[l] > P || (l > 0 && first[l] <= first[l - 1])) return ODPL_EINVAL;
+    }
+    if (first[0] != 0 || first[nlevels] != P) return ODPL_EINVAL;
+    hipLaunchKernelGGL(ssd_level_lists_kernel, dim3(nlevels), dim3(256), 0, (hipStream_t)stream, L);
     ODPL_HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -19,6 +19,7 @@ from ..LightningFunc import optimizer as _opt
 from ..LightningFunc import step as _step
 from ..LightningFunc.losses import configure_loss
 from ..LightningFunc.nms import greedy_non_max_suppression
+from ..LightningFunc.utils import ssdhead as _ssdhead
 from ..LightningFunc.utils.SSDUtils import get_dboxes
 
 try:
@@ -116,6 +117,15 @@ class SSD(_Base):
         B = x.size(0)
         out_cl, out_bbx = [], []
         src = self.f1(x)
+        cls_convs, box_convs = [getattr(self, f"cl{i}")[0] for i in range(1, 7)], [getattr(self, f"bbx{i}")[0] for i in range(1, 7)]
+        if (_ssdhead.enabled and x.is_cuda and torch.is_grad_enabled() and all(len(getattr(self, f"{p}{i}")) == 1 for i in range(1, 7) for p in ("cl", "bbx"))
+                and all(_ssdhead.is_hostable(c) for c in cls_convs + box_convs)):
+            # the twelve head convolutions hosted in one autograd node: SSDLoss may then run their backward from the rows that carry a gradient
+            sources = [src]
+            for i in range(2, 7):
+                src = self.f2(self.base1(src)) if i == 2 else getattr(self, f"f{i}")(src)
+                sources.append(src)
+            return _ssdhead.head_pairs(cls_convs, box_convs, sources, self.num_classes)
         for i in range(1, 7):
             if i == 2:
                 src = self.f2(self.base1(src))

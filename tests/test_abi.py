@@ -38,7 +38,7 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(_lib.RetinaLossDesc) == 96 and _lib.RetinaLossDesc.pos_anchor.offset == 80
     # odpl_retina_head_t: 5 + 5 + 4 pointers, 4 int64 strides, int32 (+pad); odpl_retina_heads_desc_t: 14 int32 + 3 pointers
     assert ctypes.sizeof(_lib.RetinaHead) == 152 and _lib.RetinaHead.w_stride.offset == 112
-    assert ctypes.sizeof(_lib.RetinaHeadsDesc) == 80 and _lib.RetinaHeadsDesc.pos_anchor.offset == 56
+    assert ctypes.sizeof(_lib.RetinaHeadsDesc) == 88 and _lib.RetinaHeadsDesc.pos_anchor.offset == 56 and _lib.RetinaHeadsDesc.flags.offset == 84
 
 
 def test_ctypes_layouts_against_the_compiled_header(tmp_path):
@@ -46,7 +46,7 @@ def test_ctypes_layouts_against_the_compiled_header(tmp_path):
     import subprocess
     from objectdetectionpl_amd import _lib
     cases = [("odpl_retina_loss_desc_t", _lib.RetinaLossDesc, "num_pos"), ("odpl_retina_head_t", _lib.RetinaHead, "no"),
-             ("odpl_retina_heads_desc_t", _lib.RetinaHeadsDesc, "upstream"), ("odpl_sparse_conv3x3_t", _lib.SparseConv3x3, "stats"),
+             ("odpl_retina_heads_desc_t", _lib.RetinaHeadsDesc, "flags"), ("odpl_ssd_loss_desc_t", _lib.SsdLossDesc, "active_count"), ("odpl_sparse_conv3x3_t", _lib.SparseConv3x3, "stats"),
              ("odpl_pixel_support_t", _lib.PixelSupport, "counts"), ("odpl_sparse_conv3x3_fwd_t", _lib.SparseConv3x3Fwd, "ksize"),
              ("odpl_yolo_scale_t", _lib.YoloScale, "stride"), ("odpl_sparse_grad_t", _lib.SparseGrad, "layout"),
              ("odpl_adam_desc_t", _lib.AdamDesc, "weight_decay"), ("odpl_yolo_nms_desc_t", _lib.YoloNmsDesc, "flags")]

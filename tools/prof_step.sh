@@ -3,7 +3,7 @@
 # (whole run: warm-up included; MIOpen immediate mode on the committed find-db, so there is no solver search in it)
 ROOT=$GRAFT_REPO_ROOT
 W=${1:-retina}
-if [ "$W" = retina ]; then PROG="$ROOT/tools/bench_retina_step.py --steps 10 --warmup 3"; else PROG="$ROOT/tools/bench_v5.py --steps 10 --warmup 3"; fi
+if [ "$W" = retina ]; then PROG="$ROOT/tools/bench_retina_step.py --steps 10 --warmup 3"; elif [ "$W" = ssd ]; then PROG="$ROOT/tools/bench_ssd_step.py --steps 10 --warmup 3"; else PROG="$ROOT/tools/bench_v5.py --steps 10 --warmup 3"; fi
 rm -rf /tmp/prof_step
 ( cd /tmp && TMPDIR=/tmp timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_step -- python3 $PROG > $ROOT/gpurun_out/prof_step_$W.log 2>&1 )
 f=$(find /tmp/prof_step -name "*kernel_stats.csv" 2>/dev/null | sort | sed -n 1p)
