@@ -150,11 +150,13 @@ def _dense_from_sparse(gd, gr, cells, B, G2, A, no, dc, layout):
 
 @pytest.mark.parametrize("layout", [0, 1])
 @pytest.mark.parametrize("A,no,Cin,G,nrows", [(3, 9, 64, 13, 7), (5, 25, 1024, 9, 12), (3, 85, 2048, 4, 0), (1, 6, 40, 5, 3),
-                                              (3, 85, 320, 7, 5), (2, 10, 96, 19, 4), (4, 7, 8, 23, 6)])
+                                              (3, 85, 320, 7, 5), (2, 10, 96, 19, 4), (4, 7, 8, 23, 6),
+                                              (3, 300, 64, 5, 40), (2, 2100, 32, 4, 9)])
 def test_c_abi_head_conv_backward_vs_dense_math(layout, A, no, Cin, G, nrows):
     """odpl_head_conv_backward on a synthetic odpl_sparse_grad_t (both cell orders, A = 1..5, Cin beyond one column pass,
     a half-empty second column slice (Cin = 320), many row lanes with ragged last tiles (Cin = 96, 8), no rows at all, rows
-    that share a cell-row) against float64 dense math."""
+    that share a cell-row; A * no = 900 and 4 200: the finish launch's gradient matrix in two / nine LDS slabs, six rows / one row
+    staged at a time) against float64 dense math."""
     from objectdetectionpl_amd import _lib
     g = torch.Generator().manual_seed(A * 100 + no)
     B, G2, dc = 2, G * G, 4
