@@ -1107,6 +1107,14 @@ __global__ __launch_bounds__(kScT) void greedy_nms_scatter_kernel(const GParams 
 }
 
 constexpr int kSelBins = 2048;                       // radix select: bins per level (two per thread)
+constexpr int kListCap = 1024;                       // the short top-k: keys at or above the bound that fit the LDS list
+
+#ifdef ODPL_NMS_TRACE
+__device__ unsigned long long* g_nms_trace = nullptr;                      // [B][16] wall-clock stamps (100 MHz) of greedy_nms_image_kernel
+#define NTRACE(slot) do { if (g_nms_trace && threadIdx.x == 0) g_nms_trace[(size_t)blockIdx.x * 16 + (slot)] = wall_clock64(); } while (0)
+#else
+#define NTRACE(slot) do { } while (0)
+#endif
 
 __global__ __launch_bounds__(kImgT) void greedy_nms_image_kernel(const GParams P) {
     __shared__ int s_wcnt[kImgT / 64], s_wcnt2[kImgT / 64];
@@ -1116,9 +1124,13 @@ __global__ __launch_bounds__(kImgT) void greedy_nms_image_kernel(const GParams P
     __shared__ float4 s_box[kMaxTopk]; __shared__ float s_area[kMaxTopk]; __shared__ int s_alive[kMaxTopk];
     __shared__ int s_keep[kMaxTopk];
     __shared__ int s_p;
+    __shared__ int s_rank[128];
+    __shared__ unsigned s_lkey[kListCap]; __shared__ int s_lidx[kListCap], s_la[kListCap], s_rank2[kListCap];
+    __shared__ unsigned long long s_rows[128][2];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const size_t o0 = (size_t)b * P.An;
     float* ckey = P.ckey + o0; int* cidx = P.cidx + o0;
+    NTRACE(0);
     const int n = P.ncand[b];
     float* out = P.out + (size_t)b * P.topk * 7;
     if (n <= 1) {            // 0: nothing; 1: the reference raises IndexError (0-dim squeeze) -- reported via counts
@@ -1136,6 +1148,100 @@ __global__ __launch_bounds__(kImgT) void greedy_nms_image_kernel(const GParams P
 #pragma unroll
         for (int j = 0; j < kKeyRegs; ++j) { const int i = tid + j * kImgT; kreg[j] = i < n ? __float_as_uint(ckey[i]) : 0u; }
     }
+    NTRACE(1);
+    // ---- the short way to the top m <= 128 of keys held in registers.  The m-th largest of the THREADS' maxima is a lower bound L of
+    //      the m-th largest key (m threads hold a key >= it), and only a few hundred of tens of thousands of keys reach it: one small
+    //      histogram (one value per thread) finds L, the keys >= L go to an LDS list, and the list is ordered by COUNTING -- entry e
+    //      counts the entries that come before it in (score desc, position asc), a strict total order, so the counts are the final
+    //      places and places < m are the survivors: selection, tie rule (index order) and sort in one pass, with the entries' decode
+    //      loads (candidate -> anchor -> offsets + anchor box) in flight under it.  A list that does not fit takes the general way.
+    bool fast = false;
+    if (in_regs && n > P.topk && m <= 128) {
+        unsigned mx = 0u;
+#pragma unroll
+        for (int j = 0; j < kKeyRegs; ++j) if (tid + j * kImgT < n) mx = kreg[j] > mx ? kreg[j] : mx;
+        const unsigned lo_bits = P.class_thresh > 0.f ? __float_as_uint(P.class_thresh) : 0u;
+        const unsigned hi_bits = lo_bits < 0x3f800000u ? 0x3f800000u : lo_bits;
+        int span_log = 1; while (span_log < 31 && (1u << span_log) <= hi_bits - lo_bits) ++span_log;
+        const int shift = span_log > 11 ? span_log - 11 : 0;
+        s_hist[tid] = 0; s_hist[tid + kImgT] = 0;
+        if (tid == 0) { s_sel[0] = -1; s_sel[1] = 0; }
+        __syncthreads();
+        const bool has_key = tid < n;
+        const unsigned dmx = mx - lo_bits;
+        const bool in_range = has_key && mx >= lo_bits && (dmx >> span_log) == 0u;
+        if (in_range) atomicAdd(&s_hist[dmx >> shift], 1);       // a maximum beyond 1.0 (never, for sigmoids) is not counted: the bound only gets lower
+        __syncthreads();
+        const int h0 = s_hist[2 * tid], h1 = s_hist[2 * tid + 1];
+        int inc = h0 + h1;
+        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_down(inc, o, 64); if (lane + o < 64) inc += u; }
+        if (lane == 0) s_wcnt[wv] = inc;
+        __syncthreads();
+        int above = 0;
+        for (int w = wv + 1; w < kImgT / 64; ++w) above += s_wcnt[w];
+        const int S0 = above + inc, S1 = S0 - h0, S2 = S1 - h1;
+        if (S1 >= m && S2 < m) s_sel[0] = 2 * tid + 1;
+        else if (S0 >= m && S1 < m) s_sel[0] = 2 * tid;
+        __syncthreads();
+        const int bin = s_sel[0];
+        __syncthreads();
+        if (bin >= 0) {                                                   // (uniform) -1: the maxima did not fill the range as expected -> general way
+            const unsigned L = lo_bits + ((unsigned)bin << shift);
+            if (tid == 0) s_sel[0] = 0;
+            __syncthreads();
+            NTRACE(2);
+            int hits = 0;                                                 // one cursor step per thread (most have none), then its hits in a row
+#pragma unroll
+            for (int j = 0; j < kKeyRegs; ++j) hits += (tid + j * kImgT < n && kreg[j] >= L);
+            int at = hits ? atomicAdd(&s_sel[0], hits) : 0;
+            if (hits) {
+#pragma unroll
+                for (int j = 0; j < kKeyRegs; ++j) {
+                    const int i = tid + j * kImgT;
+                    if (i < n && kreg[j] >= L) { if (at < kListCap) { s_lkey[at] = kreg[j]; s_lidx[at] = i; s_la[at] = cidx[i]; } ++at; }
+                }
+            }
+            __syncthreads();
+            const int c = s_sel[0];
+            __syncthreads();
+            NTRACE(3);
+            if (c >= m && c <= kListCap) {                                // (uniform)
+                fast = true;
+                unsigned ke = 0u; int ie = 0;
+                float4 lo4 = make_float4(0.f, 0.f, 0.f, 0.f), an4 = lo4;
+                if (tid < c) {                                            // entry tid: its key and its box loads (the anchor index is in LDS already)
+                    ke = s_lkey[tid]; ie = s_lidx[tid];
+                    const int a = s_la[tid];
+                    lo4 = *reinterpret_cast<const float4*>(P.loc + (o0 + a) * 4);
+                    an4 = *reinterpret_cast<const float4*>(P.anchors + (size_t)a * 4);
+                }
+                // counting, all threads: thread (e, g) counts the entries of slice g that come before entry e
+                int cpad = 128; while (cpad < c) cpad <<= 1;
+                const int G = kImgT / cpad, e = tid & (cpad - 1), g = tid / cpad, per = (c + G - 1) / G;
+                s_rank2[tid] = 0;
+                __syncthreads();
+                if (e < c) {
+                    const unsigned k2 = s_lkey[e]; const int i2 = s_lidx[e];
+                    const int q0 = g * per, q1 = q0 + per < c ? q0 + per : c;
+                    int cnt = 0;
+                    for (int o = q0; o < q1; ++o) { const unsigned ko = s_lkey[o]; cnt += (ko > k2) || (ko == k2 && s_lidx[o] < i2); }
+                    if (cnt) atomicAdd(&s_rank2[e], cnt);
+                }
+                __syncthreads();
+                const int rank = tid < c ? s_rank2[tid] : 0;
+                if (tid < c && rank < m) {
+                    const float lo_[4] = {lo4.x, lo4.y, lo4.z, lo4.w}, an_[4] = {an4.x, an4.y, an4.z, an4.w};
+                    const Box4 bx = decode_anchor(lo_, an_);
+                    s_key[rank] = __uint_as_float(ke); s_pos[rank] = ie;
+                    s_box[rank] = make_float4(bx.x1, bx.y1, bx.x2, bx.y2);
+                    s_area[rank] = (bx.x2 - bx.x1 + 1.0f) * (bx.y2 - bx.y1 + 1.0f);
+                }
+                __syncthreads();
+                NTRACE(4);
+            }
+        }
+    }
+    if (!fast) {
     if (n > P.topk) {
         // current range [base, base + 2^span_log), cut into bins of 2^shift; keys above it: c_above.  The first range is where the keys
         // can be -- above class_thresh, at most sigmoid's 1.0 -- so that the first histogram spreads over ~1 000 bins (the whole
@@ -1233,36 +1339,69 @@ __global__ __launch_bounds__(kImgT) void greedy_nms_image_kernel(const GParams P
     // ---- sort the m survivors by (score desc, filtered position asc) in LDS, then the candidate boxes (decode of the candidate's
     //      anchor) and areas (RetinaNet.py:133-139).  Up to 128 survivors (topk = 100) ONE wave does both without a workgroup barrier
     //      (LDS traffic of a single wave is ordered); longer lists take the whole workgroup.
+    }                                                                     // !fast
+    NTRACE(5);
     int mp = 1; while (mp < m) mp <<= 1;
     if (mp < 64) mp = 64;
     const bool one_wave = m <= 128;
-    if (one_wave) {
-        if (wv == 0) {
-            for (int i = m + lane; i < mp; i += 64) { s_key[i] = -INFINITY; s_pos[i] = 0x7fffffff; }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            for (int k = 2; k <= mp; k <<= 1)
-                for (int lj = __ffs(k) - 2; lj >= 0; --lj) {
-                    const int j = 1 << lj;
-                    for (int t = lane; t < mp / 2; t += 64) {
-                        const int i = ((t >> lj) << (lj + 1)) + (t & (j - 1)), l = i + j;
-                        const bool up = ((i & k) == 0);
-                        const float ki = s_key[i], kl = s_key[l]; const int pi = s_pos[i], pl = s_pos[l];
-                        const bool sw = up ? before(kl, (unsigned)pl, ki, (unsigned)pi) : before(ki, (unsigned)pi, kl, (unsigned)pl);
-                        if (sw) { s_key[i] = kl; s_key[l] = ki; s_pos[i] = pl; s_pos[l] = pi; }
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                }
-            for (int e = lane; e < m; e += 64) {
-                const int a = cidx[s_pos[e]];
-                const Box4 bx = decode_anchor(P.loc + (o0 + a) * 4, P.anchors + (size_t)a * 4);
-                s_box[e] = make_float4(bx.x1, bx.y1, bx.x2, bx.y2);
-                s_area[e] = (bx.x2 - bx.x1 + 1.0f) * (bx.y2 - bx.y1 + 1.0f);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+    if (one_wave && !fast) {
+        // Up to 128 survivors: every thread takes part.  Thread e < m owns survivor e: its decode loads (candidate -> anchor -> offsets and
+        // anchor box: two dependent trips) go out first; meanwhile the order is found by COUNTING -- thread (e, g) counts the survivors of
+        // block g that come before e ((score desc, position asc) is a strict total order: the counts are a permutation) -- and when the
+        // rank is known the survivor lands at its place with its box.  One pass instead of a 28-step bitonic network + a decode behind it.
+        const int e = tid & 127, g = tid >> 7;                           // 8 blocks of 16 survivors
+        if (tid < 128) s_rank[tid] = 0;
+        float my_key = 0.f; int my_pos = 0, my_a = 0;
+        float4 lo4 = make_float4(0.f, 0.f, 0.f, 0.f), an4 = lo4;
+        if (tid < m) {
+            my_key = s_key[tid]; my_pos = s_pos[tid];
+            my_a = cidx[my_pos];
+            lo4 = *reinterpret_cast<const float4*>(P.loc + (o0 + my_a) * 4);
+            an4 = *reinterpret_cast<const float4*>(P.anchors + (size_t)my_a * 4);
         }
+        __syncthreads();
+        if (e < m) {
+            const float ke = s_key[e]; const unsigned pe = (unsigned)s_pos[e];
+            int cnt = 0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int o = g * 16 + u;
+                if (o < m) cnt += before(s_key[o], (unsigned)s_pos[o], ke, pe);
+            }
+            if (cnt) atomicAdd(&s_rank[e], cnt);
+        }
+        __syncthreads();
+        if (tid < m) {
+            const int r = s_rank[tid];
+            const float lo_[4] = {lo4.x, lo4.y, lo4.z, lo4.w}, an_[4] = {an4.x, an4.y, an4.z, an4.w};
+            const Box4 bx = decode_anchor(lo_, an_);
+            s_key[r] = my_key; s_pos[r] = my_pos;
+            s_box[r] = make_float4(bx.x1, bx.y1, bx.x2, bx.y2);
+            s_area[r] = (bx.x2 - bx.x1 + 1.0f) * (bx.y2 - bx.y1 + 1.0f);
+        }
+        __syncthreads();
+    }
+    if (one_wave) {
+        NTRACE(6);
+        // overlap matrix: row i, bits j = ovr(i, j) > thr, as ballots -- wave w takes rows w, w + 16, ...; lane = candidate j (and j + 64).
+        // Symmetric in (i, j): max / min and one commutative sum per term, so a row read as a column is the same bits.
+        {
+            const float4 bj0 = lane < m ? s_box[lane] : make_float4(0.f, 0.f, 0.f, 0.f), bj1 = lane + 64 < m ? s_box[lane + 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float aj0 = lane < m ? s_area[lane] : 0.f, aj1 = lane + 64 < m ? s_area[lane + 64] : 0.f;
+            for (int i = wv; i < m; i += kImgT / 64) {
+                const float4 q = s_box[i]; const float ai = s_area[i];
+                auto over = [&](const float4& tb, float ta) {
+                    const float w = fmaxf(fminf(q.z, tb.z) - fmaxf(q.x, tb.x) + 1.0f, 0.0f);     // clamp(min=x1[i]) etc.
+                    const float h = fmaxf(fminf(q.w, tb.w) - fmaxf(q.y, tb.y) + 1.0f, 0.0f);
+                    const float inter = w * h;
+                    return inter / (ta + ai - inter) > P.nms_thresh;
+                };
+                const unsigned long long lo = __ballot(lane < m && over(bj0, aj0));
+                const unsigned long long hi = m > 64 ? __ballot(lane + 64 < m && over(bj1, aj1)) : 0ull;
+                if (lane == 0) { s_rows[i][0] = lo; s_rows[i][1] = hi; }
+            }
+        }
+        __syncthreads();
     } else {
         for (int i = m + tid; i < mp; i += kImgT) { s_key[i] = -INFINITY; s_pos[i] = 0x7fffffff; }
         __syncthreads();
@@ -1292,38 +1431,37 @@ __global__ __launch_bounds__(kImgT) void greedy_nms_image_kernel(const GParams P
     if (wv == 0) {
         int K = 0;
         if (m <= 128) {
-            // overlap matrix: lane owns candidates lane and lane + 64; bit j of a row = ovr(candidate, j) > thr (symmetric: max / min
-            // and one commutative sum per term).  Then: pivot = first alive bit; keep it; alive &= ~(its row | itself).
-            unsigned long long r0lo = 0ull, r0hi = 0ull, r1lo = 0ull, r1hi = 0ull;      // rows of candidates lane / lane + 64: bits 0-63 / 64-127
-            const int e0 = lane, e1 = lane + 64;
-            const float4 b0 = e0 < m ? s_box[e0] : make_float4(0.f, 0.f, 0.f, 0.f), b1 = e1 < m ? s_box[e1] : make_float4(0.f, 0.f, 0.f, 0.f);
-            const float a0 = e0 < m ? s_area[e0] : 0.f, a1 = e1 < m ? s_area[e1] : 0.f;
-            for (int j = 0; j < m; ++j) {                    // (uniform) candidate j against this lane's two
-                const float4 q = s_box[j]; const float aj = s_area[j];
-                auto over = [&](const float4& tb, float ta) {
-                    const float w = fmaxf(fminf(q.z, tb.z) - fmaxf(q.x, tb.x) + 1.0f, 0.0f);     // clamp(min=x1[i]) etc.
-                    const float h = fmaxf(fminf(q.w, tb.w) - fmaxf(q.y, tb.y) + 1.0f, 0.0f);
-                    const float inter = w * h;
-                    return inter / (ta + aj - inter) > P.nms_thresh;
-                };
-                const bool o0b = over(b0, a0), o1b = over(b1, a1);
-                if (j < 64) { if (o0b) r0lo |= 1ull << j; if (o1b) r1lo |= 1ull << j; }
-                else { if (o0b) r0hi |= 1ull << (j - 64); if (o1b) r1hi |= 1ull << (j - 64); }
-            }
+            // lane holds the rows of candidates lane and lane + 64 (bits 0-63 / 64-127); pivot = first alive bit; keep it;
+            // alive &= ~(its row | itself).  The loop touches registers only (scalar masks, readlane for the pivot's row); the kept list
+            // is written afterwards from the kept mask, in pivot order.
+            const unsigned long long r0lo = s_rows[lane][0], r0hi = s_rows[lane][1], r1hi = s_rows[lane + 64][1];
+            NTRACE(7);
             unsigned long long alo = m >= 64 ? ~0ull : ((1ull << m) - 1ull), ahi = m > 64 ? (m >= 128 ? ~0ull : ((1ull << (m - 64)) - 1ull)) : 0ull;
+            unsigned long long keep_lo = 0ull, keep_hi = 0ull;
             auto rl64 = [&](unsigned long long v, int src) {
                 return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), src) << 32) |
                        (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, src);
             };
-            while (__popcll(alo) + __popcll(ahi) > 1) {
-                const int p = alo ? __ffsll((long long)alo) - 1 : 64 + __ffsll((long long)ahi) - 1;
-                unsigned long long klo, khi;                 // the pivot's row
-                if (p < 64) { klo = rl64(r0lo, p); khi = rl64(r0hi, p); } else { klo = rl64(r1lo, p - 64); khi = rl64(r1hi, p - 64); }
-                if (lane == 0) s_keep[K] = s_pos[p];
-                ++K;
-                if (p < 64) alo &= ~(1ull << p); else ahi &= ~(1ull << (p - 64));
-                alo &= ~klo; ahi &= ~khi;
+            // pivots of the low word first, then of the high word: two straight scalar loops (no pivot-side branch inside)
+            while (alo != 0ull && __popcll(alo) + __popcll(ahi) > 1) {
+                const int p = __ffsll((long long)alo) - 1;
+                const unsigned long long bit = 1ull << p;
+                const unsigned long long klo = rl64(r0lo, p), khi = rl64(r0hi, p);       // the pivot's row
+                keep_lo |= bit;
+                alo &= ~(klo | bit); ahi &= ~khi;
             }
+            while (alo == 0ull && __popcll(ahi) > 1) {
+                const int p = __ffsll((long long)ahi) - 1;
+                const unsigned long long bit = 1ull << p;
+                const unsigned long long khi = rl64(r1hi, p);                             // its low half only reaches candidates already gone
+                keep_hi |= bit;
+                ahi &= ~(khi | bit);
+            }
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            const int nlo = __popcll(keep_lo);
+            if ((keep_lo >> lane) & 1ull) s_keep[__popcll(keep_lo & lt)] = s_pos[lane];
+            if ((keep_hi >> lane) & 1ull) s_keep[nlo + __popcll(keep_hi & lt)] = s_pos[lane + 64];
+            K = nlo + __popcll(keep_hi);
         } else {
             int p = 0, alive = m;
             while (alive > 1) {
@@ -1347,6 +1485,7 @@ __global__ __launch_bounds__(kImgT) void greedy_nms_image_kernel(const GParams P
         }
         if (lane == 0) s_p = K;
     }
+    NTRACE(8);
     __syncthreads();
     const int K = s_p;
     // ---- output rows (RetinaNet.py:170-176): boxes / labels indexed by the FILTERED position in the UNFILTERED arrays
@@ -1358,7 +1497,12 @@ __global__ __launch_bounds__(kImgT) void greedy_nms_image_kernel(const GParams P
         row[5] = ckey[k]; row[6] = (float)P.label[o0 + k];
     }
     if (tid == 0) { P.out_counts[b * 2] = K; P.out_counts[b * 2 + 1] = n; }
+    NTRACE(9);
 }
+
+#ifdef ODPL_NMS_TRACE
+extern "C" int odpl_greedy_nms_trace(unsigned long long* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_nms_trace), &buf, sizeof(buf)); }
+#endif
 
 struct GPlan { size_t score, label, ckey, cidx, tile_cnt, ncand, total; int ntiles; };
 bool make_gplan(const odpl_greedy_nms_desc_t* d, GPlan* p) {

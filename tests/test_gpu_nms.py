@@ -282,3 +282,29 @@ def test_greedy_nms_longer_topk_takes_the_sweep_loop():
         assert o.shape == r.shape and o.shape[0] > 50
         assert torch.equal(o[:, 4], r[:, 4]) and torch.equal(o[:, 6], r[:, 6])
         assert torch.allclose(o[:, 5], r[:, 5], rtol=1e-6, atol=1e-7) and torch.allclose(o[:, :4], r[:, :4], rtol=1e-5, atol=1e-3)
+
+
+def test_greedy_nms_short_topk_with_ties_inside_the_key_list():
+    """[r4] the short way to the top 100 (bound from the threads' maxima -> LDS list of the keys at or above it -> order by counting):
+    30 000 candidates above the threshold on one image -- 60 distinct high scores, 200 candidates TIED at one score below them, everything
+    else lower and distinct.  The top 100 are the 60 + the first 40 of the ties in index order (RetinaNet.py:140-141: a stable descending
+    sort), in that order; vs the oracle.  A second image: 5 000 candidates, all distinct."""
+    from objectdetectionpl_amd.LightningFunc.nms import greedy_non_max_suppression
+    g = torch.Generator().manual_seed(123)
+    An, C = 30000, 4
+    anchors = torch.cat([torch.rand(An, 2, generator=g) * 3000 + 50, torch.rand(An, 2, generator=g) * 30 + 10], 1)
+    loc = torch.randn(2, An, 4, generator=g) * 0.05
+    cls = torch.full((2, An, C), -6.0)
+    cls[0, :, 1] = torch.rand(An, generator=g) * 1.5                   # everyone above 0.45 (sigmoid(0) = 0.5), distinct, below 0.82
+    perm = torch.randperm(An, generator=g)
+    cls[0, perm[:200], 2] = 2.0                                        # 200 ties at sigmoid(2.0) = 0.88
+    cls[0, perm[200:260], 3] = 3.0 + torch.rand(60, generator=g)       # 60 distinct better ones
+    cls[1, :5000, 0] = torch.rand(5000, generator=g) * 4.0
+    ref = oracle_retina.greedy_nms(loc, cls, anchors, topk=100, nms_thresh=0.5, class_thresh=0.45)
+    out = greedy_non_max_suppression((loc.cuda(), cls.cuda()), anchors.cuda())
+    for r, o in zip(ref, out):
+        o = o.cpu()
+        assert o.shape == r.shape and o.shape[0] > 50
+        assert torch.equal(o[:, 4], r[:, 4]) and torch.equal(o[:, 6], r[:, 6])
+        assert torch.allclose(o[:, 5], r[:, 5], rtol=1e-6, atol=1e-7)
+        assert torch.allclose(o[:, :4], r[:, :4], rtol=1e-5, atol=1e-3)
