@@ -107,7 +107,7 @@ def main():
     measure("config4 Retina greedy top-100 NMS", ["greedy_nms_prep", "greedy_nms_image"],
             lambda: nms.greedy_non_max_suppression((loc.detach(), cls_n), anchors),
             {"greedy_nms_prep": 4 * B * An * C + 8 * B * An}, {"greedy_nms_prep": "class rows read (LDS staged) + score/label write",
-                                                                 "greedy_nms_image": "1 WG/image"})
+                                                                 "greedy_nms_image": "[r4] scan + scatter + final (1 WG/image: short top-k, ballot overlap matrix, scalar greedy loop)"})
     del loc, cls, cls_n
     # ---- config 5: YOLOv5-l loss; heads as the reference hands them (contiguous [B,na,G,G,no] = "interleaved") and as the
     # permuted VIEW of the Detect convolution's NCHW output ("planar": what Yolo_Layers returns here)
