@@ -90,9 +90,9 @@ class Adam(torch.optim.Adam):
             c = self._tables(gi, params) if ok else None
             if c is None:
                 return super().step()   # one group outside the shape: the whole step is torch's (no parameter is stepped twice)
-            plans.append((group, c, grads, dev))
+            plans.append((group, c, grads, dev, params))
         L = _lib.lib()
-        for group, c, grads, dev in plans:
+        for group, c, grads, dev, params in plans:
             c["steps"].add_(1)          # torch._foreach_add_(state_steps, 1): here the counts are one vector
             d = _lib.AdamDesc()
             d.table, d.numel, d.blk0, d.blk_tensor = c["table"].data_ptr(), c["numel"].data_ptr(), c["blk0"].data_ptr(), c["blk_tensor"].data_ptr()
@@ -102,4 +102,7 @@ class Adam(torch.optim.Adam):
             d.lr, d.beta1, d.beta2, d.eps, d.weight_decay = float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"])
             ptrs = (ctypes.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
             _lib.check(L.odpl_adam_step(ctypes.byref(d), ptrs, _lib.current_stream(dev)), "odpl_adam_step")
+            # the kernel wrote the parameters through raw pointers: tell autograd, as torch's in-place update does (a backward through a
+            # graph that saved the old weights must raise, not silently use the new ones)
+            torch.autograd.graph.increment_version(params)
         return None

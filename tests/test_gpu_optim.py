@@ -95,3 +95,22 @@ def test_more_tensors_than_one_launch_carries():
     assert om._flat
     for p, q in zip(mine, ref):
         assert torch.equal(p, q)
+
+
+def test_adam_one_launch_step_bumps_the_parameters_version_counters():
+    """The kernel writes the parameters through raw pointers; autograd must still see an in-place update: a backward through a graph that
+    saved the OLD weights raises (as after torch.optim.Adam.step), it does not silently use the new ones."""
+    import pytest as _pt
+    from objectdetectionpl_amd.optim import Adam
+    d = torch.device("cuda:0")
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(8, 8).to(d)
+    opt = Adam(lin.parameters(), lr=1e-2)
+    x = torch.randn(4, 8, device=d, requires_grad=True)
+    lin(x).sum().backward()
+    v0 = lin.weight._version
+    y = lin(x)                                   # saves lin.weight for the backward wrt x
+    opt.step()
+    assert lin.weight._version > v0
+    with _pt.raises(RuntimeError, match="modified by an inplace operation"):
+        y.sum().backward()
