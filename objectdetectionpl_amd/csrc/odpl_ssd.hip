@@ -10,7 +10,12 @@
 //   * hard negatives without a sort: the k-th largest loss among the negatives by bisection on the float
 //     bits (losses are >= 0), ties taken in index order;
 //   * fixed-order reductions, no float atomics.
-// The tensors are small (8 732 x C per image): latency/occupancy bound, not HBM bound.
+// The tensors are small (8 732 x C per image): latency/occupancy bound, not HBM bound.  [r4] timed phase by phase with wall-clock
+// stamps (tools/time_ssd_loss.py --trace, a -DODPL_SSD_TRACE build) at B = 32, 21 classes, 8 boxes per image: 375 -> 154 us --
+//   image ids all-against-all by every thread out of LDS (40 -> 9 us); both matchings in one pass over the IoUs, eight annotations at a
+//   time (60 -> 38); logits through an LDS tile with the next tile prefetched into registers, eight row elements in flight, the
+//   hardware exponential (109 -> 57); the hard-negative threshold by a three-level radix select on the loss bits instead of 31 block-wide
+//   counts (34 -> 18); loss sums and gradient rows over the compacted list of active priors, one thread per active prior (104 -> 20).
 #include "odpl_common.hpp"
 #include "odpl_boxes_dev.hpp"
 #include "../../include/odpl_hip.h"
@@ -27,11 +32,34 @@ struct SParams {
     float thresh;
     float* loss; int* ann; int* flag;         // [B*P] per prior: CE loss, annotation index, bit0 matched bit1 selected-negative
     int* best_prior;                          // [B*nT]
+    int* list;                                // [B*P] scratch: the active priors of an image (dense mode; rows-only writes them to `active`)
     float* part;                              // [B*2]
     int* meta;                                // [0] new_batch_size, [1] status
     float* out3; int* out_counts;
+    int tile_rows;                                      // rows of logits per LDS tile (0: C too wide)
     int rows_only; int* active; int* active_count;      // ODPL_SSD_ROWS_ONLY: gradients on the active rows only + their list per image
 };
+
+// Row maximum and sum of exponentials of C logits, eight loads in flight at a time (a plain `for k < C` loop waits for every load -- LDS
+// or L1 -- before issuing the next: 42 round trips per 21-class row); same order of operations as the plain loops.
+__device__ __forceinline__ void row_max_sumexp(const float* x, int C, float& mx, float& se) {
+    mx = -INFINITY;
+    for (int k0 = 0; k0 < C; k0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = x[k0 + u < C ? k0 + u : C - 1];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (k0 + u < C) mx = fmaxf(mx, v[u]);
+    }
+    se = 0.f;
+    for (int k0 = 0; k0 < C; k0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = x[k0 + u < C ? k0 + u : C - 1];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (k0 + u < C) se += __expf(v[u] - mx);
+    }
+}
 
 __device__ __forceinline__ Box4 clamp_points(float cx, float cy, float w, float h) {
     Box4 b;                                   // losses.py:180-181
@@ -68,31 +96,68 @@ __device__ __forceinline__ float block_sum_f(float v, float* sh) {
     return t;
 }
 
+#ifdef ODPL_SSD_TRACE
+__device__ unsigned long long* g_ssd_trace = nullptr;                      // [B][16] wall-clock stamps (100 MHz)
+#define STRACE(slot) do { if (g_ssd_trace && threadIdx.x == 0) g_ssd_trace[(size_t)blockIdx.x * 16 + (slot)] = wall_clock64(); } while (0)
+#else
+#define STRACE(slot) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(kT) void ssd_image_kernel(const SParams P) {
     __shared__ unsigned char s_first[kMaxT];
     __shared__ int s_i[kT / 64];
     __shared__ float s_f[kT / 64];
     __shared__ float s_bv[kT / 64]; __shared__ int s_bi[kT / 64];
     __shared__ int s_run;
+    STRACE(0);
     const int j = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int np = P.P, C = P.C, nT = P.nT;
     const size_t p0 = (size_t)j * np;
     float* loss = P.loss + p0; int* ann = P.ann + p0; int* flag = P.flag + p0;
-    // ---- lens[j] (losses.py:286-288): distinct image ids in ascending order
-    for (int t = tid; t < nT; t += kT) {
-        const float x = P.target[(size_t)t * 6];
-        bool first = true;
-        for (int u = 0; u < t; ++u) if (P.target[(size_t)u * 6] == x) { first = false; break; }
-        s_first[t] = first;
-    }
-    __syncthreads();
+    // ---- lens[j] (losses.py:286-288): distinct image ids in ascending order.  The ids are compared all against all: out of LDS (the
+    //      logits' tile, free until the classification pass) instead of nT dependent trips to L2 per thread (40 us at 256 rows)
+    extern __shared__ __align__(16) float s_tile[];
     int cD = 0, cM = 0;
-    for (int t = tid; t < nT; t += kT) {
-        const float x = P.target[(size_t)t * 6];
-        cD += s_first[t];
-        int rank = 0;
-        for (int u = 0; u < nT; ++u) rank += (s_first[u] && P.target[(size_t)u * 6] < x);
-        cM += (rank == j);
+    if (3 * nT <= P.tile_rows * C && nT <= kT) {
+        // every thread takes part: thread (t, part) scans a slice of the rows for row t; LDS integer atomics combine the slices
+        float* s_id = s_tile; int* s_dup = reinterpret_cast<int*>(s_tile) + nT; int* s_rank = s_dup + nT;
+        for (int t = tid; t < nT; t += kT) { s_id[t] = P.target[(size_t)t * 6]; s_dup[t] = 0; s_rank[t] = 0; }
+        __syncthreads();
+        int tpad = 1; while (tpad < nT) tpad <<= 1;
+        const int parts = kT / tpad, t = tid & (tpad - 1), part = tid / tpad;
+        const int per = (nT + parts - 1) / parts, u0 = part * per, u1 = u0 + per < nT ? u0 + per : nT;
+        if (t < nT) {
+            const float x = s_id[t];
+            int dup = 0;
+            for (int u = u0; u < u1 && u < t; ++u) dup |= (s_id[u] == x);
+            if (dup) atomicOr(&s_dup[t], 1);
+        }
+        __syncthreads();
+        if (tid < nT) s_first[tid] = s_dup[tid] == 0;
+        __syncthreads();
+        if (t < nT) {
+            const float x = s_id[t];
+            int r = 0;
+            for (int u = u0; u < u1; ++u) r += (s_first[u] && s_id[u] < x);
+            if (r) atomicAdd(&s_rank[t], r);
+        }
+        __syncthreads();
+        if (tid < nT) { cD = s_first[tid]; cM = (s_rank[tid] == j); }
+    } else {
+        for (int t = tid; t < nT; t += kT) {
+            const float x = P.target[(size_t)t * 6];
+            bool first = true;
+            for (int u = 0; u < t; ++u) if (P.target[(size_t)u * 6] == x) { first = false; break; }
+            s_first[t] = first;
+        }
+        __syncthreads();
+        for (int t = tid; t < nT; t += kT) {
+            const float x = P.target[(size_t)t * 6];
+            cD += s_first[t];
+            int rank = 0;
+            for (int u = 0; u < nT; ++u) rank += (s_first[u] && P.target[(size_t)u * 6] < x);
+            cM += (rank == j);
+        }
     }
     const int D = block_sum_i(cD, s_i);
     const int M = block_sum_i(cM, s_i);
@@ -107,6 +172,70 @@ __global__ __launch_bounds__(kT) void ssd_image_kernel(const SParams P) {
         if (tid == 0) { P.part[j * 2] = 0.f; P.part[j * 2 + 1] = 0.f; if (want && P.rows_only) P.active_count[j] = 0; }
         return;
     }
+    STRACE(1);
+    int* bestp = P.best_prior + (size_t)j * (nT > 0 ? nT : 1);
+    constexpr int kHoldP = 16, kAnn = 8;
+    if (np <= kHoldP * kT) {
+        // ---- both matchings in ONE pass over the IoUs (losses.py:210-214): eight annotations at a time, every IoU is computed once and
+        //      feeds the prior's best annotation (first maximum over the annotations, held in registers across the chunks) and the
+        //      annotation's best prior (first maximum over the priors: thread-local in ascending order, then (value desc, index asc)
+        //      reductions).  Two barriers per eight annotations instead of two per annotation + a second sweep of the IoUs.
+        __shared__ float s_cbv[kT / 64][kAnn]; __shared__ int s_cbi[kT / 64][kAnn];
+        float pbest[kHoldP]; int pbi[kHoldP];
+#pragma unroll
+        for (int u = 0; u < kHoldP; ++u) { pbest[u] = 0.f; pbi[u] = 0; }
+        for (int m0 = 0; m0 < M; m0 += kAnn) {
+            Box4 ab[kAnn];
+#pragma unroll
+            for (int a = 0; a < kAnn; ++a) {
+                const float* y = P.target + (size_t)(m0 + a < M ? m0 + a : M - 1) * 6;
+                ab[a] = clamp_points(y[2], y[3], y[4], y[5]);
+            }
+            float bv[kAnn]; int bp[kAnn]; bool have[kAnn];
+#pragma unroll
+            for (int a = 0; a < kAnn; ++a) { bv[a] = -INFINITY; bp[a] = 0x7fffffff; have[a] = false; }
+#pragma unroll
+            for (int u = 0; u < kHoldP; ++u) {
+                const int p = tid + u * kT;
+                if (p < np) {
+                    const float4 d = reinterpret_cast<const float4*>(P.priors)[p];
+                    const Box4 pb = clamp_points(d.x, d.y, d.z, d.w);
+#pragma unroll
+                    for (int a = 0; a < kAnn; ++a) {
+                        if (m0 + a < M) {
+                            const float v = iou_corner(pb, ab[a]);
+                            if (m0 + a == 0 || (pbest[u] == pbest[u] && (v > pbest[u] || v != v))) { pbest[u] = v; pbi[u] = m0 + a; }
+                            if (!have[a] || (bv[a] == bv[a] && (v > bv[a] || v != v))) { bv[a] = v; bp[a] = p; have[a] = true; }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < kAnn; ++a) {
+                for (int o = 32; o > 0; o >>= 1) {          // (value desc, index asc); NaN treated as largest
+                    const float ov = __shfl_down(bv[a], o, 64); const int oi = __shfl_down(bp[a], o, 64);
+                    if (better(ov, oi, bv[a], bp[a])) { bv[a] = ov; bp[a] = oi; }
+                }
+                if (lane == 0) { s_cbv[wv][a] = bv[a]; s_cbi[wv][a] = bp[a]; }
+            }
+            __syncthreads();
+            if (tid < kAnn && m0 + tid < M) {
+                float v = s_cbv[0][tid]; int i = s_cbi[0][tid];
+                for (int w = 1; w < kT / 64; ++w) {
+                    const float ov = s_cbv[w][tid]; const int oi = s_cbi[w][tid];
+                    if (better(ov, oi, v, i)) { v = ov; i = oi; }
+                }
+                bestp[m0 + tid] = i;
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int u = 0; u < kHoldP; ++u) {
+            const int p = tid + u * kT;
+            if (p < np) { ann[p] = pbi[u]; flag[p] = pbest[u] >= P.thresh ? 1 : 0; }      // losses.py:214
+        }
+        STRACE(2);
+    } else {
     // ---- per prior: best annotation (max over dim 0, first index), losses.py:213
     for (int p = tid; p < np; p += kT) {
         const float4 d = reinterpret_cast<const float4*>(P.priors)[p];
@@ -120,8 +249,8 @@ __global__ __launch_bounds__(kT) void ssd_image_kernel(const SParams P) {
         ann[p] = bi;
         flag[p] = best >= P.thresh ? 1 : 0;                 // losses.py:214
     }
+    STRACE(2);
     // ---- per annotation: best prior (max over dim 1, first index), losses.py:210
-    int* bestp = P.best_prior + (size_t)j * (nT > 0 ? nT : 1);
     for (int m = 0; m < M; ++m) {
         const float* y = P.target + (size_t)m * 6;
         const Box4 ab = clamp_points(y[2], y[3], y[4], y[5]);
@@ -147,22 +276,56 @@ __global__ __launch_bounds__(kT) void ssd_image_kernel(const SParams P) {
             bestp[m] = i;
         }
     }
+    }
     __syncthreads();
     if (tid == 0) {                                         // losses.py:215-216, sequential: last annotation wins
         for (int m = 0; m < M; ++m) { const int p = bestp[m]; flag[p] |= 1; ann[p] = m; }
     }
     __syncthreads();
     // ---- per prior classification loss (reduction='none'), N
+    STRACE(3);
+    // The logits go through an LDS tile: the rows are C floats (84 bytes at 21 classes), so a thread per row reading global memory
+    // directly spreads every load instruction over 64 cache lines (160 us of the 400 this kernel took at B = 32); a tile is copied
+    // flat (coalesced) and each thread then reads ITS row out of LDS (row stride C words: conflict-free for odd C).
+    const int tile_rows = P.tile_rows;                      // 0: C too wide for a tile -> rows straight from global memory
     int cN = 0, bad = 0;
-    for (int p = tid; p < np; p += kT) {
-        const int matched = flag[p] & 1;
+    // the NEXT tile's floats wait in registers while this one is worked on (a tile is <= 48 KB = 12 floats per thread): the trip to
+    // memory of tile i + 1 runs under the arithmetic of tile i
+    constexpr int kPre = 12;
+    float pre[kPre];
+    auto fetch = [&](int r0) {
+        const int ne = (np - r0 < tile_rows ? np - r0 : tile_rows) * C;
+        const float* src = P.cls + (p0 + r0) * C;
+#pragma unroll
+        for (int u = 0; u < kPre; ++u) { const int e = tid + u * kT; pre[u] = e < ne ? src[e] : 0.f; }
+    };
+    if (tile_rows) fetch(0);
+    for (int r0 = 0; r0 < np; r0 += (tile_rows ? tile_rows : kT)) {
+        int p;
+        const float* x;
+        int fl = 0, an = 0;                                 // this row's match: loaded before the barriers, its class under the arithmetic
+        if (tile_rows) {
+            const int nr = np - r0 < tile_rows ? np - r0 : tile_rows;
+            if (tid < nr) { fl = flag[r0 + tid]; an = ann[r0 + tid]; }
+            __syncthreads();                                // the previous tile is consumed
+#pragma unroll
+            for (int u = 0; u < kPre; ++u) { const int e = tid + u * kT; if (e < nr * C) s_tile[e] = pre[u]; }
+            __syncthreads();
+            if (r0 + tile_rows < np) fetch(r0 + tile_rows);
+            if (tid >= nr) continue;
+            p = r0 + tid; x = s_tile + (size_t)tid * C;
+        } else {
+            p = r0 + tid;
+            if (p >= np) continue;
+            x = P.cls + (p0 + p) * C;
+            fl = flag[p]; an = ann[p];
+        }
+        const int matched = fl & 1;
         cN += matched;
-        long long yv = matched ? trunc_ll(P.target[(size_t)ann[p] * 6 + 1]) : 0;      // losses.py:252-253
-        const float* x = P.cls + (p0 + p) * C;
-        float mx = -INFINITY;
-        for (int k = 0; k < C; ++k) mx = fmaxf(mx, x[k]);
-        float se = 0.f;
-        for (int k = 0; k < C; ++k) se += expf(x[k] - mx);
+        const float cls_id = matched ? P.target[(size_t)an * 6 + 1] : 0.f;
+        float mx, se;
+        row_max_sumexp(x, C, mx, se);
+        long long yv = matched ? trunc_ll(cls_id) : 0;      // losses.py:252-253
         float l = 0.f;
         if (P.cls_mode == ODPL_CLS_CE) {
             if (yv < 0 || yv >= C) { bad = 1; yv = 0; }
@@ -179,6 +342,7 @@ __global__ __launch_bounds__(kT) void ssd_image_kernel(const SParams P) {
     }
     const int N = block_sum_i(cN, s_i);
     bad = __syncthreads_or(bad);
+    STRACE(4);
     // ---- hard negatives (CE only; in focal mode background rows are exactly 0)
     int k = 0; unsigned T = 0; int cgt = 0;
     if (P.cls_mode == ODPL_CLS_CE) {
@@ -186,17 +350,69 @@ __global__ __launch_bounds__(kT) void ssd_image_kernel(const SParams P) {
         k = P.neg_ratio * N < nneg ? P.neg_ratio * N : nneg;
         if (k > 0) {
             unsigned lo = 0u, hi = 0x7f800000u;             // largest T with count(neg bits >= T) >= k
-            while (lo < hi) {
-                const unsigned mid = lo + (hi - lo + 1) / 2;
-                int c = 0;
-                for (int p = tid; p < np; p += kT) c += (!(flag[p] & 1) && __float_as_uint(loss[p]) >= mid);
-                c = block_sum_i(c, s_i);
-                if (c >= k) lo = mid; else hi = mid - 1;
+            // the negatives' loss bits of this thread's priors stay in registers over the ~31 steps (8 732 priors: nine per thread);
+            // a matched prior is entered as 0, which no step counts (mid >= 1)
+            constexpr int kHold = 16;
+            const bool held = np <= kHold * kT;
+            unsigned lb[kHold];
+#pragma unroll
+            for (int u = 0; u < kHold; ++u) {
+                const int p = tid + u * kT;
+                lb[u] = (held && p < np && !(flag[p] & 1)) ? __float_as_uint(loss[p]) : 0u;
+            }
+            if (held && P.tile_rows * C >= 2048) {
+                // radix select on the loss bits (losses are >= 0: the bits order like the values): three levels of an LDS histogram of
+                // 2 048 bins (the logits' tile is free now) + a suffix scan, instead of 31 bisection steps of a block-wide count each
+                int* hist = reinterpret_cast<int*>(s_tile);
+                __shared__ int s_selb[2];
+#pragma unroll
+                for (int u = 0; u < kHold; ++u) { const int p = tid + u * kT; if (!(held && p < np && !(flag[p] & 1))) lb[u] = 0xffffffffu; }   // not a negative: outside every range
+                unsigned base = 0u; int span_log = 31, shift = 20, c_above = 0;
+                for (;;) {
+                    hist[tid] = 0; hist[tid + kT] = 0;
+                    __syncthreads();
+#pragma unroll
+                    for (int u = 0; u < kHold; ++u) { const unsigned d = lb[u] - base; if (lb[u] >= base && (d >> span_log) == 0u) atomicAdd(&hist[d >> shift], 1); }
+                    __syncthreads();
+                    const int h0 = hist[2 * tid], h1 = hist[2 * tid + 1];
+                    int inc = h0 + h1;                               // inclusive suffix over threads tid .. 1023
+                    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_down(inc, o, 64); if (lane + o < 64) inc += v; }
+                    if (lane == 0) s_i[wv] = inc;
+                    __syncthreads();
+                    int above = 0;
+                    for (int w2 = wv + 1; w2 < kT / 64; ++w2) above += s_i[w2];
+                    const int S0 = c_above + above + inc, S1 = S0 - h0, S2 = S1 - h1;
+                    if (S1 >= k && S2 < k) { s_selb[0] = 2 * tid + 1; s_selb[1] = S2; }
+                    else if (S0 >= k && S1 < k) { s_selb[0] = 2 * tid; s_selb[1] = S1; }
+                    __syncthreads();
+                    base += (unsigned)s_selb[0] << shift; c_above = s_selb[1];
+                    __syncthreads();
+                    if (shift == 0) break;
+                    span_log = shift; shift = shift > 11 ? shift - 11 : 0;
+                }
+                lo = base; cgt = c_above;                            // largest T with count(bits >= T) >= k; count(bits > T)
+                if (lo > hi) lo = hi;                                // (a NaN loss: the bisection's upper end)
+            } else {
+                while (lo < hi) {
+                    const unsigned mid = lo + (hi - lo + 1) / 2;
+                    int c = 0;
+                    if (held) {
+#pragma unroll
+                        for (int u = 0; u < kHold; ++u) c += lb[u] >= mid;
+                    } else {
+                        for (int p = tid; p < np; p += kT) c += (!(flag[p] & 1) && __float_as_uint(loss[p]) >= mid);
+                    }
+                    c = block_sum_i(c, s_i);
+                    if (c >= k) lo = mid; else hi = mid - 1;
+                }
+                cgt = -1;
             }
             T = lo;
-            int c = 0;
-            for (int p = tid; p < np; p += kT) c += (!(flag[p] & 1) && __float_as_uint(loss[p]) > T);
-            cgt = block_sum_i(c, s_i);
+            if (cgt < 0 || T == 0x7f800000u) {
+                int c = 0;
+                for (int p = tid; p < np; p += kT) c += (!(flag[p] & 1) && __float_as_uint(loss[p]) > T);
+                cgt = block_sum_i(c, s_i);
+            }
             // select: all > T, then ties == T in index order until k
             if (tid == 0) s_run = cgt;
             __syncthreads();
@@ -218,27 +434,38 @@ __global__ __launch_bounds__(kT) void ssd_image_kernel(const SParams P) {
             }
         }
     }
+    STRACE(5);
     // ---- sums (fixed thread-strided order) and gradients
     const float w = 1.0f / ((float)N * (float)new_bs);
     float a_cls = 0.f, a_reg = 0.f;
     const bool rows_only = want && P.rows_only;
+    if (want && !rows_only) {                               // the dense gradients' zeros as two flat (coalesced) streams; the active rows follow
+        for (size_t e = tid; e < (size_t)np * C; e += kT) P.g_cls[p0 * C + e] = 0.f;
+        for (size_t e = tid; e < (size_t)np * 4; e += kT) P.g_off[p0 * 4 + e] = 0.f;
+        __syncthreads();                                    // (block-wide ordering of the stores to one address)
+    }
+    STRACE(6);
+    // The active priors (positives + mined negatives: ~7 % of the priors) are listed first, in index order (ballot prefix over the block),
+    // and the loss sums / gradient rows then run over the LIST, one thread per active prior: with a thread per prior every wave
+    // walked the two softmax passes for its four or five active lanes (104 us of this kernel's 375 at B = 32).
+    int* lst = (P.rows_only && P.active) ? P.active + p0 : P.list + p0;
     int n_act = 0;                                          // active priors listed so far (uniform)
     for (int pb = 0; pb < np; pb += kT) {
         const int p = pb + tid;
-        if (rows_only) {                                    // the image's active priors in index order (ballot prefix over the block)
-            const bool act = p < np && (flag[p] & 3);
-            const unsigned long long mk = __ballot(act);
-            __syncthreads();
-            if (lane == 0) s_i[wv] = __popcll(mk);
-            __syncthreads();
-            int offc = n_act, tot = 0;
-            for (int w2 = 0; w2 < kT / 64; ++w2) { if (w2 < wv) offc += s_i[w2]; tot += s_i[w2]; }
-            if (act) P.active[p0 + offc + __popcll(mk & ((1ull << lane) - 1ull))] = p;
-            n_act += tot;
-        }
-        if (p >= np) continue;
+        const bool act = p < np && (flag[p] & 3);
+        const unsigned long long mk = __ballot(act);
+        __syncthreads();
+        if (lane == 0) s_i[wv] = __popcll(mk);
+        __syncthreads();
+        int offc = n_act, tot = 0;
+        for (int w2 = 0; w2 < kT / 64; ++w2) { if (w2 < wv) offc += s_i[w2]; tot += s_i[w2]; }
+        if (act) lst[offc + __popcll(mk & ((1ull << lane) - 1ull))] = p;
+        n_act += tot;
+    }
+    __syncthreads();                                        // the list is read back by other threads of the block
+    for (int li = tid; li < n_act; li += kT) {
+        const int p = lst[li];
         const int f = flag[p];
-        if (rows_only && !(f & 3)) continue;                // nothing to add to the sums, no gradient row to write
         const float* x = P.cls + (p0 + p) * C;
         float* gx = want ? P.g_cls + (p0 + p) * C : nullptr;
         float* go = want ? P.g_off + (p0 + p) * 4 : nullptr;
@@ -246,13 +473,17 @@ __global__ __launch_bounds__(kT) void ssd_image_kernel(const SParams P) {
             a_cls += loss[p];
             if (want) {
                 long long yv = (f & 1) ? trunc_ll(P.target[(size_t)ann[p] * 6 + 1]) : 0;
-                float mx = -INFINITY;
-                for (int q = 0; q < C; ++q) mx = fmaxf(mx, x[q]);
-                float se = 0.f;
-                for (int q = 0; q < C; ++q) se += expf(x[q] - mx);
+                float mx, se;
+                row_max_sumexp(x, C, mx, se);
                 if (P.cls_mode == ODPL_CLS_CE) {
                     if (yv < 0 || yv >= C) yv = 0;
-                    for (int q = 0; q < C; ++q) gx[q] = (expf(x[q] - mx) / se - (q == yv ? 1.0f : 0.0f)) * w;
+                    for (int q0 = 0; q0 < C; q0 += 8) {
+                        float v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) v[u] = x[q0 + u < C ? q0 + u : C - 1];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) if (q0 + u < C) gx[q0 + u] = (__expf(v[u] - mx) / se - (q0 + u == yv ? 1.0f : 0.0f)) * w;
+                    }
                 } else {
                     if (yv < 0 || yv > C) yv = 0;
                     if (yv >= 1) {
@@ -267,8 +498,6 @@ __global__ __launch_bounds__(kT) void ssd_image_kernel(const SParams P) {
                     }
                 }
             }
-        } else if (want) {
-            for (int q = 0; q < C; ++q) gx[q] = 0.f;
         }
         if (f & 1) {                                        // losses.py:220-236, 250
             const float4 d = reinterpret_cast<const float4*>(P.priors)[p];
@@ -281,10 +510,11 @@ __global__ __launch_bounds__(kT) void ssd_image_kernel(const SParams P) {
                 a_reg += coord_elem(dd, P.coord_sl1);
                 if (want) go[q] = coord_deriv(dd, P.coord_sl1) * w;
             }
-        } else if (want) {
-            go[0] = go[1] = go[2] = go[3] = 0.f;
+        } else if (rows_only) {
+            go[0] = go[1] = go[2] = go[3] = 0.f;            // a listed hard negative: its box row is read by the heads' backward
         }
     }
+    STRACE(7);
     a_cls = block_sum_f(a_cls, s_f);
     a_reg = block_sum_f(a_reg, s_f);
     if (rows_only && tid == 0) P.active_count[j] = n_act;
@@ -294,6 +524,10 @@ __global__ __launch_bounds__(kT) void ssd_image_kernel(const SParams P) {
         if (bad) atomicOr(&P.meta[1], 1);
     }
 }
+
+#ifdef ODPL_SSD_TRACE
+extern "C" int odpl_ssd_trace(unsigned long long* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ssd_trace), &buf, sizeof(buf)); }
+#endif
 
 __global__ void ssd_finalize_kernel(const SParams P) {
     if (threadIdx.x != 0) return;
@@ -336,7 +570,7 @@ __global__ __launch_bounds__(256) void ssd_level_lists_kernel(const LevelP L) {
 }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-struct SPlan { size_t meta, loss, ann, flag, best, part, total; };
+struct SPlan { size_t meta, loss, ann, flag, list, best, part, total; };
 bool make_splan(const odpl_ssd_loss_desc_t* d, SPlan* p) {
     if (!d || d->B < 1 || d->P < 1 || d->C < 1 || d->nT < 1 || d->nT > kMaxT) return false;
     if (!d->off || !d->cls || !d->priors || !d->target) return false;
@@ -349,6 +583,7 @@ bool make_splan(const odpl_ssd_loss_desc_t* d, SPlan* p) {
     p->loss = off; off += align_up(BP * 4, 256);
     p->ann = off;  off += align_up(BP * 4, 256);
     p->flag = off; off += align_up(BP * 4, 256);
+    p->list = off; off += align_up(BP * 4, 256);
     p->best = off; off += align_up((size_t)d->B * d->nT * 4, 256);
     p->part = off; off += align_up((size_t)d->B * 8, 256);
     p->total = off;
@@ -372,12 +607,18 @@ extern "C" int odpl_ssd_loss(const odpl_ssd_loss_desc_t* d, void* workspace, siz
     P.off = d->off; P.cls = d->cls; P.g_off = d->grad_off; P.g_cls = d->grad_cls; P.priors = d->priors; P.target = d->target;
     P.B = d->B; P.P = d->P; P.C = d->C; P.nT = d->nT; P.cls_mode = d->cls_mode; P.coord_sl1 = d->coord_mode == ODPL_COORD_SMOOTH_L1;
     P.neg_ratio = 3; P.thresh = 0.5f;
-    P.loss = (float*)(ws + pl.loss); P.ann = (int*)(ws + pl.ann); P.flag = (int*)(ws + pl.flag);
+    P.loss = (float*)(ws + pl.loss); P.ann = (int*)(ws + pl.ann); P.flag = (int*)(ws + pl.flag); P.list = (int*)(ws + pl.list);
     P.best_prior = (int*)(ws + pl.best); P.part = (float*)(ws + pl.part); P.meta = (int*)(ws + pl.meta);
     P.out3 = out3; P.out_counts = out_counts;
     P.rows_only = (d->flags & ODPL_SSD_ROWS_ONLY) ? 1 : 0; P.active = d->active; P.active_count = d->active_count;
     ODPL_HIP_TRY(odpl::fill_bytes(P.meta, 0, 256, stream));
-    hipLaunchKernelGGL(ssd_image_kernel, dim3(d->B), dim3(kT), 0, stream, P);
+    {   // LDS tile of the logits: <= 48 KB, a multiple of 64 rows, at most one row per thread
+        int rows = (48 * 1024) / (4 * d->C);
+        rows = rows / 64 * 64;
+        if (rows > kT) rows = kT;
+        P.tile_rows = rows >= 64 ? rows : 0;
+    }
+    hipLaunchKernelGGL(ssd_image_kernel, dim3(d->B), dim3(kT), (size_t)P.tile_rows * d->C * sizeof(float), stream, P);
     ODPL_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(ssd_finalize_kernel, dim3(1), dim3(64), 0, stream, P);
     ODPL_HIP_TRY(hipGetLastError());
