@@ -118,7 +118,7 @@ class SSD(_Base):
         out_cl, out_bbx = [], []
         src = self.f1(x)
         cls_convs, box_convs = [getattr(self, f"cl{i}")[0] for i in range(1, 7)], [getattr(self, f"bbx{i}")[0] for i in range(1, 7)]
-        if (_ssdhead.enabled and x.is_cuda and torch.is_grad_enabled() and all(len(getattr(self, f"{p}{i}")) == 1 for i in range(1, 7) for p in ("cl", "bbx"))
+        if (_ssdhead.enabled and x.is_cuda and torch.is_grad_enabled() and not torch.is_autocast_enabled() and x.dtype == torch.float32 and all(len(getattr(self, f"{p}{i}")) == 1 for i in range(1, 7) for p in ("cl", "bbx"))
                 and all(_ssdhead.is_hostable(c) for c in cls_convs + box_convs)):
             # the twelve head convolutions hosted in one autograd node: SSDLoss may then run their backward from the rows that carry a gradient
             sources = [src]

@@ -221,3 +221,23 @@ def test_ssd_loss_vs_oracle_over_the_kernel_s_routes(C, Pn, B, per_image):
         got, want = got.cpu().numpy(), want.numpy()
         assert np.array_equal(got != 0, want != 0), name                          # matched set / mined negatives: index work
         assert np.allclose(got, want, rtol=2e-4, atol=1e-6 * np.abs(want).max() + 1e-12), (name, np.abs(got - want).max())
+
+
+def test_ssd_model_under_autocast_keeps_the_plain_head_modules():
+    """The hosted head node runs aten::convolution_backward itself: under autocast (bf16 activations, fp32 master weights) the model
+    therefore takes the reference's plain modules and the step still trains."""
+    from types import SimpleNamespace
+    from objectdetectionpl_amd.model.SSD import SSD
+    d = torch.device("cuda:0")
+    args = SimpleNamespace(model_name="SSD", cls_criterion="ce_loss", coord_criterion="smooth_l1_loss", data_module="synthetic", lr=1e-3, weight_decay=1e-5)
+    torch.manual_seed(0)
+    model = SSD([str(i) for i in range(21)], args).to(d).to(memory_format=torch.channels_last).train()
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(2, 3, 300, 300, generator=g).to(d).contiguous(memory_format=torch.channels_last)
+    y = _ssd_targets(g, 2, 1, 21).to(d)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = model(x)
+    assert not hasattr(out[0], "_odpl_ssd_src") and out[1].dtype == torch.bfloat16
+    loss = model.criterion(out, y)["loss"]
+    loss.backward()
+    assert torch.isfinite(loss) and all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
