@@ -368,7 +368,7 @@ class SSDLoss(nn.Module):
         return out3, counts
 
     fuse_head_backward = True      # class switch: False = always hand autograd the dense d loss/d preds
-    # the structured route pays only while the gradient is sparse (utils/ssdhead.py: a tie at 2 boxes per image, 2 % faster at 1, 8 % slower
+    # the structured route pays only while the gradient is sparse (utils/ssdhead.py: 2 % slower at 2 boxes per image, 2 % faster at 1, 11 % slower
     # at 8): taken when the batch holds at most this many target rows per image (a host-side number: no sync); None = whenever possible
     structured_max_boxes_per_image = 1.5
 

@@ -21,9 +21,9 @@ from ... import _lib
 # SSDLoss's choice (`SSDLoss.structured_max_boxes_per_image`), because the structured one only pays on sparse gradients: measured on SSD300
 # (B = 32, fp32, tools/bench_ssd_step.py, profiles/r04_ssd_step_ab.jsonl) the loss's gradient lives on positives + 3:1 mined negatives --
 # ~600 priors per image with 8 boxes (7 % of 8 732; ~19 000 rows per step), and from that many rows the gathered VALU products
-# (rh_dw / rh_dx / rh_pair: 8.6 ms) cost more than MIOpen's dense MFMA backward of the twelve convolutions: 73.1 vs 67.4 ms per step at
-# 8 boxes per image, 70.2 vs 67.2 at 4, 68.6 vs 67.2 at 3, a tie at 2, 65.7 vs 67.2 ms at 1.  RetinaNet's heads (863 rows of 802 800,
-# config 4) are where the same kernels win outright.
+# (rh_dw / rh_dx / rh_pair: 8.6 ms) cost more than MIOpen's dense MFMA backward of the twelve convolutions: 61.6 vs 55.4 ms per step at
+# 8 boxes per image, 56.2 vs 55.3 at 2, 54.4 vs 55.3 ms at 1 (with SSD's convolution problems in the committed MIOpen db; before they
+# were: 73.1 vs 67.4, a tie at 2, 65.7 vs 67.2).  RetinaNet's heads (863 rows of 802 800, config 4) are where the same kernels win outright.
 enabled = True
 
 
