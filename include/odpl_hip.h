@@ -165,7 +165,7 @@ int odpl_head_conv_backward(const odpl_head_conv_t* head, const odpl_sparse_grad
                             size_t workspace_bytes, void* stream);
 /* All heads of a model in ONE pair of launches (same A and dtype on every head, n <= ODPL_MAX_SCALES); `heads` / `grads`
  * are host arrays.  Limits: A <= 5 anchors per head, no <= 4096, N * Cin < 2^33; any number of rows (the finish launch walks
- * row lists longer than 4096 in chunks).  The *_workspace_bytes queries return 0 for a descriptor outside them -- callers probe
+ * row lists longer than 1 792 rows in chunks).  The *_workspace_bytes queries return 0 for a descriptor outside them -- callers probe
  * with it BEFORE choosing this route (utils/headconv.py: structured_backward_supported) and otherwise take the dense route
  * (odpl_yolo_region_loss_backward / odpl_yolov5_loss_backward + a generic convolution backward).  The queries read no device
  * memory: pointers only need to be non-NULL. */
